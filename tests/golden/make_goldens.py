@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures.  Runs ONLY in the build container (needs /root/reference).
+
+Fixtures are data (seeds, inputs, expected outputs) — never reference source.
+
+  dpt_head_ref.npz   outputs of the REFERENCE's own DPTNeckHeadForUnetAfterUpsampleIdentity
+                     (/root/reference/genpercept/models/dpt_head.py) on seeded weights/inputs.  `diffusers` is not
+                     installed, so the two symbols dpt_head.py imports from it (LoRACompatibleConv, USE_PEFT_BACKEND;
+                     dpt_head.py:20-21,130) are provided by a stub module.
+  metrics_ref.npz    outputs of the REFERENCE's src/util/metric.py + src/util/alignment.py on seeded arrays.
+  e2e_tiny.npz       end-to-end goldens of the fp32 oracle (oracle/) on the tiny configs: inputs + expected outputs
+                     for every stage (latent, unet out, feats, decode, final) — what the HIP path is checked against
+                     on the GPU box where neither /root/reference nor large weights exist.
+
+Weights are regenerated from seeds by oracle.sd21.synth_state_dict (deterministic for a fixed torch build).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from oracle import dpt as odpt  # noqa: E402
+from oracle import pipeline as opipe  # noqa: E402
+from oracle import sd21 as osd  # noqa: E402
+
+
+def _stub_diffusers():
+    d = types.ModuleType("diffusers")
+    dm = types.ModuleType("diffusers.models")
+    dl = types.ModuleType("diffusers.models.lora")
+    du = types.ModuleType("diffusers.utils")
+    dl.LoRACompatibleConv = torch.nn.Conv2d
+    du.USE_PEFT_BACKEND = True
+    d.models, dm.lora, d.utils = dm, dl, du
+    sys.modules.update({"diffusers": d, "diffusers.models": dm, "diffusers.models.lora": dl, "diffusers.utils": du})
+
+
+def make_dpt_golden():
+    _stub_diffusers()
+    sys.path.insert(0, REF)
+    from transformers import DPTConfig
+    import importlib.util
+    # load the file directly: genpercept/__init__.py imports the whole pipeline (needs real diffusers/torchvision)
+    spec = importlib.util.spec_from_file_location("ref_dpt_head", os.path.join(REF, "genpercept/models/dpt_head.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    DPTNeckHeadForUnetAfterUpsampleIdentity = mod.DPTNeckHeadForUnetAfterUpsampleIdentity
+
+    import json
+    with open(os.path.join(REF, "hf_configs/dpt-sd2.1-unet-after-upsample-general/config.json")) as f:
+        cfg = DPTConfig(**json.load(f))
+    head = DPTNeckHeadForUnetAfterUpsampleIdentity(cfg).eval()
+    manifest = odpt.dpt_manifest()
+    ref_keys = {k: tuple(v.shape) for k, v in head.state_dict().items()}
+    assert ref_keys == {k: tuple(v) for k, v in manifest.items()}, "DPT manifest differs from the reference class"
+    sd = osd.synth_state_dict(manifest, seed=7)
+    head.load_state_dict(sd, strict=True)
+    out = {}
+    for tag, (h, w) in {"a": (12, 12), "b": (16, 12)}.items():
+        g = torch.Generator().manual_seed(100 + h * w)
+        feats = [torch.randn(1, 320, h, w, generator=g), torch.randn(1, 640, h, w, generator=g),
+                 torch.randn(1, 1280, h // 2, w // 2, generator=g), torch.randn(1, 1280, h // 4, w // 4, generator=g)]
+        with torch.no_grad():
+            y = head(hidden_states=[f.clone() for f in feats], return_depth_only=True)
+        out[f"{tag}_hw"] = np.array([h, w])
+        out[f"{tag}_out"] = y.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "dpt_head_ref.npz"), seed=np.array(7), **out)
+    print("dpt_head_ref.npz", {k: v.shape for k, v in out.items()})
+
+
+def make_metrics_golden():
+    sys.path.insert(0, REF)
+    from src.util import metric as rmetric
+    from src.util.alignment import align_depth_least_square, depth2disparity
+
+    g = torch.Generator().manual_seed(11)
+    gt = torch.rand(2, 48, 64, generator=g) * 9.0 + 0.5
+    pred = (gt * 0.37 + 0.8 + 0.3 * torch.randn(2, 48, 64, generator=g)).clamp_min(0.05)
+    mask = torch.rand(2, 48, 64, generator=g) > 0.2
+    out = {"gt": gt.numpy(), "pred": pred.numpy(), "mask": mask.numpy()}
+    aligned, scale, shift = align_depth_least_square(gt_arr=gt[0].numpy(), pred_arr=pred[0].numpy(), valid_mask_arr=mask[0].numpy(),
+                                                     return_scale_shift=True, max_resolution=None)
+    out["aligned0"] = aligned
+    out["scale_shift0"] = np.array([scale, shift], dtype=np.float64).reshape(-1)
+    disp, dmask = depth2disparity(gt[0].numpy(), return_mask=True)
+    out["disp0"] = disp
+    names = ["abs_relative_difference", "squared_relative_difference", "rmse_linear", "rmse_log", "log10", "delta1_acc",
+             "delta2_acc", "delta3_acc", "i_rmse", "silog_rmse"]
+    al = torch.from_numpy(np.clip(aligned, 1e-3, 10.0))[None]
+    for n in names:
+        fn = getattr(rmetric, n)
+        out["m_" + n] = np.array(float(fn(al, gt[:1], mask[:1])))
+    np.savez_compressed(os.path.join(HERE, "metrics_ref.npz"), **out)
+    print("metrics_ref.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k.startswith("m_")})
+
+
+def make_e2e_tiny():
+    uc, vc, dc = osd.UNetCfg.tiny(), osd.VAECfg.tiny(), odpt.DPTCfg.tiny()
+    usd = osd.synth_state_dict(osd.unet_manifest(uc), 1)
+    vsd = osd.synth_state_dict(osd.vae_manifest(vc), 2)
+    dsd = osd.synth_state_dict(odpt.dpt_manifest(dc), 3)
+    g = torch.Generator().manual_seed(1234)
+    out = {}
+    for tag, (b, h, w) in {"sq": (2, 64, 64), "odd": (1, 72, 88)}.items():
+        noise = torch.randint(0, 256, (b, 3, h, w), generator=g, dtype=torch.uint8).float()
+        yy, xx = torch.meshgrid(torch.linspace(0, 1, h), torch.linspace(0, 1, w), indexing="ij")
+        smooth = torch.stack([yy, xx, (yy + xx) / 2])[None] * 255.0
+        rgb_u8 = (0.5 * noise + 0.5 * smooth).round().clamp(0, 255).to(torch.uint8)
+        ctx = torch.randn(2, uc.cross_attention_dim, generator=g)
+        rgb = opipe.normalize_rgb(rgb_u8)
+        with torch.no_grad():
+            lat = osd.encode_rgb(vsd, vc, rgb)
+            v, feats = osd.unet_forward(usd, uc, lat, 1, ctx[None].expand(b, -1, -1))
+            dec3 = osd.decode_pred(vsd, vc, -v, "normal")
+            depth = opipe.single_infer(vsd, vc, usd, uc, rgb, ctx, "depth")
+            normal = opipe.single_infer(vsd, vc, usd, uc, rgb, ctx, "normal")
+            disp = opipe.single_infer(vsd, vc, usd, uc, rgb, ctx, "disparity", dpt_sd=dsd)
+        out[f"{tag}_rgb_u8"] = rgb_u8.numpy()
+        out[f"{tag}_ctx"] = ctx.numpy()
+        out[f"{tag}_latent"] = lat.numpy()
+        out[f"{tag}_unet"] = v.numpy()
+        for i, f in enumerate(feats):
+            out[f"{tag}_feat{i}"] = f.numpy().astype(np.float16)
+        out[f"{tag}_dec3"] = dec3.numpy()
+        out[f"{tag}_depth"] = depth.numpy()
+        out[f"{tag}_normal"] = normal.numpy()
+        out[f"{tag}_disp"] = disp.numpy()
+    np.savez_compressed(os.path.join(HERE, "e2e_tiny.npz"), seeds=np.array([1, 2, 3]), **out)
+    print("e2e_tiny.npz", os.path.getsize(os.path.join(HERE, "e2e_tiny.npz")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["dpt", "metrics", "e2e"]
+    if "dpt" in which:
+        make_dpt_golden()
+    if "metrics" in which:
+        make_metrics_golden()
+    if "e2e" in which:
+        make_e2e_tiny()
