@@ -1,0 +1,249 @@
+// Attention kernels (K4/K5/K6 of SURVEY.md §2.3).
+//
+// flash_attn64: UNet self-attention, head_dim 64, flash-style (scores never leave the CU) on v_mfma_f32_32x32x16_bf16.
+//   Per 256-thread workgroup: 128 query rows of one (image, head); each wave owns 32 query rows.  K tiles [64 keys][64 d]
+//   and V^T tiles [64 d][64 keys] are brought in by LDS-DMA (double-buffered, swizzled like the GEMM tiles).
+//   The wave computes S^T = K Q^T (keys x queries), so every lane holds 32 scores of ONE query (q = lane & 31):
+//   the softmax max/sum/rescale are lane-local (one cross-half exchange with lane ^ 32), and the probabilities are
+//   already in B-operand order for O^T += V^T P^T -- no LDS round trip, no permutes.  The V^T A-operand is read in the
+//   matching key order (keys 16j+4h+{0..3} and 16j+8+4h+{0..3} for half h), which is why V is produced transposed
+//   ([C][Tpad], zero-padded beyond T) by the projection GEMM.
+// cross_attn_small: cross-attention against the constant, tiny text context (L = 2 for GenPercept's empty prompt).
+// softmax_rows: row softmax for the GEMM-based single-head VAE attention (head_dim 512).
+#include "common.h"
+#include "kernels.h"
+
+__global__ __launch_bounds__(256) void flash_attn64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                            const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
+                                                            const bf16_t* __restrict__ zero, int T, int heads, int ldq, int ldk, int Tpad,
+                                                            int ldo) {
+    constexpr int STAGE = 16384;  // K tile 8 KiB + V^T tile 8 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    const bf16_t* Qb = Q + (long long)b * T * ldq + h * 64;
+    const bf16_t* Kb = K + (long long)b * T * ldk + h * 64;
+    const bf16_t* Vb = Vt + ((long long)b * heads + h) * 64 * Tpad;
+
+    // Q fragments (B operand of S^T = K Q^T): lane (q = l31, half hh) holds Q[q][16*ks + 8*hh .. +7]
+    bf16x8_t qf[4];
+    {
+        const int q = q0 + l31;
+        const bool ok = q < T;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ok) qf[ks] = *(const bf16x8_t*)(Qb + (long long)q * ldq + ks * 16 + hh * 8);
+            else qf[ks] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+
+    const int chunk = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
+    const int nt = (T + 63) >> 6;
+    auto stage = [&](int buf, int kt) {
+        char* sb = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (wave + 4 * i) * 8 + (lane >> 3);
+            const int key = kt * 64 + r;
+            const bf16_t* src = key < T ? Kb + (long long)key * ldk + chunk * 8 : zero + chunk * 8;
+            glds16(src, sb + (wave + 4 * i) * 1024);
+            const bf16_t* vsrc = Vb + (long long)r * Tpad + kt * 64 + chunk * 8;  // row r = head channel d
+            glds16(vsrc, sb + 8192 + (wave + 4 * i) * 1024);
+        }
+    };
+
+    f32x16_t o_acc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const float sc = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
+
+    stage(0, 0);
+    wait_vm0();
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nt; ++kt) {
+        if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
+        const char* sb = smem + cur * STAGE;
+        // ---- S^T = K Q^T: two 32-key blocks, 4 k-steps of 16 over d
+        f32x16_t s_acc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.f;
+            const int row = kb * 32 + l31;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8_t kf = *(const bf16x8_t*)(sb + lds_off128(row, ks * 2 + hh));
+                s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc[kb], 0, 0, 0);
+            }
+        }
+        // ---- online softmax over this lane's 32 keys (+ the other half's 32 via lane ^ 32)
+        const int kbase = kt * 64 + 4 * hh;
+        const bool tail = (kt * 64 + 64) > T;
+        float mx = -1e30f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s = s_acc[kb][r] * sc;
+                if (tail) {
+                    const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2);
+                    if (key >= T) s = -1e30f;
+                }
+                s_acc[kb][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(s_acc[kb][r] - m_new);
+                s_acc[kb][r] = pv;
+                rs += pv;
+            }
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+        // ---- O^T += V^T P^T: k-steps (kb, j) of 16 keys; this lane's P for its own query is the B operand
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                union { bf16x8_t v; unsigned u[4]; } pf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(s_acc[kb][8 * j + 2 * e], s_acc[kb][8 * j + 2 * e + 1]);
+                const int ko = kb * 32 + 16 * j + 4 * hh;  // key offset inside the tile (multiple of 4)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const int row = d * 32 + l31;
+                    const char* vr = sb + 8192 + row * 128;
+                    const int sw = (row >> 1) & 7;
+                    union { bf16x8_t v; uint2 h2[2]; } vf;
+                    vf.h2[0] = *(const uint2*)(vr + ((((ko >> 3)) ^ sw) << 4) + (ko & 7) * 2);
+                    vf.h2[1] = *(const uint2*)(vr + ((((ko >> 3) + 1) ^ sw) << 4) + (ko & 7) * 2);
+                    o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o_acc[d], 0, 0, 0);
+                }
+            }
+        if (kt + 1 < nt) wait_vm0();
+        __syncthreads();
+        cur ^= 1;
+    }
+    // ---- normalise and store O[q][d] (this lane: q = l31, d = 32*blk + 8*(r>>2) + 4*hh + (r&3))
+    l_run += __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_run;
+    const int q = q0 + l31;
+    if (q < T) {
+        bf16_t* ob = O + ((long long)b * T + q) * ldo + h * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint2 pk = pack_bf16x4(o_acc[d][4 * g] * inv, o_acc[d][4 * g + 1] * inv, o_acc[d][4 * g + 2] * inv, o_acc[d][4 * g + 3] * inv);
+                *(uint2*)(ob + d * 32 + 8 * g + 4 * hh) = pk;
+            }
+    }
+}
+
+void launch_flash_attn64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, const bf16_t* zero, int B, int T, int heads,
+                         int ldq, int ldk, int Tpad, int ldo, hipStream_t s) {
+    dim3 grid((T + 127) / 128, heads, B);
+    hipLaunchKernelGGL(flash_attn64_kernel, grid, dim3(256), 32768, s, q, k, vt, out, zero, T, heads, ldq, ldk, Tpad, ldo);
+}
+
+// ---- cross-attention with a tiny constant context -------------------------------------------------------------------
+// One thread per (row, head): q (64 bf16) against L keys/values held in fp32 (folded at load time).
+__global__ __launch_bounds__(256) void cross_attn_small_kernel(const bf16_t* __restrict__ q, const float* __restrict__ kc,
+                                                                const float* __restrict__ vc, bf16_t* __restrict__ out, long long nrh,
+                                                                int C, int heads, int L) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nrh) return;
+    const long long row = idx / heads;
+    const int h = (int)(idx - row * heads);
+    float qv[64];
+    const bf16_t* qp = q + row * C + h * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint4 raw = *(const uint4*)(qp + i * 8);
+        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { qv[i * 8 + 2 * k] = bflo(w[k]); qv[i * 8 + 2 * k + 1] = bfhi(w[k]); }
+    }
+    float o[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) o[d] = 0.f;
+    float m = -1e30f, l = 0.f;
+    for (int j = 0; j < L; ++j) {
+        const float* kp = kc + (long long)j * C + h * 64;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) s += qv[d] * kp[d];
+        s *= 0.125f;
+        const float mn = fmaxf(m, s);
+        const float a = __expf(m - mn), pj = __expf(s - mn);
+        m = mn;
+        l = l * a + pj;
+        const float* vp = vc + (long long)j * C + h * 64;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) o[d] = o[d] * a + pj * vp[d];
+    }
+    const float inv = 1.f / l;
+    bf16_t* op = out + row * C + h * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint4 r;
+        r.x = pack_bf16x2(o[i * 8] * inv, o[i * 8 + 1] * inv);
+        r.y = pack_bf16x2(o[i * 8 + 2] * inv, o[i * 8 + 3] * inv);
+        r.z = pack_bf16x2(o[i * 8 + 4] * inv, o[i * 8 + 5] * inv);
+        r.w = pack_bf16x2(o[i * 8 + 6] * inv, o[i * 8 + 7] * inv);
+        *(uint4*)(op + i * 8) = r;
+    }
+}
+
+void launch_cross_attn_small(const bf16_t* q, const float* kc, const float* vc, bf16_t* out, int rows, int C, int L, hipStream_t s) {
+    const int heads = C / 64;
+    const long long nrh = (long long)rows * heads;
+    hipLaunchKernelGGL(cross_attn_small_kernel, dim3((unsigned)((nrh + 255) / 256)), dim3(256), 0, s, q, kc, vc, out, nrh, C, heads, L);
+}
+
+// ---- row softmax (fp32 logits -> bf16 probabilities), one workgroup per row ----------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int T, int ld, float scale) {
+    __shared__ float red[8];
+    const long long row = blockIdx.x;
+    const float* x = in + row * ld;
+    bf16_t* y = out + row * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float sc = scale * 1.44269504088896340736f;
+    float mx = -1e30f;
+    for (int i = tid; i < T; i += 256) mx = fmaxf(mx, x[i] * sc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int i = tid; i < T; i += 256) sum += exp2f(x[i] * sc - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red[4 + wv] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    for (int i = tid; i < ld; i += 256) y[i] = i < T ? f2bf(exp2f(x[i] * sc - mx) * inv) : (bf16_t)0;
+}
+
+void launch_softmax_rows(const float* in, bf16_t* out, int rows, int T, int ld, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, in, out, T, ld, scale);
+}

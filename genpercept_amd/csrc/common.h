@@ -1,0 +1,54 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bf16 bits in HBM
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));   // MFMA A/B fragment (8 bf16 = 4 VGPR)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));    // 16x16 MFMA accumulator
+typedef float f32x16_t __attribute__((ext_vector_type(16)));  // 32x32 MFMA accumulator
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2n_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4n_t __attribute__((ext_vector_type(4)));
+
+#define GP_DEV __device__ __forceinline__
+
+GP_DEV float bf2f(bf16_t x) { return __uint_as_float(((unsigned)x) << 16); }
+GP_DEV float bflo(unsigned u) { return __uint_as_float(u << 16); }          // low bf16 of a packed pair
+GP_DEV float bfhi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }  // high bf16 of a packed pair
+
+// fp32 -> bf16 round-to-nearest-even via v_cvt_pk_bf16_f32
+GP_DEV unsigned pack_bf16x2(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2n_t));
+}
+GP_DEV uint2 pack_bf16x4(float a, float b, float c, float d) {
+    f32x4_t v = {a, b, c, d};
+    return __builtin_bit_cast(uint2, __builtin_convertvector(v, bf16x4n_t));
+}
+GP_DEV bf16_t f2bf(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
+
+GP_DEV float silu_f(float x) { return x / (1.f + __expf(-x)); }
+GP_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+// Asynchronous 16-byte-per-lane global -> LDS copy (LDS-DMA).  The LDS destination is wave-uniform base + lane*16,
+// the global source is per lane; swizzles therefore go on the SOURCE address (cdna guide, rule 21).
+GP_DEV void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+GP_DEV void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// LDS tiles are [rows][64 bf16] = 128-byte rows split into eight 16-byte slots.  Logical slot c of row r lives at
+// physical slot c ^ ((r >> 1) & 7): sixteen consecutive rows at one logical slot then cover all sixteen 16-byte
+// positions of a 256-byte bank row, so a ds_read_b128 fragment read is conflict-free.
+GP_DEV int swz_slot(int row, int slot) { return slot ^ ((row >> 1) & 7); }
+GP_DEV int lds_off128(int row, int slot) { return row * 128 + (swz_slot(row, slot) << 4); }
+
+// XCD-aware bijective remap of a linear workgroup id: workgroup b runs on XCD b % 8 (observed), so give each XCD a
+// contiguous chunk of the tile space to keep neighbouring tiles in one L2 (speed only, never correctness).
+GP_DEV int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

@@ -1,0 +1,1301 @@
+// Engine: weight ingestion / constant folding / bf16 packing, activation pool, and the static forward schedules of
+// the SD2.1 VAE encoder, UNet single step (t fixed, context fixed), VAE decoder and DPT head, all enqueued on one
+// HIP stream.  Exposed through the C-ABI of include/genpercept_hip.h.
+//
+// Control flow mirrors (never copies) the reference: genpercept/genpercept_pipeline.py:399-526 (single_infer,
+// encode_rgb, decode_pred), genpercept/models/custom_unet.py:109-119,146-170,273,305-415 (UNet forward, skip order,
+// upsample_size, multi_level_feats), genpercept/models/dpt_head.py:213-335,443-582 (DPT neck/head); module internals
+// follow the public SD2.1 architecture.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/genpercept_hip.h"
+#include "kernels.h"
+
+#define HIPCHK(x)                                                                                         \
+    do {                                                                                                  \
+        hipError_t _e = (x);                                                                              \
+        if (_e != hipSuccess) throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #x); \
+    } while (0)
+
+namespace {
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline bf16_t f2bf_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+inline float half_to_float(uint16_t h) {
+    const uint32_t s = (h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ff;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) u = s;
+        else {
+            int sh = 0;
+            uint32_t mm = m;
+            while (!(mm & 0x400)) { mm <<= 1; ++sh; }
+            u = s | ((uint32_t)(113 - sh) << 23) | ((mm & 0x3ff) << 13);
+        }
+    } else if (e == 31) u = s | 0x7f800000u | (m << 13);
+    else u = s | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+struct HostTensor {
+    std::vector<float> v;
+    std::vector<int64_t> shape;
+    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct Pool {
+    std::multimap<size_t, void*> free_;
+    std::unordered_map<void*, size_t> size_;
+    size_t total = 0;
+    void* alloc(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        auto it = free_.lower_bound(bytes);
+        if (it != free_.end() && it->first <= bytes * 2 + (1u << 20)) {
+            void* p = it->second;
+            free_.erase(it);
+            return p;
+        }
+        void* p = nullptr;
+        HIPCHK(hipMalloc(&p, bytes));
+        size_[p] = bytes;
+        total += bytes;
+        return p;
+    }
+    void release(void* p) {
+        if (!p) return;
+        free_.insert({size_.at(p), p});
+    }
+    void destroy() {
+        for (auto& kv : size_) hipFree(kv.first);
+        size_.clear();
+        free_.clear();
+    }
+};
+
+struct Act {
+    bf16_t* p = nullptr;
+    int B = 0, H = 0, W = 0, C = 0;  // C = allocated channels (row stride)
+    long long pixels() const { return (long long)B * H * W; }
+};
+
+struct PackedW {
+    bf16_t* w = nullptr;   // [n_rows][taps][cin_pad]
+    float* bias = nullptr; // [cout] or null
+    int cout = 0, cin_pad = 0, ks = 1, n_rows = 0;
+};
+struct NormW {
+    float* g = nullptr;
+    float* b = nullptr;
+    int C = 0;
+};
+struct ResW {
+    NormW n1, n2;
+    PackedW c1, c2, sc;
+    bool has_sc = false;
+    // time-embedding fold (UNet only)
+    bool has_temb = false;
+    std::vector<float> c1_bias_h, tw_h, tb_h;  // conv1.bias, time_emb_proj.{weight,bias}
+};
+struct TfW {
+    NormW gn, ln1, ln2, ln3;
+    PackedW proj_in, qk, v, o1, q2, o2, ff1, ff2, proj_out;
+    float* kc = nullptr;  // folded cross-attention keys / values [L][C] fp32
+    float* vc = nullptr;
+    std::vector<float> wk_h, wv_h;  // attn2.to_k / to_v [C][D]
+    int C = 0, heads = 0;
+};
+struct VaeAttnW {
+    NormW gn;
+    PackedW qk, v, o;
+    int C = 0;
+};
+
+}  // namespace
+
+struct gp_engine {
+    gp_config cfg;
+    std::string err;
+    std::unordered_map<std::string, HostTensor> host;
+    bool finalized = false;
+    hipStream_t st = nullptr;
+    Pool pool;
+    std::vector<void*> weights_dev;  // everything hipMalloc'ed for weights
+    bf16_t* zero = nullptr;
+    float* gn_ws = nullptr;
+    size_t gn_ws_floats = 0;
+    float* mm_ws = nullptr;
+
+    std::unordered_map<std::string, PackedW> convs;
+    std::unordered_map<std::string, NormW> norms;
+    std::unordered_map<std::string, ResW> resnets;
+    std::unordered_map<std::string, TfW> tfs;
+    std::unordered_map<std::string, VaeAttnW> vattn;
+    std::vector<float> te_w1, te_b1, te_w2, te_b2;  // time_embedding MLP (host)
+    std::vector<float> ctx;                          // [L][D]
+    int ctx_L = 0, ctx_D = 0;
+    float timestep = 1.f;
+    std::vector<float> pq_w, pq_b;  // post_quant_conv
+    float* pq_w_dev = nullptr;
+    float* pq_b_dev = nullptr;
+    float* dpt_w_dev = nullptr;  // head.head.4 weight [32]
+    float dpt_b = 0.f;
+
+    // profiling
+    int prof = 0;
+    gp_timings tm{};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<int> ev_kind;
+    size_t ev_used = 0;
+
+    // ---------------------------------------------------------------------------------------------------------------
+    const HostTensor& H(const std::string& n) const {
+        auto it = host.find(n);
+        if (it == host.end()) throw std::out_of_range("missing weight: " + n);
+        return it->second;
+    }
+    bool has(const std::string& n) const { return host.find(n) != host.end(); }
+
+    template <typename T>
+    T* upload(const T* src, size_t n) {
+        T* d = nullptr;
+        HIPCHK(hipMalloc((void**)&d, n * sizeof(T) + 256));
+        HIPCHK(hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice));
+        weights_dev.push_back(d);
+        return d;
+    }
+
+    // Pack [cout][cin][ks][ks] fp32 -> [n_rows][taps][cin_pad] bf16 (+ optional GEGLU 16-row interleave).
+    static void pack_rows(const float* w, int cout, int cin, int ks, int cin_pad, bool geglu, std::vector<bf16_t>& out, int row0, int n_rows_total) {
+        const int taps = ks * ks;
+        (void)n_rows_total;
+        for (int n = 0; n < cout; ++n) {
+            int dst = n;
+            if (geglu) {
+                const int half = cout / 2;
+                const bool gate = n >= half;
+                const int r = gate ? n - half : n;
+                dst = (r / 16) * 32 + (gate ? 16 : 0) + (r % 16);
+            }
+            bf16_t* o = out.data() + (size_t)(row0 + dst) * taps * cin_pad;
+            const float* wi = w + (size_t)n * cin * taps;
+            for (int c = 0; c < cin; ++c)
+                for (int t = 0; t < taps; ++t) o[(size_t)t * cin_pad + c] = f2bf_host(wi[(size_t)c * taps + t]);
+        }
+    }
+    PackedW pack(const float* w, const float* bias, int cout, int cin, int ks, int cin_pad, bool geglu = false) {
+        PackedW pw;
+        pw.cout = cout; pw.cin_pad = cin_pad; pw.ks = ks; pw.n_rows = gp_packed_rows(cout);
+        std::vector<bf16_t> buf((size_t)pw.n_rows * ks * ks * cin_pad, 0);
+        pack_rows(w, cout, cin, ks, cin_pad, geglu, buf, 0, pw.n_rows);
+        pw.w = upload(buf.data(), buf.size());
+        if (bias) {
+            std::vector<float> b(bias, bias + cout);
+            if (geglu) {
+                const int half = cout / 2;
+                for (int n = 0; n < cout; ++n) {
+                    const bool gate = n >= half;
+                    const int r = gate ? n - half : n;
+                    b[(r / 16) * 32 + (gate ? 16 : 0) + (r % 16)] = bias[n];
+                }
+            }
+            pw.bias = upload(b.data(), b.size());
+        }
+        return pw;
+    }
+    PackedW pack_named(const std::string& name, int ks, int cin_pad_override = 0, bool geglu = false) {
+        const HostTensor& w = H(name + ".weight");
+        const int cout = (int)w.shape[0], cin = (int)w.shape[1];
+        const float* b = has(name + ".bias") ? H(name + ".bias").v.data() : nullptr;
+        const int cin_pad = cin_pad_override ? cin_pad_override : round_up(cin, 64);
+        return pack(w.v.data(), b, cout, cin, ks, cin_pad, geglu);
+    }
+    // two linear layers stacked along the output dimension ([Wa; Wb]), optional biases
+    PackedW pack_stacked(const std::string& a, const std::string& b) {
+        const HostTensor& wa = H(a + ".weight");
+        const HostTensor& wb = H(b + ".weight");
+        const int ca = (int)wa.shape[0], cb = (int)wb.shape[0], cin = (int)(wa.numel() / ca);
+        std::vector<float> w((size_t)(ca + cb) * cin);
+        memcpy(w.data(), wa.v.data(), (size_t)ca * cin * 4);
+        memcpy(w.data() + (size_t)ca * cin, wb.v.data(), (size_t)cb * cin * 4);
+        std::vector<float> bias;
+        if (has(a + ".bias")) {
+            bias.resize(ca + cb);
+            memcpy(bias.data(), H(a + ".bias").v.data(), ca * 4);
+            memcpy(bias.data() + ca, H(b + ".bias").v.data(), cb * 4);
+        }
+        return pack(w.data(), bias.empty() ? nullptr : bias.data(), ca + cb, cin, 1, round_up(cin, 64));
+    }
+    NormW norm_named(const std::string& name) {
+        NormW n;
+        const HostTensor& g = H(name + ".weight");
+        n.C = (int)g.numel();
+        n.g = upload(g.v.data(), g.v.size());
+        n.b = upload(H(name + ".bias").v.data(), (size_t)n.C);
+        return n;
+    }
+
+    void build_resnet(const std::string& p, bool temb) {
+        ResW r;
+        r.n1 = norm_named(p + ".norm1");
+        r.n2 = norm_named(p + ".norm2");
+        r.c1 = pack_named(p + ".conv1", 3);
+        r.c2 = pack_named(p + ".conv2", 3);
+        r.has_sc = has(p + ".conv_shortcut.weight");
+        if (r.has_sc) r.sc = pack_named(p + ".conv_shortcut", 1);
+        if (temb) {
+            r.has_temb = true;
+            r.c1_bias_h = H(p + ".conv1.bias").v;
+            r.tw_h = H(p + ".time_emb_proj.weight").v;
+            r.tb_h = H(p + ".time_emb_proj.bias").v;
+        }
+        resnets[p] = std::move(r);
+    }
+    void build_transformer(const std::string& p, int heads) {
+        TfW t;
+        const std::string b = p + ".transformer_blocks.0";
+        t.gn = norm_named(p + ".norm");
+        t.proj_in = pack_named(p + ".proj_in", 1);
+        t.C = t.proj_in.cout;
+        t.heads = heads;
+        if (t.C != heads * 64) throw std::invalid_argument("self-attention head_dim must be 64 (" + p + ")");
+        t.ln1 = norm_named(b + ".norm1");
+        t.ln2 = norm_named(b + ".norm2");
+        t.ln3 = norm_named(b + ".norm3");
+        t.qk = pack_stacked(b + ".attn1.to_q", b + ".attn1.to_k");
+        t.v = pack_named(b + ".attn1.to_v", 1);
+        t.o1 = pack_named(b + ".attn1.to_out.0", 1);
+        t.q2 = pack_named(b + ".attn2.to_q", 1);
+        t.o2 = pack_named(b + ".attn2.to_out.0", 1);
+        t.ff1 = pack_named(b + ".ff.net.0.proj", 1, 0, true);
+        t.ff2 = pack_named(b + ".ff.net.2", 1);
+        t.proj_out = pack_named(p + ".proj_out", 1);
+        t.wk_h = H(b + ".attn2.to_k.weight").v;
+        t.wv_h = H(b + ".attn2.to_v.weight").v;
+        tfs[p] = std::move(t);
+    }
+    void build_vae_attn(const std::string& p) {
+        VaeAttnW a;
+        const bool newn = has(p + ".to_q.weight");
+        const std::string q = p + (newn ? ".to_q" : ".query"), k = p + (newn ? ".to_k" : ".key"), v = p + (newn ? ".to_v" : ".value"),
+                          o = p + (newn ? ".to_out.0" : ".proj_attn");
+        a.gn = norm_named(p + ".group_norm");
+        a.C = a.gn.C;
+        a.qk = pack_stacked(q, k);
+        a.v = pack_named(v, 1);
+        a.o = pack_named(o, 1);
+        vattn[p] = std::move(a);
+    }
+
+    void fold_timestep() {
+        if (te_w1.empty()) return;
+        const int c0 = cfg.unet_block_out[0], te = c0 * 4, half = c0 / 2;
+        std::vector<double> temb(c0), e1(te), emb(te);
+        for (int i = 0; i < half; ++i) {
+            const double f = std::exp(-std::log(10000.0) * i / half);
+            temb[i] = std::cos((double)timestep * f);
+            temb[half + i] = std::sin((double)timestep * f);
+        }
+        for (int o = 0; o < te; ++o) {
+            double a = te_b1[o];
+            for (int i = 0; i < c0; ++i) a += (double)te_w1[(size_t)o * c0 + i] * temb[i];
+            e1[o] = a / (1.0 + std::exp(-a));
+        }
+        for (int o = 0; o < te; ++o) {
+            double a = te_b2[o];
+            for (int i = 0; i < te; ++i) a += (double)te_w2[(size_t)o * te + i] * e1[i];
+            emb[o] = a / (1.0 + std::exp(-a));  // SiLU(emb), the input of every time_emb_proj
+        }
+        for (auto& kv : resnets) {
+            ResW& r = kv.second;
+            if (!r.has_temb) continue;
+            const int co = r.c1.cout;
+            std::vector<float> b(co);
+            for (int o = 0; o < co; ++o) {
+                double a = (double)r.c1_bias_h[o] + r.tb_h[o];
+                for (int i = 0; i < te; ++i) a += (double)r.tw_h[(size_t)o * te + i] * emb[i];
+                b[o] = (float)a;
+            }
+            HIPCHK(hipMemcpy(r.c1.bias, b.data(), co * 4, hipMemcpyHostToDevice));
+        }
+    }
+    void fold_context() {
+        if (ctx.empty()) return;
+        for (auto& kv : tfs) {
+            TfW& t = kv.second;
+            const int C = t.C, D = ctx_D, L = ctx_L;
+            if ((int)(t.wk_h.size() / C) != D) throw std::invalid_argument("context dim does not match attn2.to_k");
+            std::vector<float> kc((size_t)L * C), vc((size_t)L * C);
+            for (int l = 0; l < L; ++l)
+                for (int c = 0; c < C; ++c) {
+                    double ak = 0, av = 0;
+                    for (int d = 0; d < D; ++d) {
+                        ak += (double)t.wk_h[(size_t)c * D + d] * ctx[(size_t)l * D + d];
+                        av += (double)t.wv_h[(size_t)c * D + d] * ctx[(size_t)l * D + d];
+                    }
+                    kc[(size_t)l * C + c] = (float)ak;
+                    vc[(size_t)l * C + c] = (float)av;
+                }
+            t.kc = upload(kc.data(), kc.size());
+            t.vc = upload(vc.data(), vc.size());
+        }
+    }
+
+    void finalize() {
+        if (finalized) throw std::logic_error("gp_finalize called twice");
+        HIPCHK(hipSetDevice(cfg.device));
+        {
+            std::vector<bf16_t> z(2048, 0);
+            zero = upload(z.data(), z.size());
+        }
+        const bool have_vae = has("vae.encoder.conv_in.weight") || has("vae.decoder.conv_in.weight");
+        const bool have_unet = has("unet.conv_in.weight");
+        // ---------------- VAE ----------------
+        if (has("vae.encoder.conv_in.weight")) {
+            convs["vae.encoder.conv_in"] = pack_named("vae.encoder.conv_in", 3);
+            for (int i = 0; i < 4; ++i) {
+                for (int j = 0; j < cfg.vae_layers_per_block; ++j) build_resnet("vae.encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), false);
+                if (i != 3) convs["vae.encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv"] = pack_named("vae.encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv", 3);
+            }
+            build_resnet("vae.encoder.mid_block.resnets.0", false);
+            build_vae_attn("vae.encoder.mid_block.attentions.0");
+            build_resnet("vae.encoder.mid_block.resnets.1", false);
+            norms["vae.encoder.conv_norm_out"] = norm_named("vae.encoder.conv_norm_out");
+            // fold quant_conv (1x1) into encoder.conv_out and keep only the mean half, times scaling_factor
+            const HostTensor& wc = H("vae.encoder.conv_out.weight");
+            const HostTensor& bc = H("vae.encoder.conv_out.bias");
+            const HostTensor& wq = H("vae.quant_conv.weight");
+            const HostTensor& bq = H("vae.quant_conv.bias");
+            const int L = cfg.vae_latent_channels, M2 = 2 * L, cin = (int)wc.shape[1];
+            std::vector<float> wf((size_t)L * cin * 9), bf(L);
+            for (int o = 0; o < L; ++o) {
+                double bb = bq.v[o];
+                for (int m = 0; m < M2; ++m) bb += (double)wq.v[(size_t)o * M2 + m] * bc.v[m];
+                bf[o] = (float)(bb * cfg.vae_scaling_factor);
+                for (size_t e = 0; e < (size_t)cin * 9; ++e) {
+                    double a = 0;
+                    for (int m = 0; m < M2; ++m) a += (double)wq.v[(size_t)o * M2 + m] * wc.v[(size_t)m * cin * 9 + e];
+                    wf[(size_t)o * cin * 9 + e] = (float)(a * cfg.vae_scaling_factor);
+                }
+            }
+            convs["vae.encoder.conv_out_folded"] = pack(wf.data(), bf.data(), L, cin, 3, round_up(cin, 64));
+        }
+        if (has("vae.decoder.conv_in.weight")) {
+            pq_w = H("vae.post_quant_conv.weight").v;
+            pq_b = H("vae.post_quant_conv.bias").v;
+            pq_w_dev = upload(pq_w.data(), pq_w.size());
+            pq_b_dev = upload(pq_b.data(), pq_b.size());
+            convs["vae.decoder.conv_in"] = pack_named("vae.decoder.conv_in", 3);
+            build_resnet("vae.decoder.mid_block.resnets.0", false);
+            build_vae_attn("vae.decoder.mid_block.attentions.0");
+            build_resnet("vae.decoder.mid_block.resnets.1", false);
+            for (int i = 0; i < 4; ++i) {
+                for (int j = 0; j < cfg.vae_layers_per_block + 1; ++j) build_resnet("vae.decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), false);
+                if (i != 3) convs["vae.decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv"] = pack_named("vae.decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", 3);
+            }
+            norms["vae.decoder.conv_norm_out"] = norm_named("vae.decoder.conv_norm_out");
+            convs["vae.decoder.conv_out"] = pack_named("vae.decoder.conv_out", 3);
+        }
+        // ---------------- UNet ----------------
+        if (have_unet) {
+            te_w1 = H("unet.time_embedding.linear_1.weight").v;
+            te_b1 = H("unet.time_embedding.linear_1.bias").v;
+            te_w2 = H("unet.time_embedding.linear_2.weight").v;
+            te_b2 = H("unet.time_embedding.linear_2.bias").v;
+            convs["unet.conv_in"] = pack_named("unet.conv_in", 3);
+            for (int i = 0; i < 4; ++i) {
+                const std::string bp = "unet.down_blocks." + std::to_string(i);
+                for (int j = 0; j < cfg.unet_layers_per_block; ++j) {
+                    build_resnet(bp + ".resnets." + std::to_string(j), true);
+                    if (cfg.unet_down_attn[i]) build_transformer(bp + ".attentions." + std::to_string(j), cfg.unet_num_heads[i]);
+                }
+                if (i != 3) convs[bp + ".downsamplers.0.conv"] = pack_named(bp + ".downsamplers.0.conv", 3);
+            }
+            build_resnet("unet.mid_block.resnets.0", true);
+            build_transformer("unet.mid_block.attentions.0", cfg.unet_num_heads[3]);
+            build_resnet("unet.mid_block.resnets.1", true);
+            for (int i = 0; i < 4; ++i) {
+                const std::string bp = "unet.up_blocks." + std::to_string(i);
+                const bool attn = cfg.unet_down_attn[3 - i];
+                for (int j = 0; j < cfg.unet_layers_per_block + 1; ++j) {
+                    build_resnet(bp + ".resnets." + std::to_string(j), true);
+                    if (attn) build_transformer(bp + ".attentions." + std::to_string(j), cfg.unet_num_heads[3 - i]);
+                }
+                if (i != 3) convs[bp + ".upsamplers.0.conv"] = pack_named(bp + ".upsamplers.0.conv", 3);
+            }
+            if (cfg.unet_has_out) {
+                norms["unet.conv_norm_out"] = norm_named("unet.conv_norm_out");
+                convs["unet.conv_out"] = pack_named("unet.conv_out", 3);
+            }
+            fold_timestep();
+            fold_context();
+        }
+        // ---------------- DPT head ----------------
+        if (cfg.dpt_enabled && has("dpt.neck.convs.0.weight")) {
+            convs["dpt.feature_upsample_0.conv"] = pack_named("dpt.feature_upsample_0.conv", 3);
+            for (int i = 0; i < 4; ++i) {
+                convs["dpt.neck.convs." + std::to_string(i)] = pack_named("dpt.neck.convs." + std::to_string(i), 3);
+                const std::string lp = "dpt.neck.fusion_stage.layers." + std::to_string(i);
+                convs[lp + ".projection"] = pack_named(lp + ".projection", 1);
+                if (i != 0) {
+                    convs[lp + ".residual_layer1.convolution1"] = pack_named(lp + ".residual_layer1.convolution1", 3);
+                    convs[lp + ".residual_layer1.convolution2"] = pack_named(lp + ".residual_layer1.convolution2", 3);
+                }
+                convs[lp + ".residual_layer2.convolution1"] = pack_named(lp + ".residual_layer2.convolution1", 3);
+                convs[lp + ".residual_layer2.convolution2"] = pack_named(lp + ".residual_layer2.convolution2", 3);
+            }
+            convs["dpt.head.projection"] = pack_named("dpt.head.projection", 3);
+            convs["dpt.head.head.0"] = pack_named("dpt.head.head.0", 3);
+            convs["dpt.head.head.2"] = pack_named("dpt.head.head.2", 3);
+            const HostTensor& w4 = H("dpt.head.head.4.weight");
+            dpt_w_dev = upload(w4.v.data(), w4.v.size());
+            dpt_b = H("dpt.head.head.4.bias").v[0];
+        }
+        (void)have_vae;
+        HIPCHK(hipMalloc((void**)&mm_ws, 64 * 64 * 2 * sizeof(float)));
+        weights_dev.push_back(mm_ws);
+        host.clear();
+        finalized = true;
+    }
+
+    // ---------------------------------------------------------------------------------------------------------------
+    // run-time helpers (everything below only enqueues work on `st`)
+    Act new_act(int B, int H, int W, int C) {
+        Act a;
+        a.B = B; a.H = H; a.W = W; a.C = C;
+        a.p = (bf16_t*)pool.alloc((size_t)B * H * W * C * sizeof(bf16_t));
+        return a;
+    }
+    void drop(Act& a) {
+        pool.release(a.p);
+        a.p = nullptr;
+    }
+    void prof_begin(int kind) {
+        if (prof < 2) return;
+        if (ev_used == ev_pool.size()) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a));
+            HIPCHK(hipEventCreate(&b));
+            ev_pool.push_back({a, b});
+            ev_kind.push_back(kind);
+        }
+        ev_kind[ev_used] = kind;
+        HIPCHK(hipEventRecord(ev_pool[ev_used].first, st));
+    }
+    void prof_end() {
+        if (prof < 2) return;
+        HIPCHK(hipEventRecord(ev_pool[ev_used].second, st));
+        ++ev_used;
+    }
+    void run_igemm(const IGemmParams& p, int hint = 0) {
+        const int taps = p.ks == 3 ? 9 : 1;
+        tm.flops_igemm += 2.0 * (double)p.M * (double)p.N * (double)p.Cin * taps * (p.batch > 0 ? p.batch : 1);
+        tm.n_igemm++;
+        tm.n_launches++;
+        prof_begin(0);
+        launch_igemm(p, hint, st);
+        prof_end();
+    }
+
+    struct ConvOpt {
+        int stride = 1, pad_t = 1, pad_l = 1;
+        int Ho = 0, Wo = 0;     // 0: same as input (or upsampled size)
+        int ups_h = 0, ups_w = 0;
+        const bf16_t* res = nullptr;
+        int act = GP_ACT_NONE;
+        int n_store = 0;        // 0: cout
+    };
+    Act conv(const Act& x, const PackedW& w, const ConvOpt& o) {
+        if (x.C != w.cin_pad) throw std::logic_error("conv: channel mismatch (" + std::to_string(x.C) + " vs " + std::to_string(w.cin_pad) + ")");
+        const int Hin = o.ups_h ? o.ups_h : x.H, Win = o.ups_w ? o.ups_w : x.W;
+        const int Ho = o.Ho ? o.Ho : Hin, Wo = o.Wo ? o.Wo : Win;
+        const int nst = o.n_store ? o.n_store : w.cout;
+        Act y = new_act(x.B, Ho, Wo, nst);
+        IGemmParams p{};
+        p.in = x.p; p.wt = w.w; p.bias = w.bias; p.res = o.res; p.out = y.p; p.zero = zero;
+        p.M = x.B * Ho * Wo; p.N = w.cout; p.Cin = w.cin_pad; p.n_rows = w.n_rows; p.ks = w.ks;
+        p.B = x.B; p.Hi = x.H; p.Wi = x.W; p.Ho = Ho; p.Wo = Wo;
+        p.stride = o.stride; p.pad_t = w.ks == 3 ? o.pad_t : 0; p.pad_l = w.ks == 3 ? o.pad_l : 0;
+        p.ups = o.ups_h ? 1 : 0; p.Hu = o.ups_h; p.Wu = o.ups_w;
+        p.lda = x.C; p.ldo = nst; p.ldres = nst; p.ldw = (w.ks == 3 ? 9 : 1) * w.cin_pad;
+        p.n_store = nst; p.out_fp32 = 0; p.act = o.act; p.bias_mode = w.bias ? GP_BIAS_COL : GP_BIAS_NONE;
+        p.batch = 1;
+        run_igemm(p);
+        return y;
+    }
+    // y[M][N] = x[M][K] W^T (+bias) (+res), N = w.cout (GEGLU halves it)
+    Act linear(const Act& x, const PackedW& w, const bf16_t* res = nullptr, int act = GP_ACT_NONE, bf16_t* out_inplace = nullptr) {
+        if (x.C != w.cin_pad) throw std::logic_error("linear: channel mismatch");
+        const int nout = act == GP_ACT_GEGLU ? w.cout / 2 : w.cout;
+        Act y;
+        if (out_inplace) { y = x; y.C = nout; y.p = out_inplace; }
+        else y = new_act(x.B, x.H, x.W, nout);
+        IGemmParams p{};
+        p.in = x.p; p.wt = w.w; p.bias = w.bias; p.res = res; p.out = y.p; p.zero = zero;
+        p.M = (int)x.pixels(); p.N = w.cout; p.Cin = w.cin_pad; p.n_rows = w.n_rows; p.ks = 1;
+        p.B = x.B; p.Hi = x.H; p.Wi = x.W; p.Ho = x.H; p.Wo = x.W; p.stride = 1;
+        p.lda = x.C; p.ldo = nout; p.ldres = nout; p.ldw = w.cin_pad; p.n_store = nout; p.act = act;
+        p.bias_mode = w.bias ? GP_BIAS_COL : GP_BIAS_NONE; p.batch = 1;
+        run_igemm(p);
+        return y;
+    }
+    // V^T[b][c][t] = sum_k Wv[c][k] x[b][t][k] (+ bias[c]); zero-filled up to Tpad
+    bf16_t* v_transposed(const Act& x, const PackedW& wv, int T, int Tpad) {
+        const int C = wv.cout;
+        bf16_t* vt = (bf16_t*)pool.alloc((size_t)x.B * C * Tpad * sizeof(bf16_t));
+        IGemmParams p{};
+        p.in = wv.w; p.wt = x.p; p.bias = wv.bias; p.out = vt; p.zero = zero;
+        p.M = C; p.N = T; p.Cin = wv.cin_pad; p.n_rows = T; p.ks = 1; p.stride = 1;
+        p.lda = wv.cin_pad; p.ldw = x.C; p.ldo = Tpad; p.n_store = Tpad;
+        p.bias_mode = wv.bias ? GP_BIAS_ROW : GP_BIAS_NONE;
+        p.batch = x.B; p.in_bs = 0; p.wt_bs = (long long)T * x.C; p.out_bs = (long long)C * Tpad; p.bias_bs = 0;
+        run_igemm(p);
+        return vt;
+    }
+    Act groupnorm(const Act& x, const NormW& n, float eps, bool silu) {
+        if (x.C != n.C) throw std::logic_error("groupnorm: channel mismatch");
+        const size_t need = (size_t)groupnorm_ws_floats(x.B, x.H * x.W, x.C, cfg.norm_groups);
+        if (need > gn_ws_floats) {
+            if (gn_ws) pool.release(gn_ws);
+            gn_ws = (float*)pool.alloc(need * 4 * 2);
+            gn_ws_floats = need * 2;
+        }
+        Act y = new_act(x.B, x.H, x.W, x.C);
+        launch_groupnorm(x.p, y.p, n.g, n.b, x.B, x.H * x.W, x.C, cfg.norm_groups, eps, silu ? 1 : 0, gn_ws, st);
+        tm.n_launches += 2;
+        return y;
+    }
+    Act layernorm(const Act& x, const NormW& n) {
+        Act y = new_act(x.B, x.H, x.W, x.C);
+        launch_layernorm(x.p, y.p, n.g, n.b, (int)x.pixels(), x.C, 1e-5f, st);
+        tm.n_launches++;
+        return y;
+    }
+
+    Act resnet(const Act& x, const std::string& name, float eps) {
+        const ResW& r = resnets.at(name);
+        Act n1 = groupnorm(x, r.n1, eps, true);
+        Act h = conv(n1, r.c1, ConvOpt{});
+        drop(n1);
+        Act n2 = groupnorm(h, r.n2, eps, true);
+        drop(h);
+        Act sc = x;
+        if (r.has_sc) sc = linear(x, r.sc);
+        ConvOpt o;
+        o.res = sc.p;
+        Act y = conv(n2, r.c2, o);
+        drop(n2);
+        if (r.has_sc) drop(sc);
+        return y;
+    }
+
+    Act vae_attention(const Act& x, const std::string& name) {
+        const VaeAttnW& a = vattn.at(name);
+        const int T = x.H * x.W, C = a.C, Tpad = round_up(T, 64), B = x.B;
+        Act n = groupnorm(x, a.gn, cfg.vae_norm_eps, false);
+        Act qk = linear(n, a.qk);  // [B*T][2C]
+        bf16_t* vt = v_transposed(n, a.v, T, Tpad);
+        drop(n);
+        float* S = (float*)pool.alloc((size_t)B * T * Tpad * sizeof(float));
+        {
+            IGemmParams p{};
+            p.in = qk.p; p.wt = qk.p + C; p.out = S; p.zero = zero;
+            p.M = T; p.N = T; p.Cin = C; p.n_rows = T; p.ks = 1; p.stride = 1;
+            p.lda = 2 * C; p.ldw = 2 * C; p.ldo = Tpad; p.n_store = T; p.out_fp32 = 1;
+            p.batch = B; p.in_bs = (long long)T * 2 * C; p.wt_bs = (long long)T * 2 * C; p.out_bs = (long long)T * Tpad;
+            run_igemm(p);
+        }
+        drop(qk);
+        bf16_t* P = (bf16_t*)pool.alloc((size_t)B * T * Tpad * sizeof(bf16_t));
+        launch_softmax_rows(S, P, B * T, T, Tpad, 1.0f / std::sqrt((float)C), st);
+        tm.n_launches++;
+        pool.release(S);
+        Act o = new_act(x.B, x.H, x.W, C);
+        {
+            IGemmParams p{};
+            p.in = P; p.wt = vt; p.out = o.p; p.zero = zero;
+            p.M = T; p.N = C; p.Cin = Tpad; p.n_rows = C; p.ks = 1; p.stride = 1;
+            p.lda = Tpad; p.ldw = Tpad; p.ldo = C; p.n_store = C;
+            p.batch = B; p.in_bs = (long long)T * Tpad; p.wt_bs = (long long)C * Tpad; p.out_bs = (long long)T * C;
+            run_igemm(p);
+        }
+        pool.release(P);
+        pool.release(vt);
+        Act y = linear(o, a.o, x.p);
+        drop(o);
+        return y;
+    }
+
+    Act transformer(const Act& x, const std::string& name) {
+        const TfW& t = tfs.at(name);
+        if (!t.kc) throw std::logic_error("gp_set_context has not been called");
+        const int T = x.H * x.W, C = t.C, Tpad = round_up(T, 64);
+        Act n = groupnorm(x, t.gn, 1e-6f, false);
+        Act y = linear(n, t.proj_in);
+        drop(n);
+        // self-attention
+        Act l1 = layernorm(y, t.ln1);
+        Act qk = linear(l1, t.qk);
+        bf16_t* vt = v_transposed(l1, t.v, T, Tpad);
+        drop(l1);
+        Act a = new_act(x.B, x.H, x.W, C);
+        tm.flops_attn += 4.0 * x.B * t.heads * (double)T * T * 64;
+        tm.n_attn++;
+        tm.n_launches++;
+        prof_begin(1);
+        launch_flash_attn64(qk.p, qk.p + C, vt, a.p, zero, x.B, T, t.heads, 2 * C, 2 * C, Tpad, C, st);
+        prof_end();
+        drop(qk);
+        pool.release(vt);
+        linear(a, t.o1, y.p, GP_ACT_NONE, y.p);  // y += to_out(attn), in place
+        drop(a);
+        // cross-attention against the folded constant context
+        Act l2 = layernorm(y, t.ln2);
+        Act q2 = linear(l2, t.q2);
+        drop(l2);
+        Act a2 = new_act(x.B, x.H, x.W, C);
+        launch_cross_attn_small(q2.p, t.kc, t.vc, a2.p, (int)x.pixels(), C, ctx_L, st);
+        tm.n_launches++;
+        drop(q2);
+        linear(a2, t.o2, y.p, GP_ACT_NONE, y.p);
+        drop(a2);
+        // GEGLU feed-forward
+        Act l3 = layernorm(y, t.ln3);
+        Act ff = linear(l3, t.ff1, nullptr, GP_ACT_GEGLU);
+        drop(l3);
+        linear(ff, t.ff2, y.p, GP_ACT_NONE, y.p);
+        drop(ff);
+        Act out = linear(y, t.proj_out, x.p);
+        drop(y);
+        return out;
+    }
+
+    // ---- stages ---------------------------------------------------------------------------------------------------
+    // rgb (device NCHW) -> latent NHWC, 64 allocated channels (cfg.vae_latent_channels real, scaled by scaling_factor)
+    Act vae_encode(const void* rgb, int is_u8, int B, int Hh, int Ww) {
+        Act x = new_act(B, Hh, Ww, 64);
+        launch_rgb_prologue(rgb, is_u8, x.p, B, Hh, Ww, 64, st);
+        tm.n_launches++;
+        Act h = conv(x, convs.at("vae.encoder.conv_in"), ConvOpt{});
+        drop(x);
+        for (int i = 0; i < 4; ++i) {
+            for (int j = 0; j < cfg.vae_layers_per_block; ++j) {
+                Act y = resnet(h, "vae.encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), cfg.vae_norm_eps);
+                drop(h);
+                h = y;
+            }
+            if (i != 3) {
+                ConvOpt o;  // pad (0,1,0,1) then stride-2 conv without padding (Appendix B.6)
+                o.stride = 2; o.pad_t = 0; o.pad_l = 0;
+                o.Ho = (h.H + 1 - 3) / 2 + 1; o.Wo = (h.W + 1 - 3) / 2 + 1;
+                Act y = conv(h, convs.at("vae.encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv"), o);
+                drop(h);
+                h = y;
+            }
+        }
+        Act y = resnet(h, "vae.encoder.mid_block.resnets.0", cfg.vae_norm_eps); drop(h); h = y;
+        y = vae_attention(h, "vae.encoder.mid_block.attentions.0"); drop(h); h = y;
+        y = resnet(h, "vae.encoder.mid_block.resnets.1", cfg.vae_norm_eps); drop(h); h = y;
+        Act n = groupnorm(h, norms.at("vae.encoder.conv_norm_out"), cfg.vae_norm_eps, true);
+        drop(h);
+        ConvOpt o;
+        o.n_store = 64;
+        Act lat = conv(n, convs.at("vae.encoder.conv_out_folded"), o);
+        drop(n);
+        return lat;
+    }
+
+    // latent NHWC (64 allocated channels) -> sample NHWC (64 allocated, unet_out_channels real) and/or the 4 up-block features
+    Act unet(const Act& latent, Act* feats /* [4] or null */, bool want_sample) {
+        std::vector<Act> skips;
+        const int nup = 3;
+        const bool fwd_size = (latent.H % (1 << nup)) != 0 || (latent.W % (1 << nup)) != 0;
+        Act x = conv(latent, convs.at("unet.conv_in"), ConvOpt{});
+        skips.push_back(x);
+        Act cur = x;  // `cur` aliases the top of the skip stack until replaced
+        for (int i = 0; i < 4; ++i) {
+            const std::string bp = "unet.down_blocks." + std::to_string(i);
+            for (int j = 0; j < cfg.unet_layers_per_block; ++j) {
+                Act y = resnet(cur, bp + ".resnets." + std::to_string(j), cfg.unet_norm_eps);
+                if (cfg.unet_down_attn[i]) {
+                    Act z = transformer(y, bp + ".attentions." + std::to_string(j));
+                    drop(y);
+                    y = z;
+                }
+                skips.push_back(y);
+                cur = y;
+            }
+            if (i != 3) {
+                ConvOpt o;
+                o.stride = 2;
+                o.Ho = (cur.H + 2 - 3) / 2 + 1; o.Wo = (cur.W + 2 - 3) / 2 + 1;
+                Act y = conv(cur, convs.at(bp + ".downsamplers.0.conv"), o);
+                skips.push_back(y);
+                cur = y;
+            }
+        }
+        // mid (cur is also skips.back(): do not drop it)
+        Act m = resnet(cur, "unet.mid_block.resnets.0", cfg.unet_norm_eps);
+        Act m2 = transformer(m, "unet.mid_block.attentions.0");
+        drop(m);
+        m = resnet(m2, "unet.mid_block.resnets.1", cfg.unet_norm_eps);
+        drop(m2);
+        Act h = m;
+        for (int i = 0; i < 4; ++i) {
+            const std::string bp = "unet.up_blocks." + std::to_string(i);
+            const bool attn = cfg.unet_down_attn[3 - i];
+            const int nres = cfg.unet_layers_per_block + 1;
+            for (int j = 0; j < nres; ++j) {
+                Act skip = skips.back();
+                skips.pop_back();
+                Act cat = new_act(h.B, h.H, h.W, h.C + skip.C);
+                launch_concat(h.p, h.C, skip.p, skip.C, cat.p, h.pixels(), st);
+                tm.n_launches++;
+                drop(h);
+                drop(skip);
+                Act y = resnet(cat, bp + ".resnets." + std::to_string(j), cfg.unet_norm_eps);
+                drop(cat);
+                if (attn) {
+                    Act z = transformer(y, bp + ".attentions." + std::to_string(j));
+                    drop(y);
+                    y = z;
+                }
+                h = y;
+            }
+            if (i != 3) {
+                ConvOpt o;
+                if (fwd_size) { o.ups_h = skips.back().H; o.ups_w = skips.back().W; }
+                else { o.ups_h = h.H * 2; o.ups_w = h.W * 2; }
+                Act y = conv(h, convs.at(bp + ".upsamplers.0.conv"), o);
+                drop(h);
+                h = y;
+            }
+            if (feats) {
+                feats[i] = new_act(h.B, h.H, h.W, h.C);
+                HIPCHK(hipMemcpyAsync(feats[i].p, h.p, (size_t)h.pixels() * h.C * 2, hipMemcpyDeviceToDevice, st));
+            }
+        }
+        Act out;
+        if (want_sample && cfg.unet_has_out) {
+            Act n = groupnorm(h, norms.at("unet.conv_norm_out"), cfg.unet_norm_eps, true);
+            ConvOpt o;
+            o.n_store = 64;
+            out = conv(n, convs.at("unet.conv_out"), o);
+            drop(n);
+        }
+        drop(h);
+        return out;
+    }
+
+    // z_in: NHWC with 64 allocated channels holding the UNet output v (in_scale = -1/scaling) or a pred latent (1/scaling)
+    Act vae_decode(const Act& z_in, float in_scale) {
+        const int L = cfg.vae_latent_channels;
+        Act z = new_act(z_in.B, z_in.H, z_in.W, 64);
+        launch_pointwise_small(z_in.p, z.p, pq_w_dev, pq_b_dev, z_in.pixels(), L, L, z_in.C, 64, in_scale, st);
+        tm.n_launches++;
+        Act h = conv(z, convs.at("vae.decoder.conv_in"), ConvOpt{});
+        drop(z);
+        Act y = resnet(h, "vae.decoder.mid_block.resnets.0", cfg.vae_norm_eps); drop(h); h = y;
+        y = vae_attention(h, "vae.decoder.mid_block.attentions.0"); drop(h); h = y;
+        y = resnet(h, "vae.decoder.mid_block.resnets.1", cfg.vae_norm_eps); drop(h); h = y;
+        for (int i = 0; i < 4; ++i) {
+            for (int j = 0; j < cfg.vae_layers_per_block + 1; ++j) {
+                y = resnet(h, "vae.decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), cfg.vae_norm_eps);
+                drop(h);
+                h = y;
+            }
+            if (i != 3) {
+                ConvOpt o;
+                o.ups_h = h.H * 2; o.ups_w = h.W * 2;
+                y = conv(h, convs.at("vae.decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv"), o);
+                drop(h);
+                h = y;
+            }
+        }
+        Act n = groupnorm(h, norms.at("vae.decoder.conv_norm_out"), cfg.vae_norm_eps, true);
+        drop(h);
+        ConvOpt o;
+        o.n_store = 4;  // 3 real channels + one zero: 8-byte pixels for the epilogue
+        Act out = conv(n, convs.at("vae.decoder.conv_out"), o);
+        drop(n);
+        return out;
+    }
+
+    Act rcu(const Act& x, const std::string& p) {  // pre-activation residual unit (dpt_head.py:256-271)
+        Act r = new_act(x.B, x.H, x.W, x.C);
+        launch_relu(x.p, r.p, x.pixels() * x.C, st);
+        tm.n_launches++;
+        ConvOpt o1;
+        o1.act = GP_ACT_RELU;
+        Act h = conv(r, convs.at(p + ".convolution1"), o1);
+        drop(r);
+        ConvOpt o2;
+        o2.res = x.p;
+        Act y = conv(h, convs.at(p + ".convolution2"), o2);
+        drop(h);
+        return y;
+    }
+    // feats: reversed multi_level_feats [c0@h, c1@h, c2@h/2, c3@h/4] -> fp32 [B][8h*8w] written to out_dev
+    void dpt_head(const Act* feats, float* out_dev) {
+        ConvOpt ou;
+        ou.ups_h = feats[0].H * 2; ou.ups_w = feats[0].W * 2;
+        Act f0 = conv(feats[0], convs.at("dpt.feature_upsample_0.conv"), ou);
+        Act nk[4];
+        nk[0] = conv(f0, convs.at("dpt.neck.convs.0"), ConvOpt{});
+        drop(f0);
+        for (int i = 1; i < 4; ++i) nk[i] = conv(feats[i], convs.at("dpt.neck.convs." + std::to_string(i)), ConvOpt{});
+        Act fused;
+        for (int i = 0; i < 4; ++i) {
+            const std::string lp = "dpt.neck.fusion_stage.layers." + std::to_string(i);
+            Act& hsrc = nk[3 - i];
+            Act x;
+            if (i == 0) {
+                x = hsrc;
+            } else {
+                Act r = hsrc;
+                bool resized = false;
+                if (r.H != fused.H || r.W != fused.W) {
+                    Act rr = new_act(r.B, fused.H, fused.W, r.C);
+                    launch_bilinear(r.p, rr.p, r.B, r.H, r.W, fused.H, fused.W, r.C, 0, st);
+                    tm.n_launches++;
+                    drop(r);
+                    r = rr;
+                    resized = true;
+                }
+                (void)resized;
+                Act rc = rcu(r, lp + ".residual_layer1");
+                drop(r);
+                x = new_act(fused.B, fused.H, fused.W, fused.C);
+                launch_add(fused.p, rc.p, x.p, fused.pixels() * fused.C, st);
+                tm.n_launches++;
+                drop(rc);
+                drop(fused);
+            }
+            Act x2 = rcu(x, lp + ".residual_layer2");
+            drop(x);
+            Act up = new_act(x2.B, x2.H * 2, x2.W * 2, x2.C);
+            launch_bilinear(x2.p, up.p, x2.B, x2.H, x2.W, x2.H * 2, x2.W * 2, x2.C, 1, st);
+            tm.n_launches++;
+            drop(x2);
+            fused = linear(up, convs.at(lp + ".projection"));
+            drop(up);
+        }
+        ConvOpt op;
+        op.act = GP_ACT_RELU;
+        Act x = conv(fused, convs.at("dpt.head.projection"), op);
+        drop(fused);
+        Act y = conv(x, convs.at("dpt.head.head.0"), ConvOpt{});
+        drop(x);
+        Act up = new_act(y.B, y.H * 2, y.W * 2, y.C);
+        launch_bilinear(y.p, up.p, y.B, y.H, y.W, y.H * 2, y.W * 2, y.C, 1, st);
+        tm.n_launches++;
+        drop(y);
+        ConvOpt o32;
+        o32.act = GP_ACT_RELU;
+        Act z = conv(up, convs.at("dpt.head.head.2"), o32);
+        drop(up);
+        launch_dpt_final(z.p, dpt_w_dev, dpt_b, out_dev, z.B, z.H * z.W, z.C, st);
+        tm.n_launches++;
+        drop(z);
+    }
+
+    Act from_nchw_f32(const float* src, int B, int C, int Hh, int Ww, int Cpad) {
+        Act a = new_act(B, Hh, Ww, Cpad);
+        launch_nchw_f32_to_nhwc(src, a.p, B, C, Hh, Ww, Cpad, st);
+        tm.n_launches++;
+        return a;
+    }
+    void to_nchw_f32(const Act& a, int C, float* dst) {
+        launch_nhwc_to_nchw_f32(a.p, dst, a.B, C, a.H, a.W, a.C, st);
+        tm.n_launches++;
+    }
+
+    void collect_profile() {
+        if (prof < 2 || ev_used == 0) return;
+        HIPCHK(hipStreamSynchronize(st));
+        for (size_t i = 0; i < ev_used; ++i) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, ev_pool[i].first, ev_pool[i].second));
+            if (ev_kind[i] == 0) tm.ms_igemm += ms;
+            else tm.ms_attn += ms;
+        }
+        ev_used = 0;
+    }
+};
+
+// =====================================================================================================================
+// C-ABI
+// =====================================================================================================================
+template <typename F>
+static gp_status guard(gp_engine* e, F&& f) {
+    try {
+        f();
+        return GP_OK;
+    } catch (const std::out_of_range& ex) {
+        if (e) e->err = ex.what();
+        return GP_ERR_MISSING_WEIGHT;
+    } catch (const std::invalid_argument& ex) {
+        if (e) e->err = ex.what();
+        return GP_ERR_INVALID;
+    } catch (const std::logic_error& ex) {
+        if (e) e->err = ex.what();
+        return GP_ERR_STATE;
+    } catch (const std::exception& ex) {
+        if (e) e->err = ex.what();
+        return GP_ERR_HIP;
+    }
+}
+
+static bf16_t* g_zero = nullptr;
+static float* g_gn_ws = nullptr;
+static size_t g_gn_ws_floats = 0;
+static bf16_t* zero_page() {
+    if (!g_zero) {
+        HIPCHK(hipMalloc((void**)&g_zero, 4096));
+        HIPCHK(hipMemset(g_zero, 0, 4096));
+    }
+    return g_zero;
+}
+
+extern "C" {
+
+const char* gp_version(void) { return "genpercept_hip 0.1 (gfx950)"; }
+
+void gp_default_config(gp_config* c) {
+    memset(c, 0, sizeof(*c));
+    c->device = 0;
+    c->unet_in_channels = 4; c->unet_out_channels = 4;
+    const int bo[4] = {320, 640, 1280, 1280}, nh[4] = {5, 10, 20, 20}, da[4] = {1, 1, 1, 0};
+    const int vb[4] = {128, 256, 512, 512}, dn[4] = {320, 640, 1280, 1280};
+    for (int i = 0; i < 4; ++i) { c->unet_block_out[i] = bo[i]; c->unet_num_heads[i] = nh[i]; c->unet_down_attn[i] = da[i]; c->vae_block_out[i] = vb[i]; c->dpt_neck[i] = dn[i]; }
+    c->unet_layers_per_block = 2; c->unet_cross_dim = 1024; c->unet_has_out = 1; c->unet_norm_eps = 1e-5f;
+    c->vae_layers_per_block = 2; c->vae_latent_channels = 4; c->vae_norm_eps = 1e-6f; c->vae_scaling_factor = 0.18215f;
+    c->dpt_enabled = 0; c->dpt_fusion = 256; c->norm_groups = 32;
+}
+
+gp_status gp_create(const gp_config* cfg, gp_engine** out) {
+    if (!cfg || !out) return GP_ERR_INVALID;
+    gp_engine* e = new gp_engine();
+    e->cfg = *cfg;
+    *out = e;
+    return guard(e, [&] {
+        int n = 0;
+        HIPCHK(hipGetDeviceCount(&n));
+        if (cfg->device < 0 || cfg->device >= n) throw std::invalid_argument("no such HIP device");
+        HIPCHK(hipSetDevice(cfg->device));
+        for (int i = 0; i < 4; ++i) {
+            if (cfg->unet_block_out[i] % 64 || cfg->vae_block_out[i] % 64) throw std::invalid_argument("block_out_channels must be multiples of 64");
+            if (cfg->unet_down_attn[i] && cfg->unet_block_out[i] != 64 * cfg->unet_num_heads[i]) throw std::invalid_argument("attention head_dim must be 64");
+        }
+        if (cfg->vae_latent_channels > 8 || cfg->vae_latent_channels < 1) throw std::invalid_argument("latent_channels must be in 1..8");
+    });
+}
+
+void gp_destroy(gp_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->cfg.device);
+    hipDeviceSynchronize();
+    for (void* p : e->weights_dev) hipFree(p);
+    e->pool.destroy();
+    for (auto& pr : e->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (int i = 0; i < 4; ++i) if (e->ev[i]) hipEventDestroy(e->ev[i]);
+    delete e;
+}
+
+const char* gp_last_error(const gp_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+gp_status gp_load_tensor(gp_engine* e, const char* name, const void* host_ptr, const int64_t* shape, int ndim, gp_dtype dtype) {
+    if (!e || !name || !host_ptr || (ndim > 0 && !shape)) return GP_ERR_INVALID;
+    return guard(e, [&] {
+        if (e->finalized) throw std::logic_error("gp_load_tensor after gp_finalize");
+        HostTensor t;
+        t.shape.assign(shape, shape + ndim);
+        const int64_t n = t.numel();
+        t.v.resize((size_t)n);
+        if (dtype == GP_DT_F32) memcpy(t.v.data(), host_ptr, (size_t)n * 4);
+        else if (dtype == GP_DT_F16) { const uint16_t* s = (const uint16_t*)host_ptr; for (int64_t i = 0; i < n; ++i) t.v[i] = half_to_float(s[i]); }
+        else if (dtype == GP_DT_BF16) { const uint16_t* s = (const uint16_t*)host_ptr; for (int64_t i = 0; i < n; ++i) { uint32_t u = (uint32_t)s[i] << 16; memcpy(&t.v[i], &u, 4); } }
+        else throw std::invalid_argument("unknown dtype");
+        e->host[name] = std::move(t);
+    });
+}
+
+gp_status gp_set_context(gp_engine* e, const float* embed, int L, int D) {
+    if (!e || !embed || L < 1 || D < 1) return GP_ERR_INVALID;
+    return guard(e, [&] {
+        e->ctx.assign(embed, embed + (size_t)L * D);
+        e->ctx_L = L;
+        e->ctx_D = D;
+        if (e->finalized) { HIPCHK(hipSetDevice(e->cfg.device)); HIPCHK(hipDeviceSynchronize()); e->fold_context(); }
+    });
+}
+
+gp_status gp_set_timestep(gp_engine* e, float t) {
+    if (!e) return GP_ERR_INVALID;
+    return guard(e, [&] {
+        e->timestep = t;
+        if (e->finalized) { HIPCHK(hipSetDevice(e->cfg.device)); HIPCHK(hipDeviceSynchronize()); e->fold_timestep(); }
+    });
+}
+
+gp_status gp_finalize(gp_engine* e) {
+    if (!e) return GP_ERR_INVALID;
+    return guard(e, [&] { e->finalize(); });
+}
+
+gp_status gp_set_profile(gp_engine* e, int level) {
+    if (!e) return GP_ERR_INVALID;
+    e->prof = level;
+    return GP_OK;
+}
+gp_status gp_reset_timings(gp_engine* e) {
+    if (!e) return GP_ERR_INVALID;
+    e->tm = gp_timings{};
+    e->ev_used = 0;
+    return GP_OK;
+}
+gp_status gp_get_timings(gp_engine* e, gp_timings* out) {
+    if (!e || !out) return GP_ERR_INVALID;
+    return guard(e, [&] {
+        e->collect_profile();
+        *out = e->tm;
+    });
+}
+
+static void check_ready(gp_engine* e, void* stream) {
+    if (!e->finalized) throw std::logic_error("engine not finalized");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    e->st = (hipStream_t)stream;
+}
+
+gp_status gp_infer(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, int W, gp_mode mode, float* out_dev, void* stream) {
+    if (!e || !rgb_dev || !out_dev) return GP_ERR_INVALID;
+    return guard(e, [&] {
+        check_ready(e, stream);
+        if (B < 1 || H < 8 || W < 8) throw std::invalid_argument("need B >= 1 and H, W >= 8");
+        const bool stage_ev = e->prof >= 1;
+        if (stage_ev) {
+            for (int i = 0; i < 4; ++i) if (!e->ev[i]) HIPCHK(hipEventCreate(&e->ev[i]));
+            HIPCHK(hipEventRecord(e->ev[0], e->st));
+        }
+        Act lat = e->vae_encode(rgb_dev, is_u8, B, H, W);
+        if (stage_ev) HIPCHK(hipEventRecord(e->ev[1], e->st));
+        if (!e->cfg.dpt_enabled) {
+            Act v = e->unet(lat, nullptr, true);
+            e->drop(lat);
+            if (stage_ev) HIPCHK(hipEventRecord(e->ev[2], e->st));
+            // scheduler step with beta == 1: pred_x0 = -v (F5); decode_pred divides by the scaling factor
+            Act dec = e->vae_decode(v, -1.0f / e->cfg.vae_scaling_factor);
+            e->drop(v);
+            const int mean3 = !(mode == GP_MODE_NORMAL || mode == GP_MODE_SEG);
+            launch_decode_epilogue(dec.p, out_dev, B, dec.H, dec.W, dec.C, mean3, 0, e->st);
+            e->tm.n_launches++;
+            e->drop(dec);
+        } else {
+            Act feats[4];
+            e->unet(lat, feats, false);
+            e->drop(lat);
+            if (stage_ev) HIPCHK(hipEventRecord(e->ev[2], e->st));
+            Act rev[4] = {feats[3], feats[2], feats[1], feats[0]};
+            const long long out_px = (long long)rev[0].H * 8 * rev[0].W * 8;
+            e->dpt_head(rev, out_dev);
+            for (int i = 0; i < 4; ++i) e->drop(feats[i]);
+            launch_minmax_norm(out_dev, B, out_px, e->mm_ws, e->st);
+            e->tm.n_launches += 2;
+        }
+        if (stage_ev) {
+            HIPCHK(hipEventRecord(e->ev[3], e->st));
+            HIPCHK(hipEventSynchronize(e->ev[3]));
+            HIPCHK(hipEventElapsedTime(&e->tm.ms_encode, e->ev[0], e->ev[1]));
+            HIPCHK(hipEventElapsedTime(&e->tm.ms_unet, e->ev[1], e->ev[2]));
+            HIPCHK(hipEventElapsedTime(&e->tm.ms_head, e->ev[2], e->ev[3]));
+            HIPCHK(hipEventElapsedTime(&e->tm.ms_total, e->ev[0], e->ev[3]));
+        }
+        HIPCHK(hipGetLastError());
+    });
+}
+
+gp_status gp_vae_encode(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, int W, float* latent_out, void* stream) {
+    if (!e || !rgb_dev || !latent_out) return GP_ERR_INVALID;
+    return guard(e, [&] {
+        check_ready(e, stream);
+        Act lat = e->vae_encode(rgb_dev, is_u8, B, H, W);
+        e->to_nchw_f32(lat, e->cfg.vae_latent_channels, latent_out);
+        e->drop(lat);
+        HIPCHK(hipGetLastError());
+    });
+}
+
+gp_status gp_unet(gp_engine* e, const float* latent_in, int B, int h, int w, float* sample_out, float* const* feats_out, void* stream) {
+    if (!e || !latent_in) return GP_ERR_INVALID;
+    return guard(e, [&] {
+        check_ready(e, stream);
+        Act lat = e->from_nchw_f32(latent_in, B, e->cfg.unet_in_channels, h, w, 64);
+        Act feats[4];
+        Act v = e->unet(lat, feats_out ? feats : nullptr, sample_out != nullptr);
+        e->drop(lat);
+        if (sample_out) {
+            if (!v.p) throw std::logic_error("this UNet has no conv_out (DPT variant)");
+            e->to_nchw_f32(v, e->cfg.unet_out_channels, sample_out);
+        }
+        if (v.p) e->drop(v);
+        if (feats_out)
+            for (int i = 0; i < 4; ++i) {
+                if (feats_out[i]) e->to_nchw_f32(feats[i], feats[i].C, feats_out[i]);
+                e->drop(feats[i]);
+            }
+        HIPCHK(hipGetLastError());
+    });
+}
+
+gp_status gp_vae_decode(gp_engine* e, const float* pred_latent, int B, int h, int w, int mean3, float* out, void* stream) {
+    if (!e || !pred_latent || !out) return GP_ERR_INVALID;
+    return guard(e, [&] {
+        check_ready(e, stream);
+        Act z = e->from_nchw_f32(pred_latent, B, e->cfg.vae_latent_channels, h, w, 64);
+        Act dec = e->vae_decode(z, 1.0f / e->cfg.vae_scaling_factor);
+        e->drop(z);
+        // decode_pred (genpercept_pipeline.py:507-526): channel mean for 1-channel modes, no clip / shift
+        launch_decode_epilogue(dec.p, out, B, h * 8, w * 8, dec.C, mean3, 1, e->st);
+        e->tm.n_launches++;
+        e->drop(dec);
+        HIPCHK(hipGetLastError());
+    });
+}
+
+gp_status gp_dpt_head(gp_engine* e, const float* const* feats, int B, int h, int w, float* out, void* stream) {
+    if (!e || !feats || !out) return GP_ERR_INVALID;
+    return guard(e, [&] {
+        check_ready(e, stream);
+        if (!e->dpt_w_dev) throw std::logic_error("DPT head weights were not loaded");
+        const int h2 = (h - 1) / 2 + 1, w2 = (w - 1) / 2 + 1;  // UNet stride-2 pad-1 downsamples
+        const int hs[4] = {h, h, h2, (h2 - 1) / 2 + 1}, ws[4] = {w, w, w2, (w2 - 1) / 2 + 1};
+        Act f[4];
+        for (int i = 0; i < 4; ++i) f[i] = e->from_nchw_f32(feats[i], B, e->cfg.dpt_neck[i], hs[i], ws[i], e->cfg.dpt_neck[i]);
+        e->dpt_head(f, out);
+        for (int i = 0; i < 4; ++i) e->drop(f[i]);
+        HIPCHK(hipGetLastError());
+    });
+}
+
+// ---- per-kernel entry points --------------------------------------------------------------------------------------
+int gp_packed_rows(int cout) { return (cout + 255) / 256 * 256; }
+int gp_latent_size(int x) { for (int i = 0; i < 3; ++i) x = (x - 2) / 2 + 1; return x; }
+int gp_dpt_out_size(int latent) { for (int i = 0; i < 2; ++i) latent = (latent - 1) / 2 + 1; return 32 * latent; }
+
+gp_status gp_pack_weight(const float* w, int cout, int cin, int ks, int cin_pad, int geglu, void* dev_out) {
+    if (!w || !dev_out || (ks != 1 && ks != 3) || cin_pad < cin || (cin_pad % 64)) return GP_ERR_INVALID;
+    try {
+        const int n_rows = gp_packed_rows(cout);
+        std::vector<bf16_t> buf((size_t)n_rows * ks * ks * cin_pad, 0);
+        gp_engine::pack_rows(w, cout, cin, ks, cin_pad, geglu != 0, buf, 0, n_rows);
+        HIPCHK(hipMemcpy(dev_out, buf.data(), buf.size() * 2, hipMemcpyHostToDevice));
+        return GP_OK;
+    } catch (...) { return GP_ERR_HIP; }
+}
+
+gp_status gp_conv2d(const void* in, const void* w_packed, const float* bias, const void* residual, void* out, int B, int Hi, int Wi, int Cin,
+                    int Cout, int ks, int stride, int pad_t, int pad_l, int Ho, int Wo, int ups_h, int ups_w, int act, int n_store,
+                    int out_fp32, int tile_hint, void* stream) {
+    if (!in || !w_packed || !out || (Cin % 64) || (ks != 1 && ks != 3)) return GP_ERR_INVALID;
+    try {
+        IGemmParams p{};
+        p.in = (const bf16_t*)in; p.wt = (const bf16_t*)w_packed; p.bias = bias; p.res = (const bf16_t*)residual; p.out = out; p.zero = zero_page();
+        p.M = B * Ho * Wo; p.N = Cout; p.Cin = Cin; p.n_rows = gp_packed_rows(Cout); p.ks = ks;
+        p.B = B; p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+        p.ups = ups_h > 0; p.Hu = ups_h; p.Wu = ups_w;
+        const int nout = act == GP_ACT_GEGLU ? Cout / 2 : Cout;
+        const int nst = n_store > 0 ? n_store : nout;
+        p.lda = Cin; p.ldo = nst; p.ldres = nst; p.ldw = (ks == 3 ? 9 : 1) * Cin; p.n_store = nst; p.out_fp32 = out_fp32; p.act = act;
+        p.bias_mode = bias ? GP_BIAS_COL : GP_BIAS_NONE; p.batch = 1;
+        launch_igemm(p, tile_hint, (hipStream_t)stream);
+        HIPCHK(hipGetLastError());
+        return GP_OK;
+    } catch (...) { return GP_ERR_HIP; }
+}
+
+gp_status gp_gemm(const void* a, int lda, const void* bt, int ldb, const float* bias, int bias_mode, const void* residual, int ldres, void* out,
+                  int ldo, int M, int N, int K, int n_rows_bt, int n_store, int act, int out_fp32, int batch, long long a_bs, long long bt_bs,
+                  long long out_bs, int tile_hint, void* stream) {
+    if (!a || !bt || !out || (K % 64)) return GP_ERR_INVALID;
+    try {
+        IGemmParams p{};
+        p.in = (const bf16_t*)a; p.wt = (const bf16_t*)bt; p.bias = bias; p.res = (const bf16_t*)residual; p.out = out; p.zero = zero_page();
+        p.M = M; p.N = N; p.Cin = K; p.n_rows = n_rows_bt; p.ks = 1; p.stride = 1;
+        p.lda = lda; p.ldw = ldb; p.ldo = ldo; p.ldres = ldres; p.n_store = n_store > 0 ? n_store : N; p.out_fp32 = out_fp32; p.act = act;
+        p.bias_mode = bias ? bias_mode : GP_BIAS_NONE; p.batch = batch > 0 ? batch : 1; p.in_bs = a_bs; p.wt_bs = bt_bs; p.out_bs = out_bs;
+        launch_igemm(p, tile_hint, (hipStream_t)stream);
+        HIPCHK(hipGetLastError());
+        return GP_OK;
+    } catch (...) { return GP_ERR_HIP; }
+}
+
+gp_status gp_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int silu, void* stream) {
+    if (!x || !y || !gamma || !beta || (C % 8) || (C % G)) return GP_ERR_INVALID;
+    try {
+        const size_t need = (size_t)groupnorm_ws_floats(B, HW, C, G);
+        if (need > g_gn_ws_floats) {
+            if (g_gn_ws) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(g_gn_ws)); }
+            HIPCHK(hipMalloc((void**)&g_gn_ws, need * 4));
+            g_gn_ws_floats = need;
+        }
+        launch_groupnorm((const bf16_t*)x, (bf16_t*)y, gamma, beta, B, HW, C, G, eps, silu, g_gn_ws, (hipStream_t)stream);
+        HIPCHK(hipGetLastError());
+        return GP_OK;
+    } catch (...) { return GP_ERR_HIP; }
+}
+
+gp_status gp_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C, float eps, void* stream) {
+    if (!x || !y || (C % 8) || C > 4096) return GP_ERR_INVALID;
+    launch_layernorm((const bf16_t*)x, (bf16_t*)y, gamma, beta, rows, C, eps, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
+}
+
+gp_status gp_flash_attention(const void* q, const void* k, const void* vt, void* out, int B, int T, int heads, int ldq, int ldk, int Tpad, int ldo,
+                             void* stream) {
+    if (!q || !k || !vt || !out || (Tpad % 64) || Tpad < T) return GP_ERR_INVALID;
+    try {
+        launch_flash_attn64((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, zero_page(), B, T, heads, ldq, ldk, Tpad, ldo,
+                            (hipStream_t)stream);
+        HIPCHK(hipGetLastError());
+        return GP_OK;
+    } catch (...) { return GP_ERR_HIP; }
+}
+
+gp_status gp_cross_attention(const void* q, const float* kc, const float* vc, void* out, int rows, int C, int L, void* stream) {
+    if (!q || !kc || !vc || !out || (C % 64)) return GP_ERR_INVALID;
+    launch_cross_attn_small((const bf16_t*)q, kc, vc, (bf16_t*)out, rows, C, L, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
+}
+
+gp_status gp_softmax_rows(const float* in, void* out, int rows, int T, int ld, float scale, void* stream) {
+    if (!in || !out || ld < T) return GP_ERR_INVALID;
+    launch_softmax_rows(in, (bf16_t*)out, rows, T, ld, scale, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
+}
+
+gp_status gp_bilinear(const void* in, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream) {
+    if (!in || !out || (C % 8)) return GP_ERR_INVALID;
+    launch_bilinear((const bf16_t*)in, (bf16_t*)out, B, Hi, Wi, Ho, Wo, C, align_corners, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
+}
+
+}  // extern "C"

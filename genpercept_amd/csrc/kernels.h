@@ -1,0 +1,72 @@
+// Host-side launchers of the gfx950 kernels (internal; the public C-ABI is include/genpercept_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;
+
+enum { GP_ACT_NONE = 0, GP_ACT_SILU = 1, GP_ACT_RELU = 2, GP_ACT_GEGLU = 3 };
+enum { GP_BIAS_NONE = 0, GP_BIAS_COL = 1, GP_BIAS_ROW = 2 };
+
+// Implicit-GEMM problem:  out[m][n] = act( sum_k A[m][k] * W[n][k] + bias ) (+ res[m][n])
+//   rows m  = output pixels (b, oy, ox) of an NHWC tensor (or plain matrix rows when ks == 1)
+//   cols n  = output channels; W is [n][tap][cin] (k-contiguous), i.e. "B transposed"
+//   k       = (tap, cin), cin % 64 == 0
+struct IGemmParams {
+    const bf16_t* in;     // NHWC input [B][Hi][Wi][Cin] (row stride lda elements when ks == 1)
+    const bf16_t* wt;     // [n_rows][taps][Cin]
+    const float* bias;    // [Cout] (COL) or [M] (ROW) or nullptr
+    const bf16_t* res;    // residual [M][ldres] bf16 or nullptr
+    void* out;            // bf16 or fp32 [M][ldo]
+    const bf16_t* zero;   // >= 256 bytes of zeros (source for padding / out-of-range rows)
+    int M, N, Cin;        // N = valid output channels (before GEGLU halving)
+    int n_rows;           // rows of `wt` that may be read (>= N; rows beyond read the zero page)
+    int ks;               // 1 or 3
+    int B, Hi, Wi, Ho, Wo;  // geometry (ks == 3, or ks == 1 with identical in/out geometry)
+    int stride, pad_t, pad_l;
+    int ups;              // 1: nearest-upsample the input to (Hu, Wu) before the conv
+    int Hu, Wu;
+    int lda, ldo, ldres;  // element strides of in (ks==1), out, res
+    int ldw;              // element stride between rows of `wt` (taps*Cin for packed weights)
+    int n_store;          // columns written (>= N_out; columns in [N_out, n_store) are written as 0)
+    int out_fp32;         // 1: fp32 output
+    int act, bias_mode;
+    int batch;            // grid.y batches with the strides below (elements)
+    long long in_bs, wt_bs, out_bs, res_bs, bias_bs;
+};
+
+void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s);  // tile_hint: 0 auto, 1 = 128x128, 2 = 64x64, 3 = 256x32
+
+// GroupNorm over NHWC bf16 (fp32 statistics), optional fused SiLU.  ws: >= B*nchunk*G*2 floats.
+void launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps,
+                      int silu, float* ws, hipStream_t s);
+int groupnorm_ws_floats(int B, int HW, int C, int G);
+
+// LayerNorm over the last dim of [rows][C] bf16.
+void launch_layernorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int rows, int C, float eps, hipStream_t s);
+
+// Flash self-attention, head_dim 64.  q/k: [B][T][ld] bf16 (head h at column h*64), vt: [B][heads*64][Tpad] bf16,
+// out [B][T][ldo].
+void launch_flash_attn64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, const bf16_t* zero, int B, int T, int heads,
+                         int ldq, int ldk, int Tpad, int ldo, hipStream_t s);
+
+// Cross-attention against a small constant context: q [rows][C] bf16, kc/vc [L][C] fp32, head_dim 64.
+void launch_cross_attn_small(const bf16_t* q, const float* kc, const float* vc, bf16_t* out, int rows, int C, int L, hipStream_t s);
+
+// Row softmax: in fp32 [rows][ld] (first T columns valid) -> bf16 [rows][ld], columns >= T written as 0.
+void launch_softmax_rows(const float* in, bf16_t* out, int rows, int T, int ld, float scale, hipStream_t s);
+
+// Elementwise / layout kernels
+void launch_rgb_prologue(const void* rgb, int is_u8, bf16_t* out, int B, int H, int W, int Cpad, hipStream_t s);  // NCHW -> NHWC, x/255*2-1
+void launch_concat(const bf16_t* a, int Ca, const bf16_t* b, int Cb, bf16_t* out, long long pixels, hipStream_t s);
+void launch_nchw_f32_to_nhwc(const float* in, bf16_t* out, int B, int C, int H, int W, int Cpad, hipStream_t s);
+void launch_nhwc_to_nchw_f32(const bf16_t* in, float* out, int B, int C, int H, int W, int ld, hipStream_t s);
+void launch_decode_epilogue(const bf16_t* in, float* out, int B, int H, int W, int ld, int mean3, int raw, hipStream_t s);  // mean, clip, (x+1)/2
+void launch_scale_pad(const bf16_t* in, bf16_t* out, long long pixels, int C, int ldi, int ldo, float scale, hipStream_t s);
+void launch_pointwise_small(const bf16_t* in, bf16_t* out, const float* w, const float* bias, long long pixels, int Cin, int Cout, int ldi,
+                            int ldo, float in_scale, hipStream_t s);  // 1x1 conv for Cin, Cout <= 8 (post_quant_conv)
+void launch_relu(const bf16_t* in, bf16_t* out, long long n, hipStream_t s);
+void launch_add(const bf16_t* a, const bf16_t* b, bf16_t* out, long long n, hipStream_t s);
+void launch_bilinear(const bf16_t* in, bf16_t* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, hipStream_t s);
+void launch_dpt_final(const bf16_t* in, const float* w, float bias, float* out, int B, int HW, int Cin, hipStream_t s);  // ReLU'd 32ch -> 1
+void launch_minmax_norm(float* x, int B, long long n, float* ws, hipStream_t s);  // per-image (x-min)/(max-min)

@@ -1,0 +1,216 @@
+// GroupNorm(+SiLU) and LayerNorm for NHWC bf16 activations (K7/K8 of SURVEY.md §2.3).  HBM-bound: every kernel moves
+// 16 bytes per lane per access, statistics in fp32, deterministic (no atomics).
+#include "common.h"
+#include "kernels.h"
+
+static inline int gn_nchunk(int HW) {
+    int n = HW / 256;
+    if (n < 1) n = 1;
+    if (n > 256) n = 256;
+    return n;
+}
+int groupnorm_ws_floats(int B, int HW, int C, int G) { return B * gn_nchunk(HW) * G * 2; }
+
+// ---- pass 1: per (image, pixel-chunk, group) partial sum / sum of squares -----------------------------------------
+// Thread t owns VPT fixed 8-channel vectors (v = tv, tv + tpp, ...) and walks pixels p = pl, pl + PL, ... of the chunk.
+template <int VPT>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ ws, int HW, int C, int G,
+                                                        int nchunk, int tpp, int PL) {
+    extern __shared__ __attribute__((aligned(16))) float sred[];  // [PL][C][2]
+    const int b = blockIdx.y, ck = blockIdx.x;
+    const int nvec = C >> 3;
+    const int tid = threadIdx.x;
+    const int pl = tid / tpp, tv = tid - pl * tpp;
+    const int per = (HW + nchunk - 1) / nchunk;
+    const int p0 = ck * per, p1 = min(HW, p0 + per);
+    float s[VPT][8], q[VPT][8];
+#pragma unroll
+    for (int u = 0; u < VPT; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[u][e] = q[u][e] = 0.f;
+    if (pl < PL) {
+        const bf16_t* xb = x + (long long)b * HW * C;
+        for (int p = p0 + pl; p < p1; p += PL) {
+#pragma unroll
+            for (int u = 0; u < VPT; ++u) {
+                const int v = tv + u * tpp;
+                if (v < nvec) {
+                    const uint4 raw = *(const uint4*)(xb + (long long)p * C + v * 8);
+                    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = bflo(w[e]), hi = bfhi(w[e]);
+                        s[u][2 * e] += lo; q[u][2 * e] += lo * lo;
+                        s[u][2 * e + 1] += hi; q[u][2 * e + 1] += hi * hi;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) {
+            const int v = tv + u * tpp;
+            if (v < nvec) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sred[((pl * C) + v * 8 + e) * 2 + 0] = s[u][e];
+                    sred[((pl * C) + v * 8 + e) * 2 + 1] = q[u][e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < G) {
+        const int cpg = C / G;
+        float ss = 0.f, qq = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c)
+            for (int l = 0; l < PL; ++l) { ss += sred[(l * C + c) * 2]; qq += sred[(l * C + c) * 2 + 1]; }
+        float* o = ws + (((long long)b * nchunk + ck) * G + tid) * 2;
+        o[0] = ss;
+        o[1] = qq;
+    }
+}
+
+// ---- pass 2: combine partials (Chan), fold gamma/beta into per-channel scale/shift, apply (+SiLU) ------------------
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ ws, int HW, int C, int G,
+                                                        int nchunk, float eps, int silu) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [G*2] mean/rstd, then [C] scale, [C] shift
+    float* s_stat = sm;
+    float* s_scale = sm + 2 * G;
+    float* s_shift = s_scale + C;
+    const int b = blockIdx.y, ck = blockIdx.x, tid = threadIdx.x;
+    const int cpg = C / G;
+    const int per = (HW + nchunk - 1) / nchunk;
+    if (tid < G) {
+        const float* w = ws + ((long long)b * nchunk * G + tid) * 2;
+        float tot = 0.f;
+        for (int k = 0; k < nchunk; ++k) tot += w[(long long)k * G * 2];
+        const float n_all = (float)HW * (float)cpg;
+        const float mean = tot / n_all;
+        float m2 = 0.f;
+        for (int k = 0; k < nchunk; ++k) {
+            const int cnt_px = min(HW, (k + 1) * per) - min(HW, k * per);
+            if (cnt_px <= 0) continue;
+            const float nk = (float)cnt_px * (float)cpg;
+            const float sk = w[(long long)k * G * 2], qk = w[(long long)k * G * 2 + 1];
+            const float mk = sk / nk;
+            m2 += fmaxf(qk - sk * mk, 0.f) + nk * (mk - mean) * (mk - mean);
+        }
+        s_stat[2 * tid] = mean;
+        s_stat[2 * tid + 1] = rsqrtf(m2 / n_all + eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const float sc = s_stat[2 * g + 1] * gamma[c];
+        s_scale[c] = sc;
+        s_shift[c] = beta[c] - s_stat[2 * g] * sc;
+    }
+    __syncthreads();
+    const int nvec = C >> 3;
+    const int p0 = ck * per, p1 = min(HW, p0 + per);
+    const long long base = (long long)b * HW * C;
+    const long long e0 = (long long)p0 * nvec, e1 = (long long)p1 * nvec;
+    for (long long e = e0 + tid; e < e1; e += 256) {
+        const int v = (int)(e % nvec);
+        const uint4 raw = *(const uint4*)(x + base + e * 8);
+        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = v * 8 + 2 * k;
+            o[2 * k] = bflo(w[k]) * s_scale[c] + s_shift[c];
+            o[2 * k + 1] = bfhi(w[k]) * s_scale[c + 1] + s_shift[c + 1];
+        }
+        if (silu) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = silu_f(o[k]);
+        }
+        uint4 r;
+        r.x = pack_bf16x2(o[0], o[1]); r.y = pack_bf16x2(o[2], o[3]); r.z = pack_bf16x2(o[4], o[5]); r.w = pack_bf16x2(o[6], o[7]);
+        *(uint4*)(y + base + e * 8) = r;
+    }
+}
+
+void launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int silu,
+                      float* ws, hipStream_t s) {
+    const int nchunk = gn_nchunk(HW);
+    const int nvec = C / 8;
+    const int vpt = (nvec + 255) / 256;           // 1 or 2 (C <= 4096)
+    const int tpp = (nvec + vpt - 1) / vpt;       // threads per pixel
+    const int PL = 256 / tpp;                     // pixel lanes
+    const size_t lds1 = (size_t)PL * C * 2 * sizeof(float);
+    dim3 grid(nchunk, B);
+    if (vpt == 1) hipLaunchKernelGGL(gn_stats_kernel<1>, grid, dim3(256), lds1, s, x, ws, HW, C, G, nchunk, tpp, PL);
+    else hipLaunchKernelGGL(gn_stats_kernel<2>, grid, dim3(256), lds1, s, x, ws, HW, C, G, nchunk, tpp, PL);
+    const size_t lds2 = (size_t)(2 * G + 2 * C) * sizeof(float);
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), lds2, s, x, y, gamma, beta, (const float*)ws, HW, C, G, nchunk, eps, silu);
+}
+
+// ---- LayerNorm: one wave per row, row kept in registers (C <= 4096), exact two-pass statistics -------------------
+template <int VPT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = C >> 3;
+    float v[VPT][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int vi = lane + u * 64;
+        if (vi < nvec) {
+            const uint4 raw = *(const uint4*)(x + (long long)row * C + vi * 8);
+            const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[u][2 * k] = bflo(w[k]); v[u][2 * k + 1] = bfhi(w[k]); }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += v[u][k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[u][k] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int vi = lane + u * 64;
+        if (vi < nvec) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float d = v[u][k] - mean; sq += d * d; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = rsqrtf(sq / (float)C + eps);
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int vi = lane + u * 64;
+        if (vi < nvec) {
+            const float4 g0 = *(const float4*)(gamma + vi * 8), g1 = *(const float4*)(gamma + vi * 8 + 4);
+            const float4 b0 = *(const float4*)(beta + vi * 8), b1 = *(const float4*)(beta + vi * 8 + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (v[u][k] - mean) * rstd * gg[k] + bb[k];
+            uint4 r;
+            r.x = pack_bf16x2(o[0], o[1]); r.y = pack_bf16x2(o[2], o[3]); r.z = pack_bf16x2(o[4], o[5]); r.w = pack_bf16x2(o[6], o[7]);
+            *(uint4*)(y + (long long)row * C + vi * 8) = r;
+        }
+    }
+}
+
+void launch_layernorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int rows, int C, float eps, hipStream_t s) {
+    const int nvec = C / 8;
+    const int vpt = (nvec + 63) / 64;
+    dim3 grid((rows + 3) / 4);
+    if (vpt <= 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, y, gamma, beta, rows, C, eps);
+    else if (vpt <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, y, gamma, beta, rows, C, eps);
+    else if (vpt <= 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, y, gamma, beta, rows, C, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, x, y, gamma, beta, rows, C, eps);
+}

@@ -1,0 +1,395 @@
+"""ctypes binding of libgenpercept_hip.so (include/genpercept_hip.h).  PyTorch-ROCm tensors are used for device memory
+and streams only; every tensor operation of the hot path runs in the HIP library.  There is NO fallback: if the library
+is missing or fails to load, importing the engine raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgenpercept_hip.so")
+
+GP_OK = 0
+MODES = {"depth": 0, "normal": 1, "seg": 2, "matting": 3, "dis": 4, "disparity": 5}
+ONE_CHANNEL_MODES = ("depth", "matting", "dis", "disparity")  # genpercept_pipeline.py:523
+ACT = {"none": 0, "silu": 1, "relu": 2, "geglu": 3}
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+class GpConfig(C.Structure):
+    _fields_ = [
+        ("device", C.c_int),
+        ("unet_in_channels", C.c_int), ("unet_out_channels", C.c_int),
+        ("unet_block_out", C.c_int * 4), ("unet_num_heads", C.c_int * 4), ("unet_down_attn", C.c_int * 4),
+        ("unet_layers_per_block", C.c_int), ("unet_cross_dim", C.c_int), ("unet_has_out", C.c_int), ("unet_norm_eps", C.c_float),
+        ("vae_block_out", C.c_int * 4), ("vae_layers_per_block", C.c_int), ("vae_latent_channels", C.c_int),
+        ("vae_norm_eps", C.c_float), ("vae_scaling_factor", C.c_float),
+        ("dpt_enabled", C.c_int), ("dpt_neck", C.c_int * 4), ("dpt_fusion", C.c_int),
+        ("norm_groups", C.c_int),
+    ]
+
+
+class GpTimings(C.Structure):
+    _fields_ = [
+        ("ms_encode", C.c_float), ("ms_unet", C.c_float), ("ms_head", C.c_float), ("ms_total", C.c_float),
+        ("flops_igemm", C.c_double), ("flops_attn", C.c_double),
+        ("ms_igemm", C.c_float), ("ms_attn", C.c_float),
+        ("n_igemm", C.c_int), ("n_attn", C.c_int), ("n_launches", C.c_int),
+    ]
+
+
+_lib = None
+
+# (name, restype, argtypes) for every symbol include/genpercept_hip.h declares
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+SYMBOLS = {
+    "gp_default_config": (None, [C.POINTER(GpConfig)]),
+    "gp_create": (_i, [C.POINTER(GpConfig), C.POINTER(_vp)]),
+    "gp_destroy": (None, [_vp]),
+    "gp_last_error": (C.c_char_p, [_vp]),
+    "gp_version": (C.c_char_p, []),
+    "gp_load_tensor": (_i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i, _i]),
+    "gp_set_context": (_i, [_vp, _vp, _i, _i]),
+    "gp_set_timestep": (_i, [_vp, _f]),
+    "gp_finalize": (_i, [_vp]),
+    "gp_infer": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "gp_vae_encode": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "gp_unet": (_i, [_vp, _vp, _i, _i, _i, _vp, C.POINTER(_vp), _vp]),
+    "gp_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "gp_dpt_head": (_i, [_vp, C.POINTER(_vp), _i, _i, _i, _vp, _vp]),
+    "gp_set_profile": (_i, [_vp, _i]),
+    "gp_get_timings": (_i, [_vp, C.POINTER(GpTimings)]),
+    "gp_reset_timings": (_i, [_vp]),
+    "gp_packed_rows": (_i, [_i]),
+    "gp_latent_size": (_i, [_i]),
+    "gp_dpt_out_size": (_i, [_i]),
+    "gp_pack_weight": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "gp_conv2d": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 17 + [_vp]),
+    "gp_gemm": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
+    "gp_groupnorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "gp_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "gp_flash_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "gp_cross_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "gp_softmax_rows": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
+    "gp_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+}
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the HIP library and bind every C-ABI symbol.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get("GENPERCEPT_HIP_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: build it with `python -m genpercept_amd.build` (hipcc, gfx950). "
+                          "There is no CPU/PyTorch fallback for the inference path.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _stream_ptr() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class Engine:
+    """One engine per GPU (not re-entrant).  Mirrors the reference's module handles: weights in, stages out."""
+
+    def __init__(self, device: int = 0, unet_cfg=None, vae_cfg=None, dpt_cfg=None):
+        lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("genpercept_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU path")
+        self.lib = lib
+        cfg = GpConfig()
+        lib.gp_default_config(C.byref(cfg))
+        cfg.device = device
+        if unet_cfg is not None:
+            cfg.unet_in_channels, cfg.unet_out_channels = unet_cfg.in_channels, unet_cfg.out_channels
+            for i in range(4):
+                cfg.unet_block_out[i] = unet_cfg.block_out_channels[i]
+                cfg.unet_num_heads[i] = unet_cfg.num_heads[i]
+                cfg.unet_down_attn[i] = int(unet_cfg.down_has_attn[i])
+            cfg.unet_layers_per_block = unet_cfg.layers_per_block
+            cfg.unet_cross_dim = unet_cfg.cross_attention_dim
+            cfg.unet_has_out = int(unet_cfg.has_out)
+            cfg.unet_norm_eps = unet_cfg.norm_eps
+        if vae_cfg is not None:
+            for i in range(4):
+                cfg.vae_block_out[i] = vae_cfg.block_out_channels[i]
+            cfg.vae_layers_per_block = vae_cfg.layers_per_block
+            cfg.vae_latent_channels = vae_cfg.latent_channels
+            cfg.vae_norm_eps = vae_cfg.norm_eps
+            cfg.vae_scaling_factor = vae_cfg.scaling_factor
+        if dpt_cfg is not None:
+            cfg.dpt_enabled = 1
+            for i in range(4):
+                cfg.dpt_neck[i] = dpt_cfg.neck_hidden_sizes[i]
+            cfg.dpt_fusion = dpt_cfg.fusion_hidden_size
+        self.cfg = cfg
+        self.device = torch.device("cuda", device)
+        self._h = C.c_void_p()
+        st = lib.gp_create(C.byref(cfg), C.byref(self._h))
+        if st != GP_OK:
+            msg = lib.gp_last_error(self._h).decode() if self._h else "gp_create failed"
+            raise RuntimeError(msg)
+        self.finalized = False
+
+    # -- error handling --------------------------------------------------------------------------------------------
+    def _check(self, st: int):
+        if st == GP_OK:
+            return
+        msg = self.lib.gp_last_error(self._h).decode()
+        if st == 1:
+            raise ValueError(msg)
+        if st == 3:
+            raise KeyError(msg)
+        raise RuntimeError(f"genpercept_hip error {st}: {msg}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.gp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights -----------------------------------------------------------------------------------------------------
+    def load_state_dict(self, module: str, sd: Dict[str, torch.Tensor]):
+        """module in {'vae', 'unet', 'dpt'}; sd uses the diffusers key layout (any float dtype, CPU or GPU)."""
+        for k, t in sd.items():
+            t = t.detach()
+            if t.dtype not in _DT:
+                t = t.float()
+            t = t.cpu().contiguous()
+            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape) if t.dim() else (C.c_int64 * 1)(1)
+            nd = t.dim()
+            src = t.view(torch.int16) if t.dtype in (torch.float16, torch.bfloat16) else t
+            self._check(self.lib.gp_load_tensor(self._h, f"{module}.{k}".encode(), src.data_ptr(), shape, nd, _DT[t.dtype]))
+
+    def set_context(self, embed: torch.Tensor):
+        e = embed.detach().float().cpu().reshape(-1, embed.shape[-1]).contiguous()
+        self._check(self.lib.gp_set_context(self._h, e.data_ptr(), e.shape[0], e.shape[1]))
+
+    def set_timestep(self, t: float):
+        self._check(self.lib.gp_set_timestep(self._h, float(t)))
+
+    def finalize(self):
+        self._check(self.lib.gp_finalize(self._h))
+        self.finalized = True
+
+    # -- stages --------------------------------------------------------------------------------------------------------
+    def infer(self, rgb: torch.Tensor, mode: str) -> torch.Tensor:
+        """rgb: [B,3,H,W] uint8 (0..255) or float32 in [-1,1], on this engine's device.  Returns fp32 [B,C,H,W] in [0,1]."""
+        assert rgb.is_cuda and rgb.dim() == 4 and rgb.shape[1] == 3
+        is_u8 = rgb.dtype == torch.uint8
+        if not is_u8:
+            rgb = rgb.float()
+        rgb = rgb.contiguous()
+        b, _, h, w = rgb.shape
+        c = 1 if (mode in ONE_CHANNEL_MODES or self.cfg.dpt_enabled) else 3
+        lh, lw = self.lib.gp_latent_size(h), self.lib.gp_latent_size(w)
+        oh, ow = (self.lib.gp_dpt_out_size(lh), self.lib.gp_dpt_out_size(lw)) if self.cfg.dpt_enabled else (8 * lh, 8 * lw)
+        out = torch.empty((b, c, oh, ow), dtype=torch.float32, device=rgb.device)
+        self._check(self.lib.gp_infer(self._h, rgb.data_ptr(), int(is_u8), b, h, w, MODES[mode], out.data_ptr(), _stream_ptr()))
+        return out
+
+    def vae_encode(self, rgb: torch.Tensor) -> torch.Tensor:
+        is_u8 = rgb.dtype == torch.uint8
+        rgb = (rgb if is_u8 else rgb.float()).contiguous()
+        b, _, h, w = rgb.shape
+        out = torch.empty((b, self.cfg.vae_latent_channels, self.lib.gp_latent_size(h), self.lib.gp_latent_size(w)), dtype=torch.float32,
+                          device=rgb.device)
+        self._check(self.lib.gp_vae_encode(self._h, rgb.data_ptr(), int(is_u8), b, h, w, out.data_ptr(), _stream_ptr()))
+        return out
+
+    def _feat_shapes(self, b, h, w):
+        bo = list(self.cfg.unet_block_out)
+        # multi_level_feats (custom_unet.py:365-400): each taken after that up block's upsampler
+        return [(b, bo[3], _up(h, 3, 1), _up(w, 3, 1)), (b, bo[2], _up(h, 3, 2), _up(w, 3, 2)), (b, bo[1], h, w), (b, bo[0], h, w)]
+
+    def unet(self, latent: torch.Tensor, want_sample: bool = True, want_feats: bool = False):
+        latent = latent.float().contiguous()
+        b, _, h, w = latent.shape
+        sample = torch.empty((b, self.cfg.unet_out_channels, h, w), dtype=torch.float32, device=latent.device) if want_sample else None
+        feats = None
+        fp = None
+        if want_feats:
+            feats = [torch.empty(s, dtype=torch.float32, device=latent.device) for s in self._feat_shapes(b, h, w)]
+            fp = (C.c_void_p * 4)(*[f.data_ptr() for f in feats])
+        self._check(self.lib.gp_unet(self._h, latent.data_ptr(), b, h, w, _ptr(sample), fp, _stream_ptr()))
+        return sample, feats
+
+    def vae_decode(self, pred_latent: torch.Tensor, mean3: bool) -> torch.Tensor:
+        z = pred_latent.float().contiguous()
+        b, _, h, w = z.shape
+        out = torch.empty((b, 1 if mean3 else 3, h * 8, w * 8), dtype=torch.float32, device=z.device)
+        self._check(self.lib.gp_vae_decode(self._h, z.data_ptr(), b, h, w, int(mean3), out.data_ptr(), _stream_ptr()))
+        return out
+
+    def dpt_head(self, feats: Sequence[torch.Tensor]) -> torch.Tensor:
+        feats = [f.float().contiguous() for f in feats]
+        b, _, h, w = feats[0].shape
+        out = torch.empty((b, self.lib.gp_dpt_out_size(h), self.lib.gp_dpt_out_size(w)), dtype=torch.float32, device=feats[0].device)
+        fp = (C.c_void_p * 4)(*[f.data_ptr() for f in feats])
+        self._check(self.lib.gp_dpt_head(self._h, fp, b, h, w, out.data_ptr(), _stream_ptr()))
+        return out
+
+    # -- profiling -----------------------------------------------------------------------------------------------------
+    def set_profile(self, level: int):
+        self._check(self.lib.gp_set_profile(self._h, level))
+
+    def reset_timings(self):
+        self._check(self.lib.gp_reset_timings(self._h))
+
+    def timings(self) -> dict:
+        t = GpTimings()
+        self._check(self.lib.gp_get_timings(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in GpTimings._fields_}
+
+
+def _up(x: int, levels: int, ups: int) -> int:
+    """spatial size after `levels` stride-2 (pad 1) downsamples followed by `ups` upsample-to-skip-size steps."""
+    sizes = [x]
+    for _ in range(levels):
+        sizes.append((sizes[-1] - 1) // 2 + 1)
+    return sizes[levels - ups]
+
+
+# ---- per-kernel wrappers (used by tests/) -----------------------------------------------------------------------------
+def to_nhwc_bf16(x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
+    """[B,C,H,W] float -> contiguous [B,H,W,Cpad] bf16 (zero-padded channels)."""
+    b, c, h, w = x.shape
+    cp = cpad or c
+    out = torch.zeros((b, h, w, cp), dtype=torch.bfloat16, device=x.device)
+    out[..., :c] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    return out.contiguous()
+
+
+def pack_weight(w: torch.Tensor, cin_pad: Optional[int] = None, geglu: bool = False, device="cuda") -> torch.Tensor:
+    lib = load_library()
+    w = w.detach().float().cpu().contiguous()
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    cout, cin, ks, _ = w.shape
+    cp = cin_pad or ((cin + 63) // 64 * 64)
+    rows = lib.gp_packed_rows(cout)
+    out = torch.empty((rows, ks * ks, cp), dtype=torch.bfloat16, device=device)
+    st = lib.gp_pack_weight(w.data_ptr(), cout, cin, ks, cp, int(geglu), out.data_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_pack_weight failed ({st})")
+    return out
+
+
+def conv2d(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int, ks: int, stride: int = 1, pad_t: int = 1,
+           pad_l: int = 1, out_hw=None, ups_hw=None, residual: Optional[torch.Tensor] = None, act: str = "none", n_store: int = 0,
+           out_fp32: bool = False, tile: int = 0) -> torch.Tensor:
+    lib = load_library()
+    b, hi, wi, cin = x_nhwc.shape
+    uh, uw = ups_hw if ups_hw else (0, 0)
+    hin, win = (uh, uw) if ups_hw else (hi, wi)
+    ho, wo = out_hw if out_hw else (hin, win)
+    nout = cout // 2 if act == "geglu" else cout
+    nst = n_store or nout
+    out = torch.empty((b, ho, wo, nst), dtype=torch.float32 if out_fp32 else torch.bfloat16, device=x_nhwc.device)
+    st = lib.gp_conv2d(x_nhwc.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), b, hi, wi, cin, cout, ks, stride,
+                       pad_t if ks == 3 else 0, pad_l if ks == 3 else 0, ho, wo, uh, uw, ACT[act], nst, int(out_fp32), tile, _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_conv2d failed ({st})")
+    return out
+
+
+def gemm(a: torch.Tensor, bt: torch.Tensor, bias=None, bias_mode: int = 1, residual=None, act: str = "none", out_fp32: bool = False,
+         n_store: int = 0, tile: int = 0) -> torch.Tensor:
+    """out = a @ bt^T for 2-D (or batched 3-D) bf16 tensors; K % 64 == 0."""
+    lib = load_library()
+    batched = a.dim() == 3
+    if not batched:
+        a, bt = a[None], bt[None]
+    bsz, m, k = a.shape
+    n = bt.shape[1]
+    nout = n // 2 if act == "geglu" else n
+    nst = n_store or nout
+    out = torch.empty((bsz, m, nst), dtype=torch.float32 if out_fp32 else torch.bfloat16, device=a.device)
+    st = lib.gp_gemm(a.data_ptr(), a.stride(1), bt.data_ptr(), bt.stride(1), _ptr(bias), bias_mode, _ptr(residual), nst, out.data_ptr(), nst, m, n,
+                     k, n, nst, ACT[act], int(out_fp32), bsz, a.stride(0), bt.stride(0), m * nst, tile, _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_gemm failed ({st})")
+    return out if batched else out[0]
+
+
+def groupnorm(x_nhwc: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool) -> torch.Tensor:
+    lib = load_library()
+    b, h, w, c = x_nhwc.shape
+    y = torch.empty_like(x_nhwc)
+    st = lib.gp_groupnorm(x_nhwc.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), b, h * w, c, groups, eps, int(silu), _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_groupnorm failed ({st})")
+    return y
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    lib = load_library()
+    rows, c = x.shape
+    y = torch.empty_like(x)
+    st = lib.gp_layernorm(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, c, eps, _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_layernorm failed ({st})")
+    return y
+
+
+def flash_attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int) -> torch.Tensor:
+    """q, k: [B,T,C] bf16 (row stride may exceed C); vt: [B,C,Tpad] bf16, zero beyond T."""
+    lib = load_library()
+    b, t, c = q.shape
+    out = torch.empty((b, t, c), dtype=torch.bfloat16, device=q.device)
+    st = lib.gp_flash_attention(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), b, t, heads, q.stride(1), k.stride(1), vt.shape[2], c,
+                                _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_flash_attention failed ({st})")
+    return out
+
+
+def cross_attention(q: torch.Tensor, kc: torch.Tensor, vc: torch.Tensor) -> torch.Tensor:
+    lib = load_library()
+    rows, c = q.shape
+    out = torch.empty_like(q)
+    st = lib.gp_cross_attention(q.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), rows, c, kc.shape[0], _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_cross_attention failed ({st})")
+    return out
+
+
+def softmax_rows(x: torch.Tensor, t: int, scale: float) -> torch.Tensor:
+    lib = load_library()
+    rows, ld = x.shape
+    out = torch.empty((rows, ld), dtype=torch.bfloat16, device=x.device)
+    st = lib.gp_softmax_rows(x.data_ptr(), out.data_ptr(), rows, t, ld, scale, _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_softmax_rows failed ({st})")
+    return out
+
+
+def bilinear(x_nhwc: torch.Tensor, out_hw, align_corners: bool) -> torch.Tensor:
+    lib = load_library()
+    b, h, w, c = x_nhwc.shape
+    out = torch.empty((b, out_hw[0], out_hw[1], c), dtype=torch.bfloat16, device=x_nhwc.device)
+    st = lib.gp_bilinear(x_nhwc.data_ptr(), out.data_ptr(), b, h, w, out_hw[0], out_hw[1], c, int(align_corners), _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_bilinear failed ({st})")
+    return out

@@ -1,0 +1,103 @@
+"""Depth evaluation protocol next to the hot path: least-squares alignment and the ten metrics
+`eval.py` reports, restated in numpy (float64) so "AbsRel unchanged" can be stated for predictions of this engine.
+
+Semantics follow /root/reference/src/util/alignment.py:29-94 (align_depth_least_square, depth2disparity) and
+/root/reference/src/util/metric.py:34-158; pinned by tests/golden/metrics_ref.npz (outputs of those reference functions).
+Per-image masked means, then a mean over images — exactly the reference's reduction order.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+
+def align_depth_least_square(gt: np.ndarray, pred: np.ndarray, valid_mask: np.ndarray) -> Tuple[np.ndarray, float, float]:
+    """min_{s,t} || s * pred + t - gt ||^2 over valid pixels; returns (s * pred + t, s, t)."""
+    g = np.asarray(gt).squeeze()
+    p = np.asarray(pred).squeeze()
+    m = np.asarray(valid_mask).squeeze().astype(bool)
+    a = np.stack([p[m], np.ones_like(p[m])], axis=1)
+    x = np.linalg.lstsq(a, g[m], rcond=None)[0]
+    scale, shift = float(x[0]), float(x[1])
+    return np.asarray(pred) * scale + shift, scale, shift
+
+
+def depth2disparity(depth: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    d = np.zeros_like(depth)
+    pos = depth > 0
+    d[pos] = 1.0 / depth[pos]
+    return d, pos
+
+
+def _masked_mean(x: np.ndarray, mask: Optional[np.ndarray]) -> np.ndarray:
+    if mask is None:
+        return x.mean(axis=(-1, -2))
+    return np.where(mask, x, 0.0).sum(axis=(-1, -2)) / mask.sum(axis=(-1, -2))
+
+
+def abs_relative_difference(out, tgt, mask=None) -> float:
+    return float(_masked_mean(np.abs(out - tgt) / tgt, mask).mean())
+
+
+def squared_relative_difference(out, tgt, mask=None) -> float:
+    return float(_masked_mean(np.abs(out - tgt) ** 2 / tgt, mask).mean())
+
+
+def rmse_linear(out, tgt, mask=None) -> float:
+    return float(np.sqrt(_masked_mean((out - tgt) ** 2, mask)).mean())
+
+
+def rmse_log(out, tgt, mask=None) -> float:
+    return float(np.sqrt(_masked_mean((np.log(out) - np.log(tgt)) ** 2, mask)).mean())
+
+
+def log10(out, tgt, mask=None) -> float:
+    d = np.abs(np.log10(out) - np.log10(tgt))
+    return float(d[mask].mean() if mask is not None else d.mean())
+
+
+def threshold_percentage(out, tgt, thr: float, mask=None) -> float:
+    r = np.maximum(out / tgt, tgt / out)
+    return float(_masked_mean((r < thr).astype(np.float64), mask).mean())
+
+
+def delta1_acc(out, tgt, mask=None) -> float:
+    return threshold_percentage(out, tgt, 1.25, mask)
+
+
+def delta2_acc(out, tgt, mask=None) -> float:
+    return threshold_percentage(out, tgt, 1.25 ** 2, mask)
+
+
+def delta3_acc(out, tgt, mask=None) -> float:
+    return threshold_percentage(out, tgt, 1.25 ** 3, mask)
+
+
+def i_rmse(out, tgt, mask=None) -> float:
+    return float(np.sqrt(_masked_mean((1.0 / out - 1.0 / tgt) ** 2, mask)).mean())
+
+
+def silog_rmse(out, tgt, mask=None) -> float:
+    diff = np.log(out) - np.log(tgt)
+    if mask is not None:
+        diff = np.where(mask, diff, 0.0)
+        n = mask.sum(axis=(-1, -2))
+    else:
+        n = diff.shape[-1] * diff.shape[-2]
+    first = (diff ** 2).sum(axis=(-1, -2)) / n
+    second = diff.sum(axis=(-1, -2)) ** 2 / (n ** 2)
+    return float(np.sqrt(np.mean(first - second)) * 100)
+
+
+METRICS = {f.__name__: f for f in (abs_relative_difference, squared_relative_difference, rmse_linear, rmse_log, log10, delta1_acc, delta2_acc,
+                                    delta3_acc, i_rmse, silog_rmse)}
+
+
+def evaluate_depth(pred: np.ndarray, gt: np.ndarray, valid_mask: np.ndarray, min_depth: float = 1e-3, max_depth: float = 10.0) -> Dict[str, float]:
+    """eval.py:168-215 for one image: LS alignment in depth space, clip to the dataset range, ten metrics."""
+    aligned, _, _ = align_depth_least_square(gt, pred, valid_mask)
+    aligned = np.clip(aligned, min_depth, max_depth)
+    a, g, m = (np.asarray(x, dtype=np.float64)[None] for x in (aligned.squeeze(), np.asarray(gt).squeeze(), np.asarray(valid_mask).squeeze()))
+    m = m.astype(bool)
+    return {k: f(a, g, m) for k, f in METRICS.items()}

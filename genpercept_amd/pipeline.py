@@ -1,0 +1,295 @@
+"""GenPerceptPipeline: host-side mirror of the reference's `genpercept.GenPerceptPipeline`
+(/root/reference/genpercept/genpercept_pipeline.py:64-526) for the one-step `archs=genpercept` path.
+
+Same constructor keywords, same `__call__` keywords, same assertions and exceptions, same `GenPerceptOutput`
+(`pred_np`, `pred_colored`), so `run.py:420-432` / `infer.py:417-430` style drivers work unchanged.  Differences, all
+behind the same surface:
+  * `unet` / `vae` / `customized_head` may be anything exposing `state_dict()` (real diffusers modules included), a plain
+    dict of tensors in the diffusers key layout, or a directory holding a diffusers safetensors/bin checkpoint — `diffusers`
+    itself is never imported;
+  * `scheduler` is only inspected: beta_start == beta_end == 1 and v_prediction make DDIM's pred_original_sample equal
+    to -model_output at t = 1 (genpercept_pipeline.py:465; src/customized_modules/ddim.py:166-204), which the engine
+    implements directly; any other scheduler raises NotImplementedError (multi-step archs are out of this path);
+  * `text_encoder` may be a precomputed [L, D] embedding of the prompt (e.g. the v1 `empty_text_embed.npy`);
+  * all tensor math runs in libgenpercept_hip.so on one MI355X; there is no PyTorch/CPU fallback.
+New: `infer_batch` for a list of images / a [B,3,H,W] tensor (the reference is one image per call).
+"""
+from __future__ import annotations
+
+import logging
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import config as gcfg
+from .image_util import chw2hwc, colorize_depth_maps, get_resample_method, resize_max_res, resize_to
+
+
+@dataclass
+class GenPerceptOutput:
+    """genpercept_pipeline.py:50-62.  pred_np: [H,W] (1-channel modes) or [H,W,3], values in [0,1]; pred_colored: PIL image."""
+    pred_np: np.ndarray
+    pred_colored: Union[None, Image.Image]
+
+
+def _load_checkpoint_dir(path: str) -> Dict[str, torch.Tensor]:
+    """diffusers on-disk layouts consumed by run.py:296-333."""
+    cands = ["diffusion_pytorch_model.safetensors", "model.safetensors", "diffusion_pytorch_model.bin", "pytorch_model.bin"]
+    if os.path.isfile(path):
+        files = [path]
+    else:
+        files = [os.path.join(path, c) for c in cands if os.path.exists(os.path.join(path, c))]
+        if not files and os.path.isdir(os.path.join(path, "unet")):
+            return _load_checkpoint_dir(os.path.join(path, "unet"))
+    if not files:
+        raise FileNotFoundError(f"no diffusers checkpoint under {path}")
+    f = files[0]
+    if f.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(f)
+    return torch.load(f, map_location="cpu", weights_only=True)
+
+
+def _state_dict_of(obj) -> Optional[Dict[str, torch.Tensor]]:
+    if obj is None:
+        return None
+    if isinstance(obj, dict):
+        return obj
+    if isinstance(obj, (str, os.PathLike)):
+        return _load_checkpoint_dir(str(obj))
+    if hasattr(obj, "state_dict"):
+        return obj.state_dict()
+    raise TypeError(f"cannot take weights from {type(obj)}: expected state_dict(), a dict of tensors or a checkpoint directory")
+
+
+def _sched_attr(s, name, default=None):
+    if hasattr(s, name):
+        return getattr(s, name)
+    cfg = getattr(s, "config", None)
+    if cfg is not None:
+        if isinstance(cfg, dict):
+            return cfg.get(name, default)
+        return getattr(cfg, name, default)
+    if isinstance(s, dict):
+        return s.get(name, default)
+    return default
+
+
+class GenPerceptPipeline:
+    latent_scale_factor = 0.18215  # genpercept_pipeline.py:96
+
+    def __init__(self, unet, vae, scheduler=None, text_encoder=None, tokenizer=None, default_denoising_steps: Optional[int] = 10,
+                 default_processing_resolution: Optional[int] = 768, rgb_blending=False, customized_head=None, genpercept_pipeline=True,
+                 device: Union[str, int, torch.device, None] = None):
+        self.genpercept_pipeline = genpercept_pipeline
+        if not genpercept_pipeline:
+            raise NotImplementedError("only the one-step archs=genpercept path is implemented (multi-step marigold/rgb_blending are out of scope)")
+        default_denoising_steps = 1  # genpercept_pipeline.py:115-117
+        rgb_blending = True
+        self.scheduler = scheduler
+        if scheduler is not None:
+            bs, be = _sched_attr(scheduler, "beta_start"), _sched_attr(scheduler, "beta_end")
+            pt = _sched_attr(scheduler, "prediction_type", "v_prediction")
+            if bs != 1 or be != 1 or pt != "v_prediction":
+                raise NotImplementedError(f"one-step GenPercept needs the beta=1/1 v_prediction scheduler (got beta {bs}/{be}, {pt})")
+        self._unet_src, self._vae_src, self._head_src = unet, vae, customized_head
+        self.text_encoder, self.tokenizer = text_encoder, tokenizer
+        self.default_denoising_steps = default_denoising_steps
+        self.default_processing_resolution = default_processing_resolution
+        self.rgb_blending = rgb_blending
+        self.customized_head = customized_head
+        self.text_embed: Optional[torch.Tensor] = None
+        self._embed_prompt = None
+        if text_encoder is not None and not hasattr(text_encoder, "forward") and tokenizer is None:
+            self.text_embed = torch.as_tensor(np.asarray(text_encoder, dtype=np.float32) if not torch.is_tensor(text_encoder) else text_encoder).float()
+            self.text_embed = self.text_embed.reshape(1, -1, self.text_embed.shape[-1])
+            self.text_encoder = None
+        self._engine = None
+        self._timestep = None
+        self._device = torch.device("cuda", 0) if device is None else torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        self.mode = None
+
+    # ---- diffusers-like conveniences ---------------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, checkpoint: str, variant=None, torch_dtype=None, **kwargs):
+        """run.py:370-376 call shape: sub-folders unet/, vae/ (+ text_encoder/, tokenizer/) unless passed as kwargs."""
+        kw = dict(kwargs)
+        for name in ("unet", "vae"):
+            if kw.get(name) is None:
+                kw[name] = os.path.join(checkpoint, name)
+        if kw.get("text_encoder") is None and os.path.isdir(os.path.join(checkpoint, "text_encoder")):
+            from transformers import CLIPTextModel, CLIPTokenizer
+            kw["text_encoder"] = CLIPTextModel.from_pretrained(os.path.join(checkpoint, "text_encoder"))
+            kw["tokenizer"] = CLIPTokenizer.from_pretrained(os.path.join(checkpoint, "tokenizer"))
+        return cls(**kw)
+
+    def to(self, device=None, dtype=None):
+        if device is not None and not isinstance(device, torch.dtype):
+            dev = torch.device(device)
+            if dev.type != "cuda":
+                raise RuntimeError("genpercept_amd runs on MI355X GPUs only")
+            if self._engine is not None and dev != self._device:
+                raise RuntimeError("the engine is already bound to " + str(self._device))
+            self._device = dev if dev.index is not None else torch.device("cuda", 0)
+        return self
+
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return torch.bfloat16  # storage dtype of the engine; accumulation is fp32
+
+    def enable_xformers_memory_efficient_attention(self):  # run.py:382-385 — attention is always flash-style here
+        return None
+
+    def set_progress_bar_config(self, **kwargs):
+        return None
+
+    # ---- engine ------------------------------------------------------------------------------------------------------
+    def _ensure_engine(self):
+        if self._engine is not None:
+            return self._engine
+        from .engine import Engine
+        unet_sd, vae_sd, head_sd = _state_dict_of(self._unet_src), _state_dict_of(self._vae_src), _state_dict_of(self._head_src)
+        if unet_sd is None or vae_sd is None:
+            raise ValueError("unet and vae weights are required")
+        ucfg, vcfg = gcfg.infer_unet_config(unet_sd), gcfg.infer_vae_config(vae_sd)
+        dcfg = gcfg.infer_dpt_config(head_sd) if head_sd is not None else None
+        if head_sd is not None:
+            if not any(k.startswith("neck.fusion_stage") for k in head_sd):
+                raise ValueError("unsupported customized_head (genpercept_pipeline.py:483-484)")
+            ucfg = gcfg.UNetConfig(**{**ucfg.__dict__, "has_out": False})
+        eng = Engine(self._device.index or 0, ucfg, vcfg, dcfg)
+        eng.load_state_dict("vae", vae_sd)
+        eng.load_state_dict("unet", {k: v for k, v in unet_sd.items() if not (dcfg and (k.startswith("conv_out") or k.startswith("conv_norm_out")))})
+        if head_sd is not None:
+            eng.load_state_dict("dpt", head_sd)
+        eng.finalize()
+        self._engine, self.unet_config, self.vae_config, self.dpt_config = eng, ucfg, vcfg, dcfg
+        self._timestep = 1
+        self._ctx_loaded = None
+        return eng
+
+    def encode_text(self, prompt):
+        """genpercept_pipeline.py:360-372 (padding='do_not_pad' => BOS,EOS for the empty prompt)."""
+        if self.text_encoder is None or self.tokenizer is None:
+            if self.text_embed is None:
+                raise ValueError("no text_encoder/tokenizer and no precomputed text embedding were given")
+            if prompt not in ("", None):
+                logging.warning("a precomputed text embedding is in use; prompt %r is ignored", prompt)
+            return
+        ti = self.tokenizer(prompt, padding="do_not_pad", max_length=self.tokenizer.model_max_length, truncation=True, return_tensors="pt")
+        with torch.no_grad():
+            self.text_embed = self.text_encoder(ti.input_ids.to(self.text_encoder.device))[0].float().cpu()
+        self._embed_prompt = prompt
+
+    def _prepare(self, fix_timesteps, prompt):
+        eng = self._ensure_engine()
+        if self.text_embed is None:
+            self.encode_text(prompt)
+        if self._ctx_loaded is not self.text_embed:
+            eng.set_context(self.text_embed)
+            self._ctx_loaded = self.text_embed
+        t = int(fix_timesteps) if fix_timesteps else 1  # set_timesteps(1) => [1] (leading spacing, steps_offset 1)
+        if t != self._timestep:
+            eng.set_timestep(t)
+            self._timestep = t
+        return eng
+
+    # ---- reference methods -------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def single_infer(self, rgb_in: torch.Tensor, num_inference_steps: int = 1, generator=None, show_pbar: bool = False, fix_timesteps=None,
+                     prompt="") -> torch.Tensor:
+        """genpercept_pipeline.py:375-486.  rgb_in: [B,3,h,w] in [-1,1] (or uint8 0..255) -> [B,C,h',w'] in [0,1]."""
+        assert num_inference_steps == 1, "GenPercept only forward once."
+        eng = self._prepare(fix_timesteps, prompt)
+        rgb_in = rgb_in.to(self._device)
+        return eng.infer(rgb_in, self.mode or "depth")
+
+    @torch.no_grad()
+    def encode_rgb(self, rgb_in: torch.Tensor) -> torch.Tensor:
+        """genpercept_pipeline.py:488-505."""
+        return self._ensure_engine().vae_encode(rgb_in.to(self._device))
+
+    @torch.no_grad()
+    def decode_pred(self, pred_latent: torch.Tensor) -> torch.Tensor:
+        """genpercept_pipeline.py:507-526 (channel mean for depth/matting/dis/disparity)."""
+        from .engine import ONE_CHANNEL_MODES
+        return self._ensure_engine().vae_decode(pred_latent.to(self._device), (self.mode or "depth") in ONE_CHANNEL_MODES)
+
+    @torch.no_grad()
+    def __call__(self, input_image: Union[Image.Image, torch.Tensor], denoising_steps: Optional[int] = None, ensemble_size: int = 1,
+                 processing_res: Optional[int] = None, match_input_res: bool = True, resample_method: str = "bilinear", batch_size: int = 0,
+                 generator=None, color_map: str = "Spectral", show_progress_bar: bool = True, ensemble_kwargs: Dict = None, mode=None,
+                 fix_timesteps=None, prompt="") -> GenPerceptOutput:
+        assert mode is not None, "mode of GenPerceptPipeline can be chosen from ['depth', 'normal', 'seg', 'matting', 'dis']."
+        self.mode = mode
+        if denoising_steps is None:
+            denoising_steps = self.default_denoising_steps
+        if processing_res is None:
+            processing_res = self.default_processing_resolution
+        assert processing_res >= 0
+        assert ensemble_size >= 1
+        assert ensemble_size == 1  # genpercept_pipeline.py:211-213
+        assert denoising_steps == 1
+        resample = get_resample_method(resample_method)
+
+        if isinstance(input_image, Image.Image):
+            arr = np.asarray(input_image.convert("RGB"))
+            rgb = torch.from_numpy(arr.copy()).permute(2, 0, 1).unsqueeze(0)  # [1, rgb, H, W] uint8
+        elif isinstance(input_image, torch.Tensor):
+            rgb = input_image
+        else:
+            raise TypeError(f"Unknown input type: {type(input_image) = }")
+        input_size = rgb.shape
+        assert 4 == rgb.dim() and 3 == input_size[-3], f"Wrong input shape {input_size}, expected [1, rgb, H, W]"
+        outs = self._run(rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt)
+        return outs[0] if rgb.shape[0] == 1 else outs
+
+    def infer_batch(self, images: Union[Sequence[Image.Image], torch.Tensor], mode: str, processing_res: Optional[int] = None,
+                    match_input_res: bool = True, resample_method: str = "bilinear", color_map: Optional[str] = "Spectral", fix_timesteps=None,
+                    prompt="") -> List[GenPerceptOutput]:
+        """Batch entry (new): images of one common size, one engine call; results are per image (DPT min-max per image)."""
+        self.mode = mode
+        if processing_res is None:
+            processing_res = self.default_processing_resolution
+        if not torch.is_tensor(images):
+            images = torch.stack([torch.from_numpy(np.asarray(im.convert("RGB")).copy()).permute(2, 0, 1) for im in images])
+        assert images.dim() == 4 and images.shape[1] == 3
+        return self._run(images, processing_res, match_input_res, get_resample_method(resample_method), color_map, fix_timesteps, prompt)
+
+    def _run(self, rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt) -> List[GenPerceptOutput]:
+        input_size = rgb.shape
+        if processing_res > 0:
+            rgb = resize_max_res(rgb, max_edge_resolution=processing_res, resample_method=resample)
+        if rgb.dtype == torch.uint8:
+            rgb_in = rgb  # x/255*2-1 happens in the engine's prologue kernel (same fp32 formula)
+        else:
+            rgb_in = rgb.float() / 255.0 * 2.0 - 1.0
+            assert rgb_in.min() >= -1.0 and rgb_in.max() <= 1.0
+        pred = self.single_infer(rgb_in, 1, None, False, fix_timesteps, prompt)
+        if match_input_res:
+            pred = resize_to(pred, input_size[-2:], resample)
+        pred = pred.cpu().numpy().clip(0, 1)
+        outs = []
+        for i in range(pred.shape[0]):
+            p = pred[i].squeeze()
+            if color_map is not None:
+                assert self.mode in ["depth", "disparity"]
+                col = colorize_depth_maps(p, 0, 1, cmap=color_map).squeeze()
+                col_img = Image.fromarray(chw2hwc((col * 255).astype(np.uint8)))
+            else:
+                c8 = (p * 255.0).astype(np.uint8)
+                if c8.ndim == 3 and c8.shape[0] == 3:
+                    c8 = np.transpose(c8, (1, 2, 0))
+                col_img = Image.fromarray(c8)
+            if p.ndim == 3 and p.shape[0] == 3:
+                p = np.transpose(p, (1, 2, 0))
+            outs.append(GenPerceptOutput(pred_np=p, pred_colored=col_img))
+        return outs

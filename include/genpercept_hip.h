@@ -1,0 +1,128 @@
+/* genpercept_hip.h — C-ABI of libgenpercept_hip.so: the MI355X (gfx950) engine behind GenPercept's one-step
+ * inference path.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * What each entry point replaces in the reference (/root/reference, aim-uofa/GenPercept):
+ *   gp_infer          GenPerceptPipeline.single_infer               genpercept/genpercept_pipeline.py:375-486
+ *   gp_vae_encode     GenPerceptPipeline.encode_rgb                 genpercept/genpercept_pipeline.py:488-505
+ *                       (diffusers AutoencoderKL.encoder + quant_conv, call site :500-501)
+ *   gp_unet           self.unet(...) / CustomUNet2DConditionModel.forward
+ *                                                                   genpercept_pipeline.py:455-457,476-479; models/custom_unet.py:34-427
+ *                       (+ scheduler.step == "-model_output", genpercept_pipeline.py:460-465, ddim.py:166-204)
+ *   gp_vae_decode     GenPerceptPipeline.decode_pred                genpercept/genpercept_pipeline.py:507-526
+ *   gp_dpt_head       DPTNeckHeadForUnetAfterUpsampleIdentity.forward  genpercept/models/dpt_head.py:443-560,585-593
+ *   gp_load_tensor    from_pretrained / load_state_dict of the diffusers-layout checkpoints   run.py:296-357
+ *   gp_set_context    encode_text + text_embed cache                genpercept_pipeline.py:360-372,425-429
+ *   gp_set_timestep   scheduler.set_timesteps / fix_timesteps       genpercept_pipeline.py:403-408
+ * The per-kernel entry points (gp_conv2d ... gp_bilinear) exist for the parity tests; they are the same launchers the
+ * engine uses.
+ *
+ * Ownership: the engine owns weights, folded constants and its activation pool.  The caller owns every in/out DEVICE
+ * buffer (e.g. PyTorch-ROCm tensors passed by data_ptr()) and keeps them alive until the stream has been synchronised.
+ * Errors: every call returns gp_status; gp_last_error() gives the message.  Nothing throws across the ABI.
+ * Threading: one engine per GPU; an engine is not re-entrant; different engines may run on different host threads.
+ */
+#ifndef GENPERCEPT_HIP_H
+#define GENPERCEPT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gp_engine gp_engine;
+
+typedef enum { GP_OK = 0, GP_ERR_INVALID = 1, GP_ERR_HIP = 2, GP_ERR_MISSING_WEIGHT = 3, GP_ERR_STATE = 4 } gp_status;
+typedef enum { GP_DT_F32 = 0, GP_DT_F16 = 1, GP_DT_BF16 = 2 } gp_dtype;
+/* depth / matting / dis / disparity average the 3 decoder channels (genpercept_pipeline.py:523-525); normal / seg keep 3 */
+typedef enum { GP_MODE_DEPTH = 0, GP_MODE_NORMAL = 1, GP_MODE_SEG = 2, GP_MODE_MATTING = 3, GP_MODE_DIS = 4, GP_MODE_DISPARITY = 5 } gp_mode;
+
+typedef struct gp_config {
+    int device;                 /* HIP device ordinal */
+    /* UNet2DConditionModel (SD2.1 unet/config.json) */
+    int unet_in_channels, unet_out_channels;
+    int unet_block_out[4];
+    int unet_num_heads[4];      /* `attention_head_dim` of the config = number of heads; head_dim must be 64 */
+    int unet_down_attn[4];      /* 1 = CrossAttnDownBlock2D, 0 = DownBlock2D */
+    int unet_layers_per_block;
+    int unet_cross_dim;
+    int unet_has_out;           /* 0 for DPT-head UNets (conv_norm_out / conv_out deleted, run.py:316-318) */
+    float unet_norm_eps;
+    /* AutoencoderKL (SD2.1 vae/config.json) */
+    int vae_block_out[4];
+    int vae_layers_per_block;
+    int vae_latent_channels;
+    float vae_norm_eps;
+    float vae_scaling_factor;   /* GenPerceptPipeline.latent_scale_factor = 0.18215 */
+    /* DPT neck+head (hf_configs/dpt-sd2.1-unet-after-upsample-general/config.json); dpt_enabled = 0 -> VAE-decoder head */
+    int dpt_enabled;
+    int dpt_neck[4];
+    int dpt_fusion;
+    int norm_groups;            /* 32 */
+} gp_config;
+
+typedef struct gp_timings {
+    float ms_encode, ms_unet, ms_head, ms_total;   /* last gp_infer, valid when profiling level >= 1 */
+    double flops_igemm, flops_attn;                /* algorithmic flops issued since gp_reset_timings */
+    float ms_igemm, ms_attn;                       /* summed kernel time of those launches (profiling level 2) */
+    int n_igemm, n_attn, n_launches;
+} gp_timings;
+
+void gp_default_config(gp_config* cfg);                                  /* SD2.1 values */
+gp_status gp_create(const gp_config* cfg, gp_engine** out);
+void gp_destroy(gp_engine* e);
+const char* gp_last_error(const gp_engine* e);
+const char* gp_version(void);
+
+/* One call per state-dict entry.  `name` = "<module>.<diffusers key>" with module in {vae, unet, dpt}.  The engine copies
+ * (and converts to fp32); the caller keeps ownership of host_ptr. */
+gp_status gp_load_tensor(gp_engine* e, const char* name, const void* host_ptr, const int64_t* shape, int ndim, gp_dtype dtype);
+/* Text-encoder output for the prompt: embed is HOST fp32 [L][D] (L = 2 for the empty prompt). */
+gp_status gp_set_context(gp_engine* e, const float* embed, int L, int D);
+gp_status gp_set_timestep(gp_engine* e, float t);                        /* default 1 */
+/* Fold constants (time embedding, cross-attention K/V, quant_conv), pack weights to bf16 device layouts, free host copies. */
+gp_status gp_finalize(gp_engine* e);
+
+/* rgb_dev: DEVICE [B][3][H][W], uint8 0..255 (is_u8 = 1) or fp32 already in [-1,1] (is_u8 = 0).
+ * out_dev: DEVICE fp32 [B][C][8h][8w], C = 1 or 3 by mode, values in [0,1]; (h, w) = gp_latent_size(H), gp_latent_size(W)
+ * (== H/8, W/8 when H, W are multiples of 8).  With the DPT head: [B][1][gp_dpt_out_size(h)][gp_dpt_out_size(w)].  stream: hipStream_t (NULL = default). */
+int gp_latent_size(int pixels);   /* three VAE downsamples: x -> (x - 2) / 2 + 1 */
+int gp_dpt_out_size(int latent);  /* DPT head output edge: 32 * (two UNet downsamples of the latent edge) == 8 * latent when latent % 4 == 0 */
+gp_status gp_infer(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, int W, gp_mode mode, float* out_dev, void* stream);
+
+/* Stage-level entry points (DEVICE fp32 NCHW in/out). */
+gp_status gp_vae_encode(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, int W, float* latent_out, void* stream);
+gp_status gp_unet(gp_engine* e, const float* latent_in, int B, int h, int w, float* sample_out /* may be NULL */,
+                  float* const* feats_out /* 4 pointers or NULL; multi_level_feats order */, void* stream);
+gp_status gp_vae_decode(gp_engine* e, const float* pred_latent, int B, int h, int w, int mean3, float* out, void* stream);
+gp_status gp_dpt_head(gp_engine* e, const float* const* feats /* reversed multi_level_feats: [c0@h, c1@h, c2@h/2, c3@h/4] */,
+                      int B, int h, int w, float* out /* [B][gp_dpt_out_size(h)][gp_dpt_out_size(w)], not normalised */, void* stream);
+
+/* Profiling: level 0 off, 1 per-stage hipEvents, 2 additionally per-launch events on the MFMA kernels. */
+gp_status gp_set_profile(gp_engine* e, int level);
+gp_status gp_get_timings(gp_engine* e, gp_timings* out);
+gp_status gp_reset_timings(gp_engine* e);
+
+/* ---- per-kernel entry points (DEVICE pointers, bf16 NHWC activations) -------------------------------------------- */
+/* Pack an OIHW fp32 HOST weight into the device layout [n_rows][taps][cin_pad] bf16 (n_rows = gp_packed_rows(cout)). */
+int gp_packed_rows(int cout);
+gp_status gp_pack_weight(const float* w_oihw_host, int cout, int cin, int ks, int cin_pad, int geglu, void* dev_out);
+gp_status gp_conv2d(const void* in, const void* w_packed, const float* bias, const void* residual, void* out, int B, int Hi, int Wi, int Cin,
+                    int Cout, int ks, int stride, int pad_t, int pad_l, int Ho, int Wo, int ups_h, int ups_w, int act, int n_store,
+                    int out_fp32, int tile_hint, void* stream);
+/* out[M][N] = A[M][K] * Bt[N][K]^T (+bias per column / per row), batched over `batch` with element strides. */
+gp_status gp_gemm(const void* a, int lda, const void* bt, int ldb, const float* bias, int bias_mode, const void* residual, int ldres, void* out,
+                  int ldo, int M, int N, int K, int n_rows_bt, int n_store, int act, int out_fp32, int batch, long long a_bs, long long bt_bs,
+                  long long out_bs, int tile_hint, void* stream);
+gp_status gp_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int silu, void* stream);
+gp_status gp_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C, float eps, void* stream);
+gp_status gp_flash_attention(const void* q, const void* k, const void* vt, void* out, int B, int T, int heads, int ldq, int ldk, int Tpad, int ldo,
+                             void* stream);
+gp_status gp_cross_attention(const void* q, const float* kc, const float* vc, void* out, int rows, int C, int L, void* stream);
+gp_status gp_softmax_rows(const float* in, void* out, int rows, int T, int ld, float scale, void* stream);
+gp_status gp_bilinear(const void* in, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENPERCEPT_HIP_H */

@@ -31,7 +31,7 @@ class DPTCfg:
 
     @staticmethod
     def tiny() -> "DPTCfg":
-        return DPTCfg(neck_hidden_sizes=(64, 128, 256, 256), fusion_hidden_size=64)
+        return DPTCfg(neck_hidden_sizes=(64, 128, 256, 256), fusion_hidden_size=128)
 
 
 def dpt_manifest(cfg: DPTCfg = DPTCfg()) -> "OrderedDict[str, Tuple[int, ...]]":

@@ -1,0 +1,255 @@
+"""Stage-level and end-to-end parity (GPU) of the HIP engine, through the C-ABI, against
+  (1) the committed golden vectors of the fp32 oracle (tests/golden/e2e_tiny.npz; tiny widths, two image shapes),
+  (2) the REFERENCE's own DPT head outputs (tests/golden/dpt_head_ref.npz, full-size head),
+  (3) the fp32 oracle run live on the host CPU at the full SD2.1 architecture (small image).
+
+Tolerances.  The engine stores activations in bf16 (8 mantissa bits, one rounding per layer output; accumulation and
+statistics in fp32), the oracle is fp32 end to end.  Through ~60 (VAE) / ~250 (UNet) rounded layers the observed
+deviation is ~1e-2 of the tensor's RMS; we therefore gate every stage on
+      rel_rms = rms(out - ref) / rms(ref)  <= TOL_STAGE (3e-2)         and on the final [0,1] maps additionally
+      mean |out - ref| <= TOL_MAP_MEAN (1e-2),  and for depth the reference's own protocol metric (eval.py:168-215):
+      AbsRel(out, ref) after least-squares alignment <= TOL_ABSREL (1e-2).
+north_star's "1e-3 rel" is met at the metric level only with fp32 storage; the measured numbers are logged to
+gpurun_out/parity_log.jsonl and reported in DESIGN.md.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL_STAGE = 3e-2
+TOL_MAP_MEAN = 1e-2
+TOL_ABSREL = 1e-2
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel_rms(out, ref):
+    out, ref = out.float().cpu(), torch.as_tensor(ref).float().cpu()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    assert torch.isfinite(out).all()
+    return ((out - ref).pow(2).mean().sqrt() / (ref.pow(2).mean().sqrt() + 1e-12)).item()
+
+
+def stage_check(name, out, ref, log, tol=TOL_STAGE):
+    r = rel_rms(out, ref)
+    ref_t = torch.as_tensor(ref).float()
+    log(name, rel_rms=r, max_abs=(out.float().cpu() - ref_t).abs().max().item(), ref_rms=ref_t.pow(2).mean().sqrt().item())
+    assert r <= tol, f"{name}: rel rms {r:.3e} > {tol}"
+
+
+def absrel_after_ls(pred, gt):
+    """eval.py protocol on a pair of maps: least-squares scale/shift then mean |a-b|/b (src/util/alignment.py:29-76, metric.py:34-44)."""
+    p, g = pred.reshape(-1, 1).astype(np.float64), gt.reshape(-1).astype(np.float64)
+    a = np.concatenate([p, np.ones_like(p)], axis=1)
+    x = np.linalg.lstsq(a, g, rcond=None)[0]
+    al = (a @ x).clip(1e-3, None)
+    gg = g.clip(1e-3, None)
+    return float(np.mean(np.abs(al - gg) / gg))
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(GOLD, "e2e_tiny.npz"))
+
+
+@pytest.fixture(scope="module")
+def tiny_weights():
+    from oracle import dpt as odpt
+    from oracle import sd21 as osd
+    uc, vc, dc = osd.UNetCfg.tiny(), osd.VAECfg.tiny(), odpt.DPTCfg.tiny()
+    return dict(uc=uc, vc=vc, dc=dc, usd=osd.synth_state_dict(osd.unet_manifest(uc), 1), vsd=osd.synth_state_dict(osd.vae_manifest(vc), 2),
+                dsd=osd.synth_state_dict(odpt.dpt_manifest(dc), 3))
+
+
+def _engine(tw, dpt, ctx):
+    from genpercept_amd.engine import Engine
+    import dataclasses
+    uc = tw["uc"] if not dpt else dataclasses.replace(tw["uc"], has_out=False)
+    eng = Engine(0, uc, tw["vc"], tw["dc"] if dpt else None)
+    eng.load_state_dict("vae", tw["vsd"])
+    eng.load_state_dict("unet", {k: v for k, v in tw["usd"].items() if not (dpt and k.startswith(("conv_out", "conv_norm_out")))})
+    if dpt:
+        eng.load_state_dict("dpt", tw["dsd"])
+    eng.set_context(torch.as_tensor(ctx))
+    eng.finalize()
+    return eng
+
+
+@pytest.fixture(scope="module")
+def eng_vae(tiny_weights, golden):
+    e = _engine(tiny_weights, False, golden["sq_ctx"])
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng_dpt(tiny_weights, golden):
+    e = _engine(tiny_weights, True, golden["sq_ctx"])
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("tag", ["sq", "odd"])
+def test_stages_vs_golden(tag, eng_vae, golden, metric_log):
+    d = torch.device("cuda", 0)
+    eng_vae.set_context(torch.as_tensor(golden[f"{tag}_ctx"]))
+    rgb = torch.as_tensor(golden[f"{tag}_rgb_u8"]).to(d)
+    lat = eng_vae.vae_encode(rgb)
+    stage_check(f"vae_encode[{tag}]", lat, golden[f"{tag}_latent"], metric_log)
+    # feed the GOLDEN latent so each stage is judged on its own
+    gl = torch.as_tensor(golden[f"{tag}_latent"]).to(d)
+    v, feats = eng_vae.unet(gl, want_sample=True, want_feats=True)
+    stage_check(f"unet[{tag}]", v, golden[f"{tag}_unet"], metric_log)
+    for i, f in enumerate(feats):
+        stage_check(f"unet_feat{i}[{tag}]", f, golden[f"{tag}_feat{i}"].astype(np.float32), metric_log)
+    gv = torch.as_tensor(golden[f"{tag}_unet"]).to(d)
+    dec = eng_vae.vae_decode(-gv, mean3=False)
+    stage_check(f"vae_decode3[{tag}]", dec, golden[f"{tag}_dec3"], metric_log)
+    dec1 = eng_vae.vae_decode(-gv, mean3=True)
+    stage_check(f"vae_decode1[{tag}]", dec1, golden[f"{tag}_dec3"].mean(axis=1, keepdims=True), metric_log)
+
+
+@pytest.mark.parametrize("tag", ["sq", "odd"])
+@pytest.mark.parametrize("mode", ["depth", "normal"])
+def test_infer_vs_golden(tag, mode, eng_vae, golden, metric_log):
+    d = torch.device("cuda", 0)
+    eng_vae.set_context(torch.as_tensor(golden[f"{tag}_ctx"]))
+    out = eng_vae.infer(torch.as_tensor(golden[f"{tag}_rgb_u8"]).to(d), mode)
+    ref = golden[f"{tag}_{mode}"]
+    assert tuple(out.shape) == ref.shape
+    o = out.cpu().numpy()
+    assert o.min() >= 0.0 and o.max() <= 1.0
+    mean_abs = float(np.abs(o - ref).mean())
+    rec = dict(mean_abs=mean_abs, max_abs=float(np.abs(o - ref).max()), rel_rms=rel_rms(out, ref))
+    if mode == "depth":
+        rec["absrel_ls"] = absrel_after_ls(o, ref)
+    metric_log(f"infer_{mode}[{tag}]", **rec)
+    assert mean_abs <= TOL_MAP_MEAN, rec
+    if mode == "depth":
+        assert rec["absrel_ls"] <= TOL_ABSREL, rec
+
+
+@pytest.mark.parametrize("tag", ["sq", "odd"])
+def test_infer_dpt_vs_golden(tag, eng_dpt, golden, metric_log):
+    d = torch.device("cuda", 0)
+    eng_dpt.set_context(torch.as_tensor(golden[f"{tag}_ctx"]))
+    out = eng_dpt.infer(torch.as_tensor(golden[f"{tag}_rgb_u8"]).to(d), "disparity")
+    ref = golden[f"{tag}_disp"]
+    assert tuple(out.shape) == ref.shape
+    o = out.cpu().numpy()
+    mean_abs = float(np.abs(o - ref).mean())
+    metric_log(f"infer_disp_dpt[{tag}]", mean_abs=mean_abs, max_abs=float(np.abs(o - ref).max()), rel_rms=rel_rms(out, ref), mn=float(o.min()), mx=float(o.max()))
+    assert abs(o.min()) < 1e-6 and abs(o.max() - 1.0) < 1e-6  # per-image min-max (genpercept_pipeline.py:482)
+    assert mean_abs <= TOL_MAP_MEAN
+
+
+def test_dpt_head_vs_reference_outputs(metric_log):
+    """Full-size DPT head against outputs of the reference's own dpt_head.py (generated in the build container)."""
+    from genpercept_amd.engine import Engine
+    from oracle import dpt as odpt
+    from oracle import sd21 as osd
+    g = np.load(os.path.join(GOLD, "dpt_head_ref.npz"))
+    sd = osd.synth_state_dict(odpt.dpt_manifest(), int(g["seed"]))
+    uc, vc = osd.UNetCfg.tiny(), osd.VAECfg.tiny()
+    eng = Engine(0, uc, vc, odpt.DPTCfg())
+    eng.load_state_dict("dpt", sd)
+    eng.finalize()
+    d = torch.device("cuda", 0)
+    try:
+        for tag in "ab":
+            h, w = (int(x) for x in g[f"{tag}_hw"])
+            gen = torch.Generator().manual_seed(100 + h * w)
+            feats = [torch.randn(1, 320, h, w, generator=gen), torch.randn(1, 640, h, w, generator=gen),
+                     torch.randn(1, 1280, h // 2, w // 2, generator=gen), torch.randn(1, 1280, h // 4, w // 4, generator=gen)]
+            out = eng.dpt_head([f.to(d) for f in feats])
+            stage_check(f"dpt_head_ref[{tag}]", out, g[f"{tag}_out"], metric_log)
+    finally:
+        eng.close()
+
+
+def test_batch_equals_single(eng_vae, golden, metric_log):
+    """Sharding correctness: an image's result does not depend on what else is in the batch."""
+    d = torch.device("cuda", 0)
+    eng_vae.set_context(torch.as_tensor(golden["sq_ctx"]))
+    rgb = torch.as_tensor(golden["sq_rgb_u8"]).to(d)
+    both = eng_vae.infer(rgb, "depth")
+    one0 = eng_vae.infer(rgb[:1], "depth")
+    one1 = eng_vae.infer(rgb[1:], "depth")
+    diff = max((both[:1] - one0).abs().max().item(), (both[1:] - one1).abs().max().item())
+    metric_log("batch_vs_single", max_abs=diff, bitwise=float(diff == 0.0))
+    assert diff <= 1e-6
+
+
+def test_full_sd21_architecture_small_image(metric_log):
+    """Full-width SD2.1 UNet (865.9 M params) + VAE at 64x64 px against the fp32 oracle run on the host CPU."""
+    from genpercept_amd.engine import Engine
+    from oracle import pipeline as opipe
+    from oracle import sd21 as osd
+    uc, vc = osd.UNetCfg(), osd.VAECfg()
+    usd = osd.synth_state_dict(osd.unet_manifest(uc), 11)
+    vsd = osd.synth_state_dict(osd.vae_manifest(vc), 12)
+    g = torch.Generator().manual_seed(77)
+    rgb_u8 = torch.randint(0, 256, (1, 3, 64, 64), generator=g, dtype=torch.uint8)
+    rgb_u8[:, :, :32] //= 2
+    ctx = torch.randn(2, 1024, generator=g)
+    with torch.no_grad():
+        rgb = opipe.normalize_rgb(rgb_u8)
+        lat = osd.encode_rgb(vsd, vc, rgb)
+        v, _ = osd.unet_forward(usd, uc, lat, 1, ctx[None])
+        ref = opipe.single_infer(vsd, vc, usd, uc, rgb, ctx, "depth")
+    eng = Engine(0, uc, vc, None)
+    eng.load_state_dict("vae", vsd)
+    eng.load_state_dict("unet", usd)
+    eng.set_context(ctx)
+    eng.finalize()
+    d = torch.device("cuda", 0)
+    try:
+        stage_check("full_vae_encode", eng.vae_encode(rgb_u8.to(d)), lat, metric_log)
+        stage_check("full_unet", eng.unet(lat.to(d))[0], v, metric_log)
+        out = eng.infer(rgb_u8.to(d), "depth").cpu().numpy()
+        mean_abs = float(np.abs(out - ref.numpy()).mean())
+        metric_log("full_infer_depth", mean_abs=mean_abs, max_abs=float(np.abs(out - ref.numpy()).max()), absrel_ls=absrel_after_ls(out, ref.numpy()))
+        assert mean_abs <= TOL_MAP_MEAN
+    finally:
+        eng.close()
+
+
+def test_pipeline_surface(tiny_weights, golden, metric_log):
+    """The GenPerceptPipeline mirror: same kwargs / asserts / outputs as genpercept_pipeline.py:146-337."""
+    from PIL import Image
+    from genpercept_amd import GenPerceptOutput, GenPerceptPipeline
+
+    class Sched:  # what run.py:371 loads from hf_configs/scheduler_beta_1.0_1.0
+        beta_start, beta_end, prediction_type = 1.0, 1.0, "v_prediction"
+
+    pipe = GenPerceptPipeline(unet=tiny_weights["usd"], vae=tiny_weights["vsd"], scheduler=Sched(), text_encoder=golden["sq_ctx"], tokenizer=None)
+    pipe.to("cuda")
+    assert pipe.default_denoising_steps == 1 and pipe.rgb_blending
+    img = Image.fromarray(np.transpose(golden["sq_rgb_u8"][0], (1, 2, 0)))
+    out = pipe(img, denoising_steps=1, ensemble_size=1, processing_res=0, match_input_res=True, batch_size=0, color_map="Spectral",
+               show_progress_bar=False, resample_method="bilinear", mode="depth")
+    assert isinstance(out, GenPerceptOutput) and out.pred_np.shape == (64, 64) and out.pred_np.dtype == np.float32
+    assert out.pred_colored.size == (64, 64)
+    mean_abs = float(np.abs(out.pred_np - golden["sq_depth"][0, 0]).mean())
+    metric_log("pipeline_call_depth", mean_abs=mean_abs)
+    assert mean_abs <= TOL_MAP_MEAN
+    outn = pipe(img, processing_res=0, color_map=None, mode="normal")
+    assert outn.pred_np.shape == (64, 64, 3)
+    # processing_res resizes to max edge then back to the input size
+    out2 = pipe(img.resize((80, 60)), processing_res=64, mode="depth")
+    assert out2.pred_np.shape == (60, 80)
+    with pytest.raises(AssertionError):
+        pipe(img)  # mode is required (:199)
+    with pytest.raises(AssertionError):
+        pipe(img, mode="depth", ensemble_size=2)
+    with pytest.raises(AssertionError):
+        pipe(img, mode="normal", color_map="Spectral")  # color_map only for depth/disparity (:318)
+    with pytest.raises(ValueError):
+        pipe(img, mode="depth", resample_method="lanczos")
+    with pytest.raises(TypeError):
+        pipe(np.zeros((8, 8, 3)), mode="depth")
+    outs = pipe.infer_batch(torch.as_tensor(golden["sq_rgb_u8"]), mode="depth", processing_res=0)
+    assert len(outs) == 2 and np.abs(outs[0].pred_np - out.pred_np).max() <= 1e-6

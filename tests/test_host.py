@@ -1,0 +1,183 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, config inference, pre/post
+processing, pipeline argument validation, sharding, and the world-size-2 gather over gloo."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from genpercept_amd import engine
+    lib = engine.load_library()
+    hdr = open(os.path.join(ROOT, "include", "genpercept_hip.h")).read()
+    declared = set(re.findall(r"\b(gp_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    assert declared == set(engine.SYMBOLS), declared ^ set(engine.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.gp_version().startswith(b"genpercept_hip")
+    assert lib.gp_packed_rows(320) == 512 and lib.gp_latent_size(768) == 96 and lib.gp_latent_size(511) == 63
+    assert lib.gp_dpt_out_size(96) == 768 and lib.gp_dpt_out_size(9) == 96
+
+
+def test_library_contains_gfx950_code_objects():
+    from genpercept_amd import engine
+    blob = open(engine.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"igemm_kernel" in blob and b"flash_attn64_kernel" in blob
+
+
+def test_default_config_is_sd21():
+    import ctypes as C
+    from genpercept_amd import engine
+    lib = engine.load_library()
+    cfg = engine.GpConfig()
+    lib.gp_default_config(C.byref(cfg))
+    assert list(cfg.unet_block_out) == [320, 640, 1280, 1280] and list(cfg.unet_num_heads) == [5, 10, 20, 20]
+    assert list(cfg.vae_block_out) == [128, 256, 512, 512] and abs(cfg.vae_scaling_factor - 0.18215) < 1e-7
+    assert abs(cfg.unet_norm_eps - 1e-5) < 1e-12 and abs(cfg.vae_norm_eps - 1e-6) < 1e-12
+
+
+def test_engine_requires_gpu_no_fallback():
+    from genpercept_amd.engine import Engine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        Engine(0)
+
+
+def test_config_inference_from_state_dict_shapes():
+    from genpercept_amd import config as gc
+    from oracle import dpt as odpt
+    from oracle import sd21 as osd
+    meta = lambda m: {k: torch.empty(s, device="meta") for k, s in m.items()}  # noqa: E731
+    u = gc.infer_unet_config(meta(osd.unet_manifest()))
+    assert u.block_out_channels == (320, 640, 1280, 1280) and u.num_heads == (5, 10, 20, 20) and u.cross_attention_dim == 1024
+    assert u.down_has_attn == (True, True, True, False) and u.layers_per_block == 2 and u.has_out
+    ut = gc.infer_unet_config(meta(osd.unet_manifest(osd.UNetCfg.tiny())))
+    assert ut.block_out_channels == (64, 128, 256, 256) and ut.cross_attention_dim == 64
+    v = gc.infer_vae_config(meta(osd.vae_manifest()))
+    assert v.block_out_channels == (128, 256, 512, 512) and v.layers_per_block == 2 and v.latent_channels == 4
+    dec_only = {k: t for k, t in meta(osd.vae_manifest()).items() if not k.startswith("encoder")}
+    assert gc.infer_vae_config(dec_only).block_out_channels == (128, 256, 512, 512)
+    d = gc.infer_dpt_config(meta(odpt.dpt_manifest()))
+    assert d.neck_hidden_sizes == (320, 640, 1280, 1280) and d.fusion_hidden_size == 256
+    with pytest.raises(KeyError):
+        gc.infer_unet_config({})
+
+
+def test_resize_semantics():
+    from genpercept_amd import image_util as iu
+    img = torch.randint(0, 256, (1, 3, 480, 640), dtype=torch.uint8)
+    out = iu.resize_max_res(img, 768, "bilinear")
+    assert out.shape == (1, 3, 576, 768) and out.dtype == torch.uint8  # int() truncation of 480 * 1.2
+    assert iu.resize_max_res(torch.zeros(1, 3, 333, 500, dtype=torch.uint8), 768).shape == (1, 3, int(333 * 768 / 500), 768)
+    same = iu.resize_to(img, (480, 640), "bilinear")
+    assert same is img
+    with pytest.raises(ValueError):
+        iu.get_resample_method("lanczos")
+    assert iu.get_resample_method("nearest") == "nearest-exact"
+    col = iu.colorize_depth_maps(np.linspace(0, 1, 12, dtype=np.float32).reshape(3, 4), 0, 1)
+    assert col.shape == (1, 3, 3, 4) and col.min() >= 0 and col.max() <= 1
+
+
+def test_pipeline_validation_without_gpu():
+    from genpercept_amd import GenPerceptPipeline
+
+    class BadSched:
+        beta_start, beta_end, prediction_type = 0.00085, 0.012, "v_prediction"
+
+    with pytest.raises(NotImplementedError):
+        GenPerceptPipeline(unet={}, vae={}, scheduler=BadSched())
+    with pytest.raises(NotImplementedError):
+        GenPerceptPipeline(unet={}, vae={}, genpercept_pipeline=False)
+    pipe = GenPerceptPipeline(unet={}, vae={}, scheduler={"beta_start": 1.0, "beta_end": 1.0, "prediction_type": "v_prediction"},
+                              text_encoder=np.zeros((2, 1024), np.float32), default_denoising_steps=10)
+    assert pipe.default_denoising_steps == 1 and pipe.rgb_blending and pipe.latent_scale_factor == 0.18215
+    assert pipe.text_embed.shape == (1, 2, 1024) and pipe.dtype == torch.bfloat16
+    with pytest.raises(AssertionError):
+        pipe(torch.zeros(1, 3, 8, 8))  # mode missing
+    with pytest.raises(AssertionError):
+        pipe(torch.zeros(3, 8, 8), mode="depth")  # wrong rank
+    with pytest.raises(RuntimeError):
+        pipe.to("cpu")
+
+
+def test_v1_empty_text_embed_fixture_shape():
+    """The only fixture-like artefact of the reference (GenPercept_v1/empty_text_embed.npy) is [77,1024] fp16; rows [0:2]
+    are what the v2 pipeline's do_not_pad tokenisation yields.  Only checked where the reference tree is mounted."""
+    p = "/root/reference/GenPercept_v1/empty_text_embed.npy"
+    if not os.path.exists(p):
+        pytest.skip("reference tree not mounted")
+    e = np.load(p)
+    assert e.shape == (77, 1024) and e.dtype == np.float16
+
+
+def test_shard_range_partitions_the_batch():
+    from genpercept_amd.distributed import shard_range
+    for n, w in [(64, 8), (10, 4), (3, 8), (7, 2), (1, 1)]:
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert shard_range(64, 3, 8) == (24, 32)
+
+
+_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, {root!r})
+from genpercept_amd import distributed as gd
+rank, local, world = gd.init_process_group("gloo")
+n_total = 5
+lo, hi = gd.shard_range(n_total, rank, world)
+local_out = torch.stack([torch.full((1, 4, 6), float(i)) for i in range(lo, hi)]) if hi > lo else torch.zeros((0, 1, 4, 6))
+gd.barrier()
+full = gd.gather_results(local_out, n_total, dst=0)
+allf = gd.gather_results(local_out, n_total, dst=None)
+ok = allf.shape == (n_total, 1, 4, 6) and all(float(allf[i].mean()) == i for i in range(n_total))
+if rank == 0:
+    ok = ok and full.shape == (n_total, 1, 4, 6) and all(float(full[i].mean()) == i for i in range(n_total))
+else:
+    ok = ok and full is None
+mx = gd.max_over_ranks(float(rank + 1), torch.device("cpu"))
+ok = ok and mx == float(world)
+print("RANK", rank, "OK" if ok else "FAIL", flush=True)
+sys.exit(0 if ok else 1)
+"""
+
+
+def test_gather_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("OK") == 2, r.stdout + r.stderr
+
+
+def test_product_manifests_equal_oracle_manifests_and_public_counts():
+    from genpercept_amd import config as gc
+    from genpercept_amd import weights as gw
+    from oracle import dpt as odpt
+    from oracle import sd21 as osd
+    assert list(gw.unet_manifest().items()) == list(osd.unet_manifest().items())
+    assert list(gw.vae_manifest().items()) == list(osd.vae_manifest().items())
+    assert list(gw.dpt_manifest().items()) == list(odpt.dpt_manifest().items())
+    assert gw.count_params(gw.unet_manifest()) == 865_910_724 and gw.count_params(gw.vae_manifest()) == 83_653_863
+    assert gw.count_params(gw.dpt_manifest()) == 18_474_753
+    tu = gc.UNetConfig(block_out_channels=(64, 128, 256, 256), num_heads=(1, 2, 4, 4), cross_attention_dim=64)
+    assert list(gw.unet_manifest(tu).items()) == list(osd.unet_manifest(osd.UNetCfg.tiny()).items())
+    nohead = gc.UNetConfig(has_out=False)
+    assert "conv_out.weight" not in gw.unet_manifest(nohead) and len(gw.unet_manifest(nohead)) == 682
+    a, b = gw.synth_state_dict(gw.unet_manifest(tu), 1), osd.synth_state_dict(osd.unet_manifest(osd.UNetCfg.tiny()), 1)
+    assert all(torch.equal(a[k], b[k]) for k in a)

@@ -1,0 +1,307 @@
+"""Per-kernel parity tests (GPU): every HIP kernel, called through the C-ABI, against a plain PyTorch fp32 reference of
+the same op evaluated on the same bf16-rounded operands.
+
+Tolerances (written here, used below):
+  * bf16 output of an fp32-accumulated kernel: one rounding to bf16 => relative error <= 2^-8 per element; we require
+    max|err| <= 1.2e-2 * max|ref| and mean|err| <= 2e-3 * mean|ref|   (TOL_BF16)
+  * fp32 output: accumulation-order differences only => max|err| <= 2e-4 * max|ref|                      (TOL_F32)
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL_BF16 = (1.2e-2, 2e-3)
+TOL_F32 = 2e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda", 0)
+
+
+def _eng():
+    from genpercept_amd import engine
+    return engine
+
+
+def rbf(x):  # round to bf16 and back: the kernels see exactly these values
+    return x.to(torch.bfloat16).float()
+
+
+def check(name, out, ref, log, fp32=False):
+    out = out.float().cpu()
+    ref = ref.float().cpu()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    assert torch.isfinite(out).all(), f"{name}: non-finite output"
+    err = (out - ref).abs()
+    mx, mean = err.max().item(), err.mean().item()
+    rmx, rmean = ref.abs().max().item() + 1e-12, ref.abs().mean().item() + 1e-12
+    log(name, max_err=mx, mean_err=mean, ref_max=rmx, ref_mean=rmean, rel_max=mx / rmx, rel_mean=mean / rmean)
+    if fp32:
+        assert mx <= TOL_F32 * rmx, f"{name}: max err {mx:.3e} vs ref max {rmx:.3e}"
+    else:
+        assert mx <= TOL_BF16[0] * rmx, f"{name}: max err {mx:.3e} vs ref max {rmx:.3e}"
+        assert mean <= TOL_BF16[1] * rmean + 1e-6, f"{name}: mean err {mean:.3e} vs ref mean {rmean:.3e}"
+
+
+def nhwc_to_nchw(y, c=None):
+    y = y.float().permute(0, 3, 1, 2)
+    return y if c is None else y[:, :c]
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, tile
+    (2, 16, 16, 64, 64, 1), (2, 16, 16, 64, 64, 2), (2, 16, 16, 64, 64, 3),
+    (1, 24, 20, 128, 320, 0), (1, 13, 15, 192, 100, 1), (3, 9, 7, 64, 3, 0), (1, 12, 12, 1280, 1280, 0), (1, 40, 36, 256, 128, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3_s1(case, metric_log):
+    e = _eng()
+    b, h, w, cin, cout, tile = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = rbf(torch.randn(b, cin, h, w, generator=g))
+    wt = rbf(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
+    bias = torch.randn(cout, generator=g)
+    res = rbf(torch.randn(b, cout, h, w, generator=g))
+    ref = F.conv2d(x, wt, bias, padding=1) + res
+    d = _dev()
+    wp = e.pack_weight(wt, device=d)
+    y = e.conv2d(e.to_nhwc_bf16(x.to(d)), wp, bias.to(d), cout, 3, residual=e.to_nhwc_bf16(res.to(d)), tile=tile)
+    check(f"conv3x3_s1{case}", nhwc_to_nchw(y), ref, metric_log)
+
+
+def test_conv_small_cin_padded(metric_log):
+    """conv_in-style layers: 3 (or 4) real input channels zero-padded to 64; small Cout zero-padded on store."""
+    e = _eng()
+    g = torch.Generator().manual_seed(5)
+    x = rbf(torch.randn(2, 3, 24, 24, generator=g))
+    wt = rbf(torch.randn(128, 3, 3, 3, generator=g) / math.sqrt(27))
+    bias = torch.randn(128, generator=g)
+    d = _dev()
+    y = e.conv2d(e.to_nhwc_bf16(x.to(d), 64), e.pack_weight(wt, 64, device=d), bias.to(d), 128, 3)
+    check("conv_in_pad64", nhwc_to_nchw(y), F.conv2d(x, wt, bias, padding=1), metric_log)
+    # Cout = 4 stored into 64 zero-padded channels (latent layout)
+    x2 = rbf(torch.randn(1, 128, 10, 12, generator=g))
+    w2 = rbf(torch.randn(4, 128, 3, 3, generator=g) / math.sqrt(128 * 9))
+    b2 = torch.randn(4, generator=g)
+    y2 = e.conv2d(e.to_nhwc_bf16(x2.to(d)), e.pack_weight(w2, device=d), b2.to(d), 4, 3, n_store=64)
+    assert y2.shape[-1] == 64 and float(y2[..., 4:].float().abs().max()) == 0.0
+    check("conv_cout4_store64", nhwc_to_nchw(y2, 4), F.conv2d(x2, w2, b2, padding=1), metric_log)
+
+
+@pytest.mark.parametrize("hw", [(16, 16), (15, 13), (30, 40)])
+def test_conv_stride2_both_paddings(hw, metric_log):
+    e = _eng()
+    h, w = hw
+    g = torch.Generator().manual_seed(h * 100 + w)
+    x = rbf(torch.randn(2, 64, h, w, generator=g))
+    wt = rbf(torch.randn(128, 64, 3, 3, generator=g) / math.sqrt(64 * 9))
+    bias = torch.randn(128, generator=g)
+    d = _dev()
+    xd, wp = e.to_nhwc_bf16(x.to(d)), e.pack_weight(wt, device=d)
+    # UNet Downsample2D: symmetric pad 1
+    ref = F.conv2d(x, wt, bias, stride=2, padding=1)
+    y = e.conv2d(xd, wp, bias.to(d), 128, 3, stride=2, pad_t=1, pad_l=1, out_hw=ref.shape[2:])
+    check(f"conv_s2_sym{hw}", nhwc_to_nchw(y), ref, metric_log)
+    # VAE encoder Downsample2D: pad right/bottom only, then stride 2 without padding (Appendix B.6)
+    ref2 = F.conv2d(F.pad(x, (0, 1, 0, 1)), wt, bias, stride=2, padding=0)
+    y2 = e.conv2d(xd, wp, bias.to(d), 128, 3, stride=2, pad_t=0, pad_l=0, out_hw=ref2.shape[2:])
+    check(f"conv_s2_asym{hw}", nhwc_to_nchw(y2), ref2, metric_log)
+
+
+@pytest.mark.parametrize("sizes", [((8, 8), (16, 16)), ((7, 10), (15, 20)), ((4, 5), (8, 10)), ((8, 10), (15, 20))])
+def test_conv_fused_nearest_upsample(sizes, metric_log):
+    """Upsample2D: nearest x2 or nearest-to-size (custom_unet.py:377-378) fused into the conv's gather."""
+    e = _eng()
+    (h, w), (uh, uw) = sizes
+    g = torch.Generator().manual_seed(h * 31 + uw)
+    x = rbf(torch.randn(2, 128, h, w, generator=g))
+    wt = rbf(torch.randn(64, 128, 3, 3, generator=g) / math.sqrt(128 * 9))
+    bias = torch.randn(64, generator=g)
+    ref = F.conv2d(F.interpolate(x, size=(uh, uw), mode="nearest"), wt, bias, padding=1)
+    d = _dev()
+    y = e.conv2d(e.to_nhwc_bf16(x.to(d)), e.pack_weight(wt, device=d), bias.to(d), 64, 3, ups_hw=(uh, uw))
+    check(f"conv_ups{sizes}", nhwc_to_nchw(y), ref, metric_log)
+
+
+GEMM_CASES = [(64, 64, 64, 0), (576, 1280, 320, 0), (100, 72, 128, 2), (1000, 320, 1280, 1), (36, 2560, 320, 0), (300, 24, 192, 3), (4800, 320, 320, 1)]
+
+
+@pytest.mark.parametrize("case", GEMM_CASES)
+def test_gemm_bias_residual(case, metric_log):
+    e = _eng()
+    m, n, k, tile = case
+    g = torch.Generator().manual_seed(m + n + k)
+    a = rbf(torch.randn(m, k, generator=g))
+    bt = rbf(torch.randn(n, k, generator=g) / math.sqrt(k))
+    bias = torch.randn(n, generator=g)
+    res = rbf(torch.randn(m, n, generator=g))
+    d = _dev()
+    ad, bd = a.to(d).to(torch.bfloat16), bt.to(d).to(torch.bfloat16)
+    nst = (n + 3) // 4 * 4
+    resd = torch.zeros(m, nst, dtype=torch.bfloat16, device=d)
+    resd[:, :n] = res.to(d).to(torch.bfloat16)
+    y = e.gemm(ad, bd, bias=bias.to(d), residual=resd, n_store=nst, tile=tile)
+    check(f"gemm{case}", y[:, :n], a @ bt.t() + bias + res, metric_log)
+    y32 = e.gemm(ad, bd, out_fp32=True, n_store=nst, tile=tile)
+    check(f"gemm_f32{case}", y32[:, :n], a @ bt.t(), metric_log, fp32=True)
+
+
+def test_gemm_row_bias_batched_zero_fill(metric_log):
+    """The V^T projection form: out[b][c][t] = sum_k W[c][k] x[b][t][k] + bias[c], zero-filled to Tpad columns."""
+    e = _eng()
+    g = torch.Generator().manual_seed(3)
+    bsz, t, c = 3, 100, 128
+    tpad = 128
+    wv = rbf(torch.randn(c, c, generator=g) / math.sqrt(c))
+    x = rbf(torch.randn(bsz, t, c, generator=g))
+    bias = torch.randn(c, generator=g)
+    d = _dev()
+    lib = e.load_library()
+    out = torch.full((bsz, c, tpad), 7.0, dtype=torch.bfloat16, device=d)
+    wd, xd, bd = wv.to(d).to(torch.bfloat16), x.to(d).to(torch.bfloat16), bias.to(d)
+    st = lib.gp_gemm(wd.data_ptr(), c, xd.data_ptr(), c, bd.data_ptr(), 2, None, 0, out.data_ptr(), tpad, c, t, c, t, tpad, 0, 0, bsz, 0, t * c, c * tpad, 0,
+                     torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    ref = torch.einsum("ck,btk->bct", wv, x) + bias[None, :, None]
+    check("gemm_vt_rowbias", out[:, :, :t], ref, metric_log)
+    assert float(out[:, :, t:].float().abs().max()) == 0.0, "padding columns must be written as zeros"
+
+
+def test_gemm_geglu(metric_log):
+    e = _eng()
+    g = torch.Generator().manual_seed(4)
+    m, c = 200, 128
+    a = rbf(torch.randn(m, c, generator=g))
+    w = rbf(torch.randn(8 * c, c, generator=g) / math.sqrt(c))
+    bias = torch.randn(8 * c, generator=g)
+    proj = a @ w.t() + bias
+    hidden, gate = proj.chunk(2, dim=-1)
+    ref = hidden * F.gelu(gate)
+    d = _dev()
+    wp = e.pack_weight(w, geglu=True, device=d)
+    # GEGLU-permuted bias: 16-row blocks alternate value / gate
+    half = 4 * c
+    idx = torch.arange(8 * c)
+    r = torch.where(idx >= half, idx - half, idx)
+    dst = (r // 16) * 32 + (idx >= half).long() * 16 + (r % 16)
+    pb = torch.empty_like(bias)
+    pb[dst] = bias
+    y = e.conv2d(a.to(d).to(torch.bfloat16).reshape(1, 1, m, c), wp, pb.to(d), 8 * c, 1, act="geglu")
+    check("gemm_geglu", y.reshape(m, 4 * c), ref, metric_log)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, True), (1, 128, 4096, True), (2, 320, 300, False), (1, 960, 144, True), (3, 2560, 36, True),
+                                  (1, 512, 1, True), (1, 128, 70000, True)])
+def test_groupnorm(case, metric_log):
+    e = _eng()
+    b, c, hw, silu = case
+    g = torch.Generator().manual_seed(c + hw)
+    x = rbf(torch.randn(b, c, hw, 1, generator=g) * 2.0 + 0.7)
+    gamma = 1 + 0.2 * torch.randn(c, generator=g)
+    beta = 0.3 * torch.randn(c, generator=g)
+    for eps in (1e-5, 1e-6):
+        ref = F.group_norm(x, 32, gamma, beta, eps)
+        if silu:
+            ref = F.silu(ref)
+        d = _dev()
+        y = e.groupnorm(e.to_nhwc_bf16(x.to(d)), gamma.to(d), beta.to(d), 32, eps, silu)
+        check(f"groupnorm{case}eps{eps}", nhwc_to_nchw(y), ref, metric_log)
+
+
+@pytest.mark.parametrize("case", [(100, 64), (577, 320), (64, 640), (1000, 1280), (3, 2560)])
+def test_layernorm(case, metric_log):
+    e = _eng()
+    rows, c = case
+    g = torch.Generator().manual_seed(rows + c)
+    x = rbf(torch.randn(rows, c, generator=g) * 3 - 1)
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.3 * torch.randn(c, generator=g)
+    d = _dev()
+    y = e.layernorm(x.to(d).to(torch.bfloat16), gamma.to(d), beta.to(d))
+    check(f"layernorm{case}", y, F.layer_norm(x, (c,), gamma, beta, 1e-5), metric_log)
+
+
+def _attn_ref(q, k, v, heads):
+    b, t, c = q.shape
+    hd = c // heads
+    qh, kh, vh = (z.view(b, -1, heads, hd).transpose(1, 2) for z in (q, k, v))
+    w = torch.softmax(qh @ kh.transpose(-1, -2) * hd ** -0.5, dim=-1)
+    return (w @ vh).transpose(1, 2).reshape(b, t, c)
+
+
+@pytest.mark.parametrize("case", [(1, 1, 1), (2, 16, 2), (1, 64, 1), (2, 100, 5), (1, 144, 20), (1, 576, 4), (2, 1200, 2), (1, 2304, 10)])
+def test_flash_attention_hd64(case, metric_log):
+    e = _eng()
+    b, t, heads = case
+    c = heads * 64
+    g = torch.Generator().manual_seed(t * 7 + heads)
+    qk = rbf(torch.randn(b, t, 2 * c, generator=g) * 1.5)  # fused [q | k] rows like the engine's projection output
+    v = rbf(torch.randn(b, t, c, generator=g))
+    q, k = qk[..., :c], qk[..., c:]
+    ref = _attn_ref(q, k, v, heads)
+    d = _dev()
+    tpad = (t + 63) // 64 * 64
+    vt = torch.zeros(b, c, tpad, dtype=torch.bfloat16, device=d)
+    vt[:, :, :t] = v.transpose(1, 2).to(d).to(torch.bfloat16)
+    qkd = qk.to(d).to(torch.bfloat16)
+    y = e.flash_attention(qkd[..., :c], qkd[..., c:], vt, heads)
+    check(f"flash64{case}", y, ref, metric_log)
+
+
+def test_flash_attention_spiky_scores(metric_log):
+    """Online-softmax rescale path: one key dominates late in the sequence (cdna guide rule 26)."""
+    e = _eng()
+    g = torch.Generator().manual_seed(9)
+    b, t, heads, c = 1, 320, 1, 64
+    q = rbf(torch.randn(b, t, c, generator=g))
+    k = rbf(torch.randn(b, t, c, generator=g))
+    k[0, 250] = rbf(q[0, 7] * 6.0)  # huge score for query 7 at a late tile
+    v = rbf(torch.randn(b, t, c, generator=g))
+    ref = _attn_ref(q, k, v, heads)
+    d = _dev()
+    vt = torch.zeros(b, c, 320, dtype=torch.bfloat16, device=d)
+    vt[:, :, :t] = v.transpose(1, 2).to(d).to(torch.bfloat16)
+    y = e.flash_attention(q.to(d).to(torch.bfloat16).contiguous(), k.to(d).to(torch.bfloat16).contiguous(), vt, heads)
+    check("flash64_spiky", y, ref, metric_log)
+
+
+@pytest.mark.parametrize("L", [2, 77])
+def test_cross_attention_small(L, metric_log):
+    e = _eng()
+    g = torch.Generator().manual_seed(L)
+    rows, c = 500, 320
+    q = rbf(torch.randn(rows, c, generator=g))
+    kc, vc = torch.randn(L, c, generator=g), torch.randn(L, c, generator=g)
+    ref = _attn_ref(q[None], kc[None], vc[None], c // 64)[0]
+    d = _dev()
+    y = e.cross_attention(q.to(d).to(torch.bfloat16), kc.to(d), vc.to(d))
+    check(f"cross_attn_L{L}", y, ref, metric_log)
+
+
+def test_softmax_rows(metric_log):
+    e = _eng()
+    g = torch.Generator().manual_seed(1)
+    rows, t, ld = 37, 1000, 1024
+    x = torch.randn(rows, ld, generator=g) * 20
+    d = _dev()
+    y = e.softmax_rows(x.to(d), t, 0.05)
+    check("softmax_rows", y[:, :t], torch.softmax(x[:, :t] * 0.05, dim=-1), metric_log)
+    assert float(y[:, t:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", [((6, 6), (12, 12), True), ((5, 7), (10, 14), True), ((12, 12), (24, 24), False), ((9, 12), (18, 23), False)])
+def test_bilinear(case, metric_log):
+    e = _eng()
+    (h, w), (ho, wo), align = case
+    g = torch.Generator().manual_seed(h + wo)
+    x = rbf(torch.randn(2, 64, h, w, generator=g))
+    ref = F.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=align)
+    d = _dev()
+    y = e.bilinear(e.to_nhwc_bf16(x.to(d)), (ho, wo), align)
+    check(f"bilinear{case}", nhwc_to_nchw(y), ref, metric_log)
