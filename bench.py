@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the one-step GenPercept path (depth head: SD2.1 VAE encoder -> UNet (t=1) -> VAE
+decoder) at 768x768, bf16 storage / fp32 accumulate, batch 4 per GPU, synthetic RGB resident in HBM, random-init weights
+of the exact SD2.1 architecture (BASELINE.json configs[1]; no checkpoints exist offline).
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch per GPU (gp_infer).  N > 1: one process per GPU, the batch of
+N*B independent images is sharded contiguously, weights replicated, no collective on the data path ("weak" scaling).
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the implicit-GEMM conv/linear MFMA kernel):
+algorithmic flops of its launches / their summed duration, measured with HIP events on the engine's stream in a separate
+instrumented pass right after the timed region (events around ~330 launches would perturb the timed region itself).
+`cpu_baseline` = the fp32 oracle (oracle/, a restatement: kind "port") on the host cores, rank 0, N == 1 only, on a
+bounded sample (one 384x384 image = BASELINE.json configs[0], 32 threads) so the default run stays within minutes.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TFLOP_PER_IMAGE_768 = 10.50  # VAE-enc 2.609 + UNet 2.137 + VAE-dec 5.754 (2*MAC of conv/linear/QK^T/PV)
+PEAK_BF16_TFLOPS = 2500.0    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def synthetic_rgb(batch: int, res: int, seed: int, device) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    noise = torch.randint(0, 256, (batch, 3, res, res), generator=g, dtype=torch.uint8).float()
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, res), torch.linspace(0, 1, res), indexing="ij")
+    smooth = torch.stack([yy, xx, (yy + xx) / 2])[None] * 255.0
+    return (0.5 * noise + 0.5 * smooth).round().clamp(0, 255).to(torch.uint8).to(device)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step")
+    ap.add_argument("--res", type=int, default=768)
+    ap.add_argument("--mode", default="depth")
+    ap.add_argument("--cpu-res", type=int, default=384, help="edge of the single image timed on the CPU oracle (BASELINE.json configs[0])")
+    ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads for the baseline leg (256 oversubscribes badly)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    from genpercept_amd import config as gc
+    from genpercept_amd import distributed as gd
+    from genpercept_amd import weights as gw
+    from genpercept_amd.engine import Engine
+
+    rank, local_rank, world = gd.init_process_group()
+    assert world == max(args.gpus, 1) or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    n_gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    ucfg, vcfg = gc.UNetConfig(), gc.VAEConfig()
+    t0 = time.time()
+    usd = gw.synth_state_dict(gw.unet_manifest(ucfg), seed=0)
+    vsd = gw.synth_state_dict(gw.vae_manifest(vcfg), seed=1)
+    ctx = torch.randn(2, ucfg.cross_attention_dim, generator=torch.Generator().manual_seed(2))
+    eng = Engine(local_rank, ucfg, vcfg, None)
+    eng.load_state_dict("vae", vsd)
+    eng.load_state_dict("unet", usd)
+    eng.set_context(ctx)
+    eng.finalize()
+    t_load = time.time() - t0
+    if not (rank == 0 and n_gpus == 1 and not args.no_cpu):
+        del usd  # the CPU-baseline leg needs the fp32 weights
+
+    lo, hi = gd.shard_range(args.batch * n_gpus, rank, n_gpus)
+    rgb = synthetic_rgb(args.batch * n_gpus, args.res, 1234, "cpu")[lo:hi].to(dev)
+
+    for _ in range(args.warmup):
+        out = eng.infer(rgb, args.mode)
+    torch.cuda.synchronize()
+    gd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.infer(rgb, args.mode)
+    torch.cuda.synchronize()
+    gd.barrier()
+    elapsed = gd.max_over_ranks(time.perf_counter() - t0, dev)
+    ms_per_step = elapsed / args.steps * 1e3
+    images = args.batch * n_gpus * args.steps
+    value = images / elapsed
+    assert torch.isfinite(out).all()
+
+    roofline = None
+    stages = None
+    if not args.no_profile:
+        eng.set_profile(2)
+        eng.reset_timings()
+        eng.infer(rgb, args.mode)
+        tm = eng.timings()
+        eng.set_profile(0)
+        scale = (args.res / 768.0) ** 2
+        if tm["ms_igemm"] > 0:
+            ach = tm["flops_igemm"] / (tm["ms_igemm"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x32_bf16)",
+                        "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "launches": tm["n_igemm"], "flops_per_launch_avg": tm["flops_igemm"] / max(tm["n_igemm"], 1),
+                        "avg_launch_ms": tm["ms_igemm"] / max(tm["n_igemm"], 1),
+                        "attn_achieved": round(tm["flops_attn"] / max(tm["ms_attn"], 1e-9) / 1e9, 2), "attn_launches": tm["n_attn"],
+                        "pipeline_achieved": round(TFLOP_PER_IMAGE_768 * scale * args.batch / (ms_per_step * 1e-3), 2),
+                        "pipeline_frac": round(TFLOP_PER_IMAGE_768 * scale * args.batch / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4)}
+        stages = {"ms_encode": round(tm["ms_encode"], 3), "ms_unet": round(tm["ms_unet"], 3), "ms_head": round(tm["ms_head"], 3),
+                  "ms_igemm_sum": round(tm["ms_igemm"], 3), "ms_attn_sum": round(tm["ms_attn"], 3), "kernel_launches": tm["n_launches"],
+                  "algorithmic_tflop_counted": round((tm["flops_igemm"] + tm["flops_attn"]) / 1e12 / args.batch, 3)}
+
+    cpu = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu:
+        from oracle import pipeline as opipe  # CPU baseline leg only
+        from oracle import sd21 as osd
+        nthr = max(1, min(os.cpu_count(), args.cpu_threads))
+        torch.set_num_threads(nthr)
+        r = args.cpu_res
+        x = opipe.normalize_rgb(synthetic_rgb(1, r, 99, "cpu"))
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            ref = opipe.single_infer(vsd, osd.VAECfg(), usd, osd.UNetCfg(), x, ctx, args.mode)
+            dt = time.perf_counter() - t0
+        cpu = {"value": round(1.0 / dt, 5), "unit": f"images/sec at {r}x{r} fp32", "cores": nthr, "kind": "port",
+               "sample": f"1 image {r}x{r} ({TFLOP_PER_IMAGE_768 * (r / 768.0) ** 2:.3f} TFLOP), torch-CPU fp32 restatement of the diffusers path "
+                         f"(oracle/), {dt:.1f} s; scaled by pixel count to 768x768: {1.0 / (dt * (768.0 / r) ** 2):.5f} images/sec",
+               "seconds": round(dt, 2)}
+        assert torch.isfinite(ref).all()
+
+    if rank == 0:
+        line = {"metric": "images/sec at 768x768 bf16 (depth head)", "value": round(value, 3), "unit": "images/sec", "n_gpus": n_gpus,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"depth head, SD2.1 VAE-enc + UNet(t=1) + VAE-dec, {args.res}x{args.res}, batch {args.batch}/GPU "
+                                       "(BASELINE.json configs[1])", "global_batch": args.batch * n_gpus, "resolution": args.res,
+                           "parallelism": f"dp{n_gpus} (batch-sharded, weights replicated, no data-path collective)",
+                           "weights": "random-init SD2.1 architecture (865.9M + 83.7M params)", "load_s": round(t_load, 1)},
+                "roofline": roofline, "cpu_baseline": cpu, "stages": stages}
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

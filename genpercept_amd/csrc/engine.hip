@@ -1115,7 +1115,7 @@ gp_status gp_infer(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, i
             e->drop(lat);
             if (stage_ev) HIPCHK(hipEventRecord(e->ev[2], e->st));
             Act rev[4] = {feats[3], feats[2], feats[1], feats[0]};
-            const long long out_px = (long long)rev[0].H * 8 * rev[0].W * 8;
+            const long long out_px = (long long)gp_dpt_out_size(rev[0].H) * gp_dpt_out_size(rev[0].W);
             e->dpt_head(rev, out_dev);
             for (int i = 0; i < 4; ++i) e->drop(feats[i]);
             launch_minmax_norm(out_dev, B, out_px, e->mm_ws, e->st);

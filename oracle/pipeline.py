@@ -50,7 +50,7 @@ def single_infer(vae_sd, vae_cfg: osd.VAECfg, unet_sd, unet_cfg: osd.UNetCfg, rg
     min-max normalised [B,1,H,W] (DPT head; min/max PER IMAGE, which is what the reference computes because it
     only ever sees B == 1)."""
     b = rgb_norm.shape[0]
-    ctx = ctx.reshape(1, -1, ctx.shape[-1]).float().expand(b, -1, -1)
+    ctx = ctx.reshape(1, -1, ctx.shape[-1]).to(rgb_norm.dtype).expand(b, -1, -1)
     latent = osd.encode_rgb(vae_sd, vae_cfg, rgb_norm)
     if dpt_sd is None:
         v, _ = osd.unet_forward(unet_sd, unet_cfg, latent, timestep, ctx)

@@ -346,6 +346,7 @@ def timestep_embedding(t: Tensor, dim: int) -> Tensor:
 
 def time_embed(sd, cfg: UNetCfg, t: Tensor) -> Tensor:
     te = timestep_embedding(t, cfg.block_out_channels[0])
+    te = te.to(sd["time_embedding.linear_1.weight"].dtype)  # custom_unet.py:165-168: fp32 sinusoid cast to the model dtype
     return _linear(F.silu(_linear(te, sd, "time_embedding.linear_1")), sd, "time_embedding.linear_2")
 
 
