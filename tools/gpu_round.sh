@@ -17,3 +17,12 @@ if [[ "$WHAT" == "all" || "$WHAT" == *bench* ]]; then
   timeout 1500 python bench.py --steps 3 --warmup 1 > gpurun_out/bench.log 2>&1
   echo "== bench exit $?"; tail -n 12 gpurun_out/bench.log
 fi
+if [[ "$WHAT" == *prof* ]]; then
+  export TMPDIR=/tmp
+  ROOTD=$(pwd)
+  (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOTD/gpurun_out/prof" -- python "$ROOTD/bench.py" --steps 2 --warmup 1 --no-cpu --no-profile > "$ROOTD/gpurun_out/prof_bench.log" 2>&1)
+  echo "== prof exit $?"; tail -n 3 gpurun_out/prof_bench.log
+  find gpurun_out/prof -name "*kernel_stats*" | head; F=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && head -40 "$F"
+  # keep the merge small: drop the raw trace, keep stats
+  find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete
+fi
