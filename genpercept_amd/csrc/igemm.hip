@@ -15,13 +15,19 @@
 #include "common.h"
 #include "kernels.h"
 
-template <int BM, int BN, int WM, int WN, int KS>
-__global__ __launch_bounds__(256) void igemm_kernel(const IGemmParams p) {
+template <int N>
+GP_DEV void wait_vm_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WM, int WN, int KS, int NSTAGE>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p) {
+    constexpr int NW = WM * WN;                     // waves per workgroup (4 or 8)
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 16, FN = TN / 16;
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;  // 8-row DMA groups per wave
+    constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW);  // 8-row DMA groups per wave
+    constexpr int LPS = A_IT + B_IT;                // LDS-DMA instructions per wave per stage
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
-    static_assert(WM * WN == 4 && TM % 16 == 0 && TN % 16 == 0 && (FN % 2) == 0, "tile shape");
+    static_assert((NW == 4 || NW == 8) && TM % 16 == 0 && TN % 16 == 0 && (FN % 2) == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmParams p) {
     bool a_tok[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + (wave + 4 * i) * 8 + (lane >> 3);
+        const int m = m0 + (wave + NW * i) * 8 + (lane >> 3);
         a_ok[i] = m < p.M;
         if (KS == 1) {
             a_base[i] = in + (long long)m * p.lda + chunk * 8;
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmParams p) {
     bool w_ok[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int n = n0 + (wave + 4 * i) * 8 + (lane >> 3);
+        const int n = n0 + (wave + NW * i) * 8 + (lane >> 3);
         w_ok[i] = n < p.n_rows;
         w_base[i] = wt + (long long)n * p.ldw + chunk * 8;
     }
@@ -103,13 +109,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmParams p) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const bf16_t* src = a_tok[i] ? a_tap[i] + koff : zsrc;
-            glds16(src, sb + (wave + 4 * i) * 1024);
+            glds16(src, sb + (wave + NW * i) * 1024);
         }
         const int woff = st_tap * Cin + koff;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const bf16_t* src = w_ok[i] ? w_base[i] + woff : zsrc;
-            glds16(src, sb + A_BYTES + (wave + 4 * i) * 1024);
+            glds16(src, sb + A_BYTES + (wave + NW * i) * 1024);
         }
         if (++st_cc == cpt) {
             st_cc = 0;
@@ -144,19 +150,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmParams p) {
         }
     };
 
-    // ---- main loop: DMA(t+1) in flight under MFMA(t) ----------------------------------------------------------
-    stage(0);
-    wait_vm0();
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        stage(cur ^ 1);
+    // ---- main loop: an NSTAGE-deep LDS ring, NSTAGE-1 K-steps of DMA in flight under the MFMAs -----------------------
+    // Per step: counted vmcnt (this wave's DMAs of step kt have landed) -> raw s_barrier (everybody's have, and everybody
+    // is done reading the slot about to be refilled) -> issue the DMA of step kt+NSTAGE-1 -> MFMAs of step kt.
+    // __syncthreads() would drain vmcnt to 0 and serialise the ring (cdna guide, "Pipelining across barriers").
+#pragma unroll
+    for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+        if (s0 < nk) stage(s0);
+    int cur = 0, nxt = NSTAGE - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = min(NSTAGE - 2, nk - 1 - kt);  // stages issued after step kt's
+        if (ahead >= 2) wait_vm_n<2 * LPS>();
+        else if (ahead == 1) wait_vm_n<LPS>();
+        else wait_vm_n<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NSTAGE - 1 < nk) stage(nxt);
         compute(cur);
-        wait_vm0();
-        __syncthreads();
-        cur ^= 1;
+        cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
     }
-    compute(cur);
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
     const bool geglu = p.act == GP_ACT_GEGLU;
@@ -228,33 +240,39 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSTAGE>
 static void launch_cfg(const IGemmParams& p, hipStream_t s) {
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
     const int tiles = ((p.M + BM - 1) / BM) * ((ncols + BN - 1) / BN);
-    const size_t lds = 2 * (BM + BN) * 128;
-    dim3 grid(tiles, p.batch > 0 ? p.batch : 1);
+    const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
+    dim3 grid(tiles, p.batch > 0 ? p.batch : 1), block(64 * WM * WN);
     if (p.ks == 3) {
         static bool attr3 = false;
-        if (!attr3) { hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr3 = true; }
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), lds, s, p);
+        if (!attr3) { (void)hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, 3, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr3 = true; }
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 3, NSTAGE>), grid, block, lds, s, p);
     } else {
         static bool attr1 = false;
-        if (!attr1) { hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), lds, s, p);
+        if (!attr1) { (void)hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, 1, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, NSTAGE>), grid, block, lds, s, p);
     }
 }
 
+// tile_hint: 0 auto, 1 = 128x128 (4 waves, 2-deep), 2 = 64x64 (4 waves, 3-deep), 3 = 256x32 (4 waves, 2-deep),
+//            4 = 256x128 (8 waves, 3-deep ring: the large-problem configuration)
 void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s) {
     int cfg = tile_hint;
     if (cfg == 0) {
         const int ncols = p.N > p.n_store ? p.N : p.n_store;
-        const long long t128 = (long long)((p.M + 127) / 128) * ((ncols + 127) / 128) * (p.batch > 0 ? p.batch : 1);
+        const long long nb = p.batch > 0 ? p.batch : 1;
+        const long long t128 = (long long)((p.M + 127) / 128) * ((ncols + 127) / 128) * nb;
+        const long long t256 = (long long)((p.M + 255) / 256) * ((ncols + 127) / 128) * nb;
         if (ncols <= 32) cfg = 3;
         else if (ncols <= 64 || t128 < 192) cfg = 2;
+        else if (t256 >= 256) cfg = 4;
         else cfg = 1;
     }
-    if (cfg == 1) launch_cfg<128, 128, 2, 2>(p, s);
-    else if (cfg == 2) launch_cfg<64, 64, 2, 2>(p, s);
-    else launch_cfg<256, 32, 4, 1>(p, s);
+    if (cfg == 1) launch_cfg<128, 128, 2, 2, 2>(p, s);
+    else if (cfg == 2) launch_cfg<64, 64, 2, 2, 3>(p, s);
+    else if (cfg == 3) launch_cfg<256, 32, 4, 1, 2>(p, s);
+    else launch_cfg<256, 128, 4, 2, 3>(p, s);
 }

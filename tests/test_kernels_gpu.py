@@ -57,6 +57,7 @@ CONV_CASES = [
     # B, H, W, Cin, Cout, tile
     (2, 16, 16, 64, 64, 1), (2, 16, 16, 64, 64, 2), (2, 16, 16, 64, 64, 3),
     (1, 24, 20, 128, 320, 0), (1, 13, 15, 192, 100, 1), (3, 9, 7, 64, 3, 0), (1, 12, 12, 1280, 1280, 0), (1, 40, 36, 256, 128, 1),
+    (2, 16, 16, 64, 64, 4), (1, 40, 36, 256, 128, 4), (2, 33, 31, 128, 320, 4), (1, 96, 96, 128, 128, 0), (1, 17, 19, 64, 200, 2),
 ]
 
 
@@ -130,7 +131,8 @@ def test_conv_fused_nearest_upsample(sizes, metric_log):
     check(f"conv_ups{sizes}", nhwc_to_nchw(y), ref, metric_log)
 
 
-GEMM_CASES = [(64, 64, 64, 0), (576, 1280, 320, 0), (100, 72, 128, 2), (1000, 320, 1280, 1), (36, 2560, 320, 0), (300, 24, 192, 3), (4800, 320, 320, 1)]
+GEMM_CASES = [(64, 64, 64, 0), (576, 1280, 320, 0), (100, 72, 128, 2), (1000, 320, 1280, 1), (36, 2560, 320, 0), (300, 24, 192, 3), (4800, 320, 320, 1),
+              (4800, 320, 320, 4), (1000, 130, 64, 4), (36864, 320, 320, 0), (70, 64, 2304, 4)]
 
 
 @pytest.mark.parametrize("case", GEMM_CASES)
