@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -183,17 +184,22 @@ struct gp_engine {
         return d;
     }
 
-    // Pack [cout][cin][ks][ks] fp32 -> [n_rows][taps][cin_pad] bf16 (+ optional GEGLU 16-row interleave).
+    // GEGLU projection rows [value(0..C4) ; gate(0..C4)] -> packed order: every 32-row block holds 16 outputs, value j at
+    // 8*(j%16/4) + j%4 and its gate 4 rows further, which is where the igemm epilogue finds them in one lane.
+    static int geglu_row(int n, int cout) {
+        const int half = cout / 2;
+        const bool gate = n >= half;
+        const int r = gate ? n - half : n;
+        return (r / 16) * 32 + ((r % 16) / 4) * 8 + (gate ? 4 : 0) + (r % 4);
+    }
+    // Pack [cout][cin][ks][ks] fp32 -> [n_rows][taps][cin_pad] bf16 (+ optional GEGLU row interleave).
     static void pack_rows(const float* w, int cout, int cin, int ks, int cin_pad, bool geglu, std::vector<bf16_t>& out, int row0, int n_rows_total) {
         const int taps = ks * ks;
         (void)n_rows_total;
         for (int n = 0; n < cout; ++n) {
             int dst = n;
             if (geglu) {
-                const int half = cout / 2;
-                const bool gate = n >= half;
-                const int r = gate ? n - half : n;
-                dst = (r / 16) * 32 + (gate ? 16 : 0) + (r % 16);
+                dst = geglu_row(n, cout);
             }
             bf16_t* o = out.data() + (size_t)(row0 + dst) * taps * cin_pad;
             const float* wi = w + (size_t)n * cin * taps;
@@ -210,12 +216,7 @@ struct gp_engine {
         if (bias) {
             std::vector<float> b(bias, bias + cout);
             if (geglu) {
-                const int half = cout / 2;
-                for (int n = 0; n < cout; ++n) {
-                    const bool gate = n >= half;
-                    const int r = gate ? n - half : n;
-                    b[(r / 16) * 32 + (gate ? 16 : 0) + (r % 16)] = bias[n];
-                }
+                for (int n = 0; n < cout; ++n) b[geglu_row(n, cout)] = bias[n];
             }
             pw.bias = upload(b.data(), b.size());
         }
@@ -1226,6 +1227,7 @@ gp_status gp_conv2d(const void* in, const void* w_packed, const float* bias, con
         const int nst = n_store > 0 ? n_store : nout;
         p.lda = Cin; p.ldo = nst; p.ldres = nst; p.ldw = (ks == 3 ? 9 : 1) * Cin; p.n_store = nst; p.out_fp32 = out_fp32; p.act = act;
         p.bias_mode = bias ? GP_BIAS_COL : GP_BIAS_NONE; p.batch = 1;
+        if (const char* dbg = getenv("GENPERCEPT_IGEMM_DBG")) p.dbg = atoi(dbg);  // profiling ablations (tools/conv_bench.py)
         launch_igemm(p, tile_hint, (hipStream_t)stream);
         HIPCHK(hipGetLastError());
         return GP_OK;

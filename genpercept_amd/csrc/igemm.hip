@@ -6,33 +6,41 @@
 //   out[m][n] = act( sum_{tap, c} in[pixel(m, tap)][c] * wt[n][tap][c] + bias ) (+ res[m][n])
 //
 // Data layout (HBM): activations NHWC bf16, weights [Cout][tap][Cin] bf16 (k-contiguous), fp32 bias, fp32 accumulate.
-// Tiling: BM pixels x BN channels per 256-thread workgroup (4 waves), BK = 64 channels of one tap per K-step.
-// Both operand tiles are brought HBM->LDS by LDS-DMA (global_load_lds_dwordx4, 16 B/lane) into 128-byte rows with a
-// 16-byte-slot XOR swizzle applied on the SOURCE address (the DMA destination is lane-linear), double-buffered: the
-// DMA of K-step t+1 is in flight while the MFMAs of K-step t run.  Padding / out-of-range rows read a zero page.
-// The MFMA is issued with the WEIGHTS as the A operand and the PIXELS as the B operand, so each lane ends up holding
-// 4 consecutive output channels of one pixel: bias is a float4, the bf16 store is 8 bytes per lane.
+// Tiling: BM pixels x BN channels per workgroup of 4 or 8 waves, BK = 64 channels of one tap per K-step.
+//  * Both operand tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 16 B/lane) into 128-byte rows with a 16-byte
+//    slot XOR swizzle applied on the SOURCE address (the DMA destination is lane-linear); padding / out-of-range rows
+//    read a zero page.  Pixel tile and weight tile use different swizzles, each conflict-free for its ds_read_b128 pattern.
+//  * NSTAGE-deep LDS ring: counted s_waitcnt vmcnt + raw s_barrier, NSTAGE-1 K-steps of DMA in flight under the MFMAs.
+//  * Role split: the first half of the waves runs MFMAs then issues DMA, the second half the other way round, so each
+//    SIMD always has one wave feeding the matrix pipe while its partner feeds the memory pipe (measured: lock-step issue
+//    made DMA and MFMA time add up instead of overlap).
+//  * The MFMA takes the WEIGHTS as A operand and the PIXELS as B operand, and the weight-fragment rows are chosen so that
+//    a lane ends up with 8 consecutive output channels of one pixel: bias is two float4 loaded before the K loop, the
+//    bf16 store is 16 bytes per lane, the residual one 16-byte load.
 #include "common.h"
 #include "kernels.h"
 
 template <int N>
 GP_DEV void wait_vm_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// KS: 1 = 1x1 / plain rows, 3 = 3x3, 4 = 3x3 on a nearest-upsampled input
 template <int BM, int BN, int WM, int WN, int KS, int NSTAGE>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p) {
     constexpr int NW = WM * WN;                     // waves per workgroup (4 or 8)
     constexpr int TM = BM / WM, TN = BN / WN;
-    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int FM = TM / 16, FN = TN / 16, FP = FN / 2;  // FP: pairs of weight fragments (32 output channels)
     constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW);  // 8-row DMA groups per wave
     constexpr int LPS = A_IT + B_IT;                // LDS-DMA instructions per wave per stage
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
-    static_assert((NW == 4 || NW == 8) && TM % 16 == 0 && TN % 16 == 0 && (FN % 2) == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
+    constexpr bool CONV = KS != 1, UPS = KS == 4;
+    static_assert((NW == 4 || NW == 8) && TM % 16 == 0 && TN % 32 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    const bool second_half = wave >= NW / 2;
 
     const int ncols = p.N > p.n_store ? p.N : p.n_store;  // n_store > N: zero-filled padding columns
     const int tiles_n = (ncols + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
@@ -44,36 +52,49 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
     const bf16_t* wt = p.wt + (long long)z * p.wt_bs;
     const int Cin = p.Cin;
     const int cpt = Cin >> 6;                       // 64-channel chunks per tap
-    const int nk = (KS == 3 ? 9 : 1) * cpt;
-    const int taps = (KS == 3 ? 9 : 1);
+    const int nk = (CONV ? 9 : 1) * cpt;
 
     // this lane's 16-byte source chunk inside a 128-byte row (swizzled; identical for every DMA group of the wave)
-    const int chunk = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
-    const bf16_t* zsrc = p.zero + chunk * 8;
+    //   pixel tile:  slot ^ ((row >> 1) & 7)                       rows read 16-consecutive
+    //   weight tile: slot ^ (b1 | b3 << 1 | b4 << 2) of the row    rows read as {8q + 4h + r}
+    const int chunk_a = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
+    const int chunk_w = (lane & 7) ^ (((lane >> 4) & 1) | ((wave & 1) << 1) | (((wave >> 1) & 1) << 2));
+    const bf16_t* zsrc_a = p.zero + chunk_a * 8;
+    const bf16_t* zsrc_w = p.zero + chunk_w * 8;
 
-    // ---- per-lane row descriptors -------------------------------------------------------------------------
-    const bf16_t* a_base[A_IT];   // KS==1: row pointer (+chunk); KS==3: image base pointer (+chunk)
-    int a_y0[A_IT], a_x0[A_IT];
-    bool a_ok[A_IT];
-    const bf16_t* a_tap[A_IT];    // KS==3: pointer for the current tap
-    bool a_tok[A_IT];
+    // ---- per-lane row descriptors ---------------------------------------------------------------------------------
+    const bf16_t* a_base[A_IT];   // plain: row pointer; conv: pointer of the (virtual) top-left tap pixel; ups: image base
+    unsigned a_mask[A_IT];        // bit t: tap t of this row is inside the image (plain rows: bit 0)
+    int a_y0[UPS ? A_IT : 1], a_x0[UPS ? A_IT : 1];
+    const bf16_t* a_tap[UPS ? A_IT : 1];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int m = m0 + (wave + NW * i) * 8 + (lane >> 3);
-        a_ok[i] = m < p.M;
-        if (KS == 1) {
-            a_base[i] = in + (long long)m * p.lda + chunk * 8;
-            a_y0[i] = a_x0[i] = 0;
+        const bool ok = m < p.M;
+        if (!CONV) {
+            a_base[i] = in + (long long)m * p.lda + chunk_a * 8;
+            a_mask[i] = ok ? 1u : 0u;
         } else {
             const int hw = p.Ho * p.Wo;
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            a_y0[i] = oy * p.stride - p.pad_t;
-            a_x0[i] = ox * p.stride - p.pad_l;
-            a_base[i] = in + (long long)b * p.Hi * p.Wi * Cin + chunk * 8;
+            const int y0 = oy * p.stride - p.pad_t, x0 = ox * p.stride - p.pad_l;
+            const bf16_t* img = in + (long long)b * p.Hi * p.Wi * Cin + chunk_a * 8;
+            unsigned mk = 0;
+            const int hlim = UPS ? p.Hu : p.Hi, wlim = UPS ? p.Wu : p.Wi;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if (ok && (unsigned)(y0 + t / 3) < (unsigned)hlim && (unsigned)(x0 + t % 3) < (unsigned)wlim) mk |= 1u << t;
+            a_mask[i] = mk;
+            if constexpr (UPS) {
+                a_base[i] = img;
+                a_y0[i] = y0;
+                a_x0[i] = x0;
+                a_tap[i] = img;
+            } else {
+                a_base[i] = img + ((long long)y0 * p.Wi + x0) * Cin;  // may point outside the image; only dereferenced under the mask
+            }
         }
-        a_tap[i] = a_base[i];
-        a_tok[i] = a_ok[i];
     }
     const bf16_t* w_base[B_IT];
     bool w_ok[B_IT];
@@ -81,46 +102,46 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
     for (int i = 0; i < B_IT; ++i) {
         const int n = n0 + (wave + NW * i) * 8 + (lane >> 3);
         w_ok[i] = n < p.n_rows;
-        w_base[i] = wt + (long long)n * p.ldw + chunk * 8;
+        w_base[i] = wt + (long long)n * p.ldw + chunk_w * 8;
     }
-    const float ups_sy = p.ups ? (float)p.Hi / (float)p.Hu : 1.f;
-    const float ups_sx = p.ups ? (float)p.Wi / (float)p.Wu : 1.f;
+    const float ups_sy = UPS ? (float)p.Hi / (float)p.Hu : 1.f;
+    const float ups_sx = UPS ? (float)p.Wi / (float)p.Wu : 1.f;
 
     int st_tap = 0, st_cc = 0, st_ky = 0, st_kx = 0;
     auto stage = [&](int buf) {
         char* sb = smem + buf * STAGE;
-        if (KS == 3 && st_cc == 0) {
+        if constexpr (UPS) {
+          if (st_cc == 0) {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
-                int iy = a_y0[i] + st_ky, ix = a_x0[i] + st_kx;
-                bool ok;
-                if (p.ups) {
-                    ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hu && (unsigned)ix < (unsigned)p.Wu;
-                    iy = min((int)floorf((float)iy * ups_sy), p.Hi - 1);
-                    ix = min((int)floorf((float)ix * ups_sx), p.Wi - 1);
-                } else {
-                    ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-                }
-                a_tok[i] = ok;
+                const int iy = min((int)floorf((float)(a_y0[i] + st_ky) * ups_sy), p.Hi - 1);
+                const int ix = min((int)floorf((float)(a_x0[i] + st_kx) * ups_sx), p.Wi - 1);
                 a_tap[i] = a_base[i] + ((long long)iy * p.Wi + ix) * Cin;
             }
+          }
         }
         const int koff = st_cc << 6;
+        const long long aoff = CONV && !UPS ? (long long)(st_ky * p.Wi + st_kx) * Cin + koff : koff;  // wave-uniform
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const bf16_t* src = a_tok[i] ? a_tap[i] + koff : zsrc;
+            const bool ok = (a_mask[i] >> st_tap) & 1u;
+            const bf16_t* ab;
+            if constexpr (UPS) ab = a_tap[i]; else ab = a_base[i];
+            const bf16_t* src = ok ? ab + aoff : zsrc_a;
             glds16(src, sb + (wave + NW * i) * 1024);
         }
         const int woff = st_tap * Cin + koff;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const bf16_t* src = w_ok[i] ? w_base[i] + woff : zsrc;
+            const bf16_t* src = w_ok[i] ? w_base[i] + woff : zsrc_w;
             glds16(src, sb + A_BYTES + (wave + NW * i) * 1024);
         }
         if (++st_cc == cpt) {
             st_cc = 0;
-            ++st_tap;
-            if (++st_kx == 3) { st_kx = 0; ++st_ky; }
+            if (CONV) {
+                ++st_tap;
+                if (++st_kx == 3) { st_kx = 0; ++st_ky; }
+            }
         }
     };
 
@@ -130,19 +151,25 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int xr = (lane >> 1) & 7;  // swizzle term of the fragment rows (row & 15 == lane & 15)
-    const int a_row_off = (wm * TM + (lane & 15)) * 128;
-    const int b_row_off = A_BYTES + (wn * TN + (lane & 15)) * 128;
+    // fragment addressing: pixel fragment j = 16 consecutive tile rows; weight fragment i of pair ip = i/2 takes tile rows
+    // 32*ip + 8*(a>>2) + 4*(i&1) + (a&3) for MFMA row a = lane&15, i.e. accumulator (q = lane>>4, r) of fragments
+    // (2ip, 2ip+1) are output channels 32*ip + 8q + r and 32*ip + 8q + 4 + r: 8 consecutive channels per lane.
+    const int a15 = lane & 15;
+    const int xr_a = (lane >> 1) & 7;
+    const int xr_w = ((a15 >> 1) & 1) | (((a15 >> 2) & 1) << 1) | (((a15 >> 3) & 1) << 2);
+    const int a_row_off = (wm * TM + a15) * 128;
+    const int w_row_off = A_BYTES + (wn * TN + 8 * (a15 >> 2) + (a15 & 3)) * 128;
     auto compute = [&](int buf) {
         const char* sb = smem + buf * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const int so = ((kk * 4 + (lane >> 4)) ^ xr) << 4;
+            const int sl = kk * 4 + (lane >> 4);
+            const int so_a = (sl ^ xr_a) << 4, so_w = (sl ^ xr_w) << 4;
             bf16x8_t wf[FN], xf[FM];
 #pragma unroll
-            for (int i = 0; i < FN; ++i) wf[i] = *(const bf16x8_t*)(sb + b_row_off + i * 2048 + so);
+            for (int i = 0; i < FN; ++i) wf[i] = *(const bf16x8_t*)(sb + w_row_off + (i >> 1) * 4096 + (i & 1) * 512 + so_w);
 #pragma unroll
-            for (int j = 0; j < FM; ++j) xf[j] = *(const bf16x8_t*)(sb + a_row_off + j * 2048 + so);
+            for (int j = 0; j < FM; ++j) xf[j] = *(const bf16x8_t*)(sb + a_row_off + j * 2048 + so_a);
 #pragma unroll
             for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -150,83 +177,82 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
         }
     };
 
-    // ---- main loop: an NSTAGE-deep LDS ring, NSTAGE-1 K-steps of DMA in flight under the MFMAs -----------------------
-    // Per step: counted vmcnt (this wave's DMAs of step kt have landed) -> raw s_barrier (everybody's have, and everybody
-    // is done reading the slot about to be refilled) -> issue the DMA of step kt+NSTAGE-1 -> MFMAs of step kt.
-    // __syncthreads() would drain vmcnt to 0 and serialise the ring (cdna guide, "Pipelining across barriers").
+    // ---- prologue: fill NSTAGE-1 ring slots, then fetch this lane's bias values while the DMA is in flight ------------
 #pragma unroll
     for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
         if (s0 < nk) stage(s0);
+
+    const bool geglu = p.act == GP_ACT_GEGLU;
+    const float* bias = p.bias ? p.bias + (long long)z * p.bias_bs : nullptr;
+    const int q8 = 8 * (lane >> 4);
+    float bcol[FP][8];
+#pragma unroll
+    for (int ip = 0; ip < FP; ++ip) {
+        const int c0 = n0 + wn * TN + 32 * ip + q8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bcol[ip][e] = 0.f;
+        if (p.bias_mode == GP_BIAS_COL) {
+            if (c0 + 7 < p.N) {
+                const float4 b0 = *(const float4*)(bias + c0), b1 = *(const float4*)(bias + c0 + 4);
+                bcol[ip][0] = b0.x; bcol[ip][1] = b0.y; bcol[ip][2] = b0.z; bcol[ip][3] = b0.w;
+                bcol[ip][4] = b1.x; bcol[ip][5] = b1.y; bcol[ip][6] = b1.z; bcol[ip][7] = b1.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (c0 + e < p.N) bcol[ip][e] = bias[c0 + e];
+            }
+        }
+    }
+
+    // ---- main loop -------------------------------------------------------------------------------------------------------
+    // Per step: counted vmcnt (this wave's DMAs of step kt have landed) -> raw s_barrier (everybody's have, and everybody
+    // is done reading the slot about to be refilled) -> {MFMAs of step kt, DMA of step kt+NSTAGE-1} in role-dependent order.
+    // __syncthreads() would drain vmcnt to 0 and serialise the ring (cdna guide, "Pipelining across barriers").
     int cur = 0, nxt = NSTAGE - 1;
     for (int kt = 0; kt < nk; ++kt) {
         const int ahead = min(NSTAGE - 2, nk - 1 - kt);  // stages issued after step kt's
-        if (ahead >= 2) wait_vm_n<2 * LPS>();
-        else if (ahead == 1) wait_vm_n<LPS>();
-        else wait_vm_n<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + NSTAGE - 1 < nk) stage(nxt);
-        compute(cur);
+        if (!(p.dbg & 4)) {
+            if (ahead >= 2) wait_vm_n<2 * LPS>();
+            else if (ahead == 1) wait_vm_n<LPS>();
+            else wait_vm_n<0>();
+            __builtin_amdgcn_s_barrier();
+        }
+        const bool do_stage = kt + NSTAGE - 1 < nk && !(p.dbg & 1);
+        const bool do_comp = !(p.dbg & 2);
+        if (second_half) {
+            if (do_stage) stage(nxt);
+            if (do_comp) compute(cur);
+        } else {
+            if (do_comp) compute(cur);
+            if (do_stage) stage(nxt);
+        }
         cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
         nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
     }
 
-    // ---- epilogue ------------------------------------------------------------------------------------------------
-    const bool geglu = p.act == GP_ACT_GEGLU;
+    // ---- epilogue ------------------------------------------------------------------------------------------------------
     const int n_out = geglu ? (p.N >> 1) : p.N;
-    const float* bias = p.bias ? p.bias + (long long)z * p.bias_bs : nullptr;
     const bf16_t* res = p.res ? p.res + (long long)z * p.res_bs : nullptr;
-    const int q4 = 4 * (lane >> 4);
+    const bool vec_ok = (p.ldo & 7) == 0;
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
-        const int m = m0 + wm * TM + j * 16 + (lane & 15);
+        const int m = m0 + wm * TM + j * 16 + a15;
         if (m >= p.M) continue;
-        float rb = 0.f;
-        if (p.bias_mode == GP_BIAS_ROW) rb = bias[m];
+        const float rb = p.bias_mode == GP_BIAS_ROW ? bias[m] : 0.f;
 #pragma unroll
-        for (int i = 0; i < FN; i += 1) {
-            const int nb = n0 + wn * TN + i * 16;
-            float v[4];
-            int col;
+        for (int ip = 0; ip < FP; ++ip) {
+            const int cb = n0 + wn * TN + 32 * ip;  // first packed column of this fragment pair
             if (geglu) {
-                if (i & 1) continue;
-                col = (nb >> 1) + q4;
+                // packed rows of a 32-block: 8q + r = value, 8q + 4 + r = gate of output column cb/2 + 4q + r
+                const int col = (cb >> 1) + (q8 >> 1);
+                if (col >= p.n_store) continue;
+                float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float a = acc[i][j][r], g = acc[i + 1][j][r];
-                    if (p.bias_mode == GP_BIAS_COL && nb + q4 + r < p.N) { a += bias[nb + q4 + r]; g += bias[nb + 16 + q4 + r]; }
+                    const float a = acc[2 * ip][j][r] + bcol[ip][r], g = acc[2 * ip + 1][j][r] + bcol[ip][4 + r];
                     v[r] = a * gelu_erf_f(g);
+                    if (col + r >= n_out) v[r] = 0.f;
                 }
-            } else {
-                col = nb + q4;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float a = acc[i][j][r] + rb;
-                    if (p.bias_mode == GP_BIAS_COL && col + r < p.N) a += bias[col + r];
-                    v[r] = a;
-                }
-            }
-            if (col >= p.n_store) continue;
-            if (res) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (col + r < n_out) v[r] += bf2f(res[(long long)m * p.ldres + col + r]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (p.act == GP_ACT_SILU) v[r] = silu_f(v[r]);
-                else if (p.act == GP_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
-                if (col + r >= n_out) v[r] = 0.f;
-            }
-            if (p.out_fp32) {
-                float* o = (float*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
-                if (col + 3 < p.n_store && (p.ldo & 3) == 0) {
-                    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (col + r < p.n_store) o[r] = v[r];
-                }
-            } else {
                 bf16_t* o = (bf16_t*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
                 if (col + 3 < p.n_store && (p.ldo & 3) == 0) {
                     *(uint2*)o = pack_bf16x4(v[0], v[1], v[2], v[3]);
@@ -235,26 +261,77 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
                     for (int r = 0; r < 4; ++r)
                         if (col + r < p.n_store) o[r] = f2bf(v[r]);
                 }
+                continue;
+            }
+            const int col = cb + q8;
+            if (col >= p.n_store) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[2 * ip + (e >> 2)][j][e & 3] + bcol[ip][e] + rb;
+            const bool full = col + 7 < p.n_store && vec_ok;
+            if (res) {
+                const bf16_t* rp = res + (long long)m * p.ldres + col;
+                if (full && (p.ldres & 7) == 0 && col + 7 < n_out) {
+                    const uint4 rv = *(const uint4*)rp;
+                    v[0] += bflo(rv.x); v[1] += bfhi(rv.x); v[2] += bflo(rv.y); v[3] += bfhi(rv.y);
+                    v[4] += bflo(rv.z); v[5] += bfhi(rv.z); v[6] += bflo(rv.w); v[7] += bfhi(rv.w);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (col + e < n_out) v[e] += bf2f(rp[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (p.act == GP_ACT_SILU) v[e] = silu_f(v[e]);
+                else if (p.act == GP_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                if (col + e >= n_out) v[e] = 0.f;
+            }
+            if (p.out_fp32) {
+                float* o = (float*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
+                if (col + 7 < p.n_store && (p.ldo & 3) == 0) {
+                    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (col + e < p.n_store) o[e] = v[e];
+                }
+            } else {
+                bf16_t* o = (bf16_t*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
+                if (full) {
+                    uint4 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+                    *(uint4*)o = pk;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (col + e < p.n_store) o[e] = f2bf(v[e]);
+                }
             }
         }
     }
+}
+
+template <int BM, int BN, int WM, int WN, int KS, int NSTAGE>
+static void launch_one(const IGemmParams& p, dim3 grid, hipStream_t s) {
+    constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, KS, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, KS, NSTAGE>), grid, dim3(64 * WM * WN), lds, s, p);
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 static void launch_cfg(const IGemmParams& p, hipStream_t s) {
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
     const int tiles = ((p.M + BM - 1) / BM) * ((ncols + BN - 1) / BN);
-    const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
-    dim3 grid(tiles, p.batch > 0 ? p.batch : 1), block(64 * WM * WN);
-    if (p.ks == 3) {
-        static bool attr3 = false;
-        if (!attr3) { (void)hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, 3, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr3 = true; }
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 3, NSTAGE>), grid, block, lds, s, p);
-    } else {
-        static bool attr1 = false;
-        if (!attr1) { (void)hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, 1, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, NSTAGE>), grid, block, lds, s, p);
-    }
+    dim3 grid(tiles, p.batch > 0 ? p.batch : 1);
+    if (p.ks == 3 && p.ups) launch_one<BM, BN, WM, WN, 4, NSTAGE>(p, grid, s);
+    else if (p.ks == 3) launch_one<BM, BN, WM, WN, 3, NSTAGE>(p, grid, s);
+    else launch_one<BM, BN, WM, WN, 1, NSTAGE>(p, grid, s);
 }
 
 // tile_hint: 0 auto, 1 = 128x128 (4 waves, 2-deep), 2 = 64x64 (4 waves, 3-deep), 3 = 256x32 (4 waves, 2-deep),

@@ -31,6 +31,7 @@ struct IGemmParams {
     int n_store;          // columns written (>= N_out; columns in [N_out, n_store) are written as 0)
     int out_fp32;         // 1: fp32 output
     int act, bias_mode;
+    int dbg;              // ablation bits for profiling only (1: no DMA in the loop, 2: no MFMA work, 4: no waits/barriers)
     int batch;            // grid.y batches with the strides below (elements)
     long long in_bs, wt_bs, out_bs, res_bs, bias_bs;
 };

@@ -188,11 +188,11 @@ def test_gemm_geglu(metric_log):
     ref = hidden * F.gelu(gate)
     d = _dev()
     wp = e.pack_weight(w, geglu=True, device=d)
-    # GEGLU-permuted bias: 16-row blocks alternate value / gate
+    # GEGLU-permuted bias (same row permutation as gp_pack_weight(geglu=1)): per 32-row block, value j at 8*(j%16//4) + j%4, gate +4
     half = 4 * c
     idx = torch.arange(8 * c)
     r = torch.where(idx >= half, idx - half, idx)
-    dst = (r // 16) * 32 + (idx >= half).long() * 16 + (r % 16)
+    dst = (r // 16) * 32 + ((r % 16) // 4) * 8 + (idx >= half).long() * 4 + (r % 4)
     pb = torch.empty_like(bias)
     pb[dst] = bias
     y = e.conv2d(a.to(d).to(torch.bfloat16).reshape(1, 1, m, c), wp, pb.to(d), 8 * c, 1, act="geglu")

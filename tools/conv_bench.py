@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the implicit-GEMM conv/linear kernel on the shapes of the 768x768 path (through the C-ABI).
+Usage: python tools/conv_bench.py [--iters 10] [--shapes vae128,vae256,...] [--tiles 0,1,4]
+Prints one line per (shape, tile config): time, TFLOP/s."""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from genpercept_amd import engine as e  # noqa: E402
+
+SHAPES = {
+    # name: (B, H, W, Cin, Cout, ks)
+    "vae128": (4, 768, 768, 128, 128, 3),
+    "vae256": (4, 384, 384, 256, 256, 3),
+    "vae512": (4, 192, 192, 512, 512, 3),
+    "vae512_96": (4, 96, 96, 512, 512, 3),
+    "unet320": (4, 96, 96, 320, 320, 3),
+    "unet640": (4, 48, 48, 640, 640, 3),
+    "unet1280_24": (4, 24, 24, 1280, 1280, 3),
+    "unet1280_12": (4, 12, 12, 1280, 1280, 3),
+    "unet2560_12": (4, 12, 12, 2560, 1280, 3),
+    "lin320": (4, 96, 96, 320, 320, 1),
+    "ff320": (4, 96, 96, 320, 2560, 1),
+    "ff1280": (4, 96, 96, 1280, 320, 1),
+    "lin1280_24": (4, 24, 24, 1280, 1280, 1),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--shapes", default=",".join(SHAPES))
+    ap.add_argument("--tiles", default="0")
+    ap.add_argument("--dbg", default="0", help="comma list of GENPERCEPT_IGEMM_DBG ablation values")
+    args = ap.parse_args()
+    d = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(0)
+    for name in args.shapes.split(","):
+        b, h, w, cin, cout, ks = SHAPES[name]
+        x = torch.randn(b, h, w, cin, generator=g).to(torch.bfloat16).to(d)
+        wt = torch.randn(cout, cin, ks, ks, generator=g) / math.sqrt(cin * ks * ks)
+        wp = e.pack_weight(wt, device=d)
+        bias = torch.randn(cout, generator=g).to(d)
+        flops = 2.0 * b * h * w * cout * cin * ks * ks
+        for tile, dbg in [(int(t), dv) for t in args.tiles.split(",") for dv in args.dbg.split(",")]:
+            os.environ["GENPERCEPT_IGEMM_DBG"] = dbg
+            y = e.conv2d(x, wp, bias, cout, ks, tile=tile)
+            torch.cuda.synchronize()
+            st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st.record()
+            for _ in range(args.iters):
+                y = e.conv2d(x, wp, bias, cout, ks, tile=tile)
+            en.record()
+            torch.cuda.synchronize()
+            ms = st.elapsed_time(en) / args.iters
+            print(f"{name:14s} tile={tile} dbg={dbg} M={b*h*w:8d} N={cout:5d} K={cin*ks*ks:6d}  {ms*1e3:9.1f} us  {flops/ms/1e9:8.1f} TFLOP/s", flush=True)
+        del x, wp, y
+
+
+if __name__ == "__main__":
+    main()
