@@ -18,6 +18,7 @@
 //    a lane ends up with 8 consecutive output channels of one pixel: bias is two float4 loaded before the K loop, the
 //    bf16 store is 16 bytes per lane, the residual one 16-byte load.
 #include "common.h"
+#include "epilogue.h"
 #include "kernels.h"
 
 template <int N>
@@ -177,39 +178,20 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
         }
     };
 
-    // ---- prologue: fill NSTAGE-1 ring slots, then fetch this lane's bias values while the DMA is in flight ------------
+    // ---- prologue: this lane's bias values, then fill NSTAGE-1 ring slots ---------------------------------------------------
+    // (bias first: an ordinary load issued while LDS-DMA is in flight makes hipcc drain vmcnt to 0 at its first use)
+    float bcol[FP][8];
+    load_bias_cols<FP>(p, z, n0 + wn * TN, 8 * (lane >> 4), bcol);
 #pragma unroll
     for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
-        if (s0 < nk) stage(s0);
-
-    const bool geglu = p.act == GP_ACT_GEGLU;
-    const float* bias = p.bias ? p.bias + (long long)z * p.bias_bs : nullptr;
-    const int q8 = 8 * (lane >> 4);
-    float bcol[FP][8];
-#pragma unroll
-    for (int ip = 0; ip < FP; ++ip) {
-        const int c0 = n0 + wn * TN + 32 * ip + q8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bcol[ip][e] = 0.f;
-        if (p.bias_mode == GP_BIAS_COL) {
-            if (c0 + 7 < p.N) {
-                const float4 b0 = *(const float4*)(bias + c0), b1 = *(const float4*)(bias + c0 + 4);
-                bcol[ip][0] = b0.x; bcol[ip][1] = b0.y; bcol[ip][2] = b0.z; bcol[ip][3] = b0.w;
-                bcol[ip][4] = b1.x; bcol[ip][5] = b1.y; bcol[ip][6] = b1.z; bcol[ip][7] = b1.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (c0 + e < p.N) bcol[ip][e] = bias[c0 + e];
-            }
-        }
-    }
+        if (s0 < nk && !(p.dbg & 32)) stage(s0);
 
     // ---- main loop -------------------------------------------------------------------------------------------------------
     // Per step: counted vmcnt (this wave's DMAs of step kt have landed) -> raw s_barrier (everybody's have, and everybody
     // is done reading the slot about to be refilled) -> {MFMAs of step kt, DMA of step kt+NSTAGE-1} in role-dependent order.
     // __syncthreads() would drain vmcnt to 0 and serialise the ring (cdna guide, "Pipelining across barriers").
     int cur = 0, nxt = NSTAGE - 1;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < ((p.dbg & 8) ? 0 : nk); ++kt) {
         const int ahead = min(NSTAGE - 2, nk - 1 - kt);  // stages issued after step kt's
         if (!(p.dbg & 4)) {
             if (ahead >= 2) wait_vm_n<2 * LPS>();
@@ -219,98 +201,19 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
         }
         const bool do_stage = kt + NSTAGE - 1 < nk && !(p.dbg & 1);
         const bool do_comp = !(p.dbg & 2);
-        if (second_half) {
-            if (do_stage) stage(nxt);
-            if (do_comp) compute(cur);
-        } else {
-            if (do_comp) compute(cur);
-            if (do_stage) stage(nxt);
-        }
+        if (second_half && do_stage) stage(nxt);   // one compute() site: two would make the compiler shuffle all accumulators
+        if (do_comp) compute(cur);
+        if (!second_half && do_stage) stage(nxt);
         cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
         nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
     }
 
-    // ---- epilogue ------------------------------------------------------------------------------------------------------
-    const int n_out = geglu ? (p.N >> 1) : p.N;
-    const bf16_t* res = p.res ? p.res + (long long)z * p.res_bs : nullptr;
-    const bool vec_ok = (p.ldo & 7) == 0;
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-        const int m = m0 + wm * TM + j * 16 + a15;
-        if (m >= p.M) continue;
-        const float rb = p.bias_mode == GP_BIAS_ROW ? bias[m] : 0.f;
-#pragma unroll
-        for (int ip = 0; ip < FP; ++ip) {
-            const int cb = n0 + wn * TN + 32 * ip;  // first packed column of this fragment pair
-            if (geglu) {
-                // packed rows of a 32-block: 8q + r = value, 8q + 4 + r = gate of output column cb/2 + 4q + r
-                const int col = (cb >> 1) + (q8 >> 1);
-                if (col >= p.n_store) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float a = acc[2 * ip][j][r] + bcol[ip][r], g = acc[2 * ip + 1][j][r] + bcol[ip][4 + r];
-                    v[r] = a * gelu_erf_f(g);
-                    if (col + r >= n_out) v[r] = 0.f;
-                }
-                bf16_t* o = (bf16_t*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
-                if (col + 3 < p.n_store && (p.ldo & 3) == 0) {
-                    *(uint2*)o = pack_bf16x4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (col + r < p.n_store) o[r] = f2bf(v[r]);
-                }
-                continue;
-            }
-            const int col = cb + q8;
-            if (col >= p.n_store) continue;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = acc[2 * ip + (e >> 2)][j][e & 3] + bcol[ip][e] + rb;
-            const bool full = col + 7 < p.n_store && vec_ok;
-            if (res) {
-                const bf16_t* rp = res + (long long)m * p.ldres + col;
-                if (full && (p.ldres & 7) == 0 && col + 7 < n_out) {
-                    const uint4 rv = *(const uint4*)rp;
-                    v[0] += bflo(rv.x); v[1] += bfhi(rv.x); v[2] += bflo(rv.y); v[3] += bfhi(rv.y);
-                    v[4] += bflo(rv.z); v[5] += bfhi(rv.z); v[6] += bflo(rv.w); v[7] += bfhi(rv.w);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (col + e < n_out) v[e] += bf2f(rp[e]);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (p.act == GP_ACT_SILU) v[e] = silu_f(v[e]);
-                else if (p.act == GP_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
-                if (col + e >= n_out) v[e] = 0.f;
-            }
-            if (p.out_fp32) {
-                float* o = (float*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
-                if (col + 7 < p.n_store && (p.ldo & 3) == 0) {
-                    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-                    *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (col + e < p.n_store) o[e] = v[e];
-                }
-            } else {
-                bf16_t* o = (bf16_t*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
-                if (full) {
-                    uint4 pk;
-                    pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
-                    *(uint4*)o = pk;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (col + e < p.n_store) o[e] = f2bf(v[e]);
-                }
-            }
-        }
-    }
+    // ---- epilogue (epilogue.h): LDS-staged, fully coalesced bf16 stores ---------------------------------------------------
+    if ((p.dbg & 16) && m0 >= 0) return;  // ablation: no epilogue
+    conv_epilogue<BM, BN, WM, WN, 64 * NW>(p, acc, bcol, n0, z, wave, lane, smem, [&](int pr) {
+        const int m = m0 + pr;
+        return m < p.M ? m : -1;
+    });
 }
 
 template <int BM, int BN, int WM, int WN, int KS, int NSTAGE>
@@ -338,6 +241,15 @@ static void launch_cfg(const IGemmParams& p, hipStream_t s) {
 //            4 = 256x128 (8 waves, 3-deep ring: the large-problem configuration)
 void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s) {
     int cfg = tile_hint;
+    if (cfg == 5 || (cfg == 0 && conv_halo_applicable(p))) {
+        const int ncols = p.N > p.n_store ? p.N : p.n_store;
+        const long long tiles = (long long)((p.Wo + 15) / 16) * ((p.Ho + 15) / 16) * p.B * ((ncols + 127) / 128);
+        if (conv_halo_applicable(p) && (cfg == 5 || (tiles >= 160 && ncols > 32))) {
+            launch_conv_halo(p, s);
+            return;
+        }
+        cfg = 0;
+    }
     if (cfg == 0) {
         const int ncols = p.N > p.n_store ? p.N : p.n_store;
         const long long nb = p.batch > 0 ? p.batch : 1;

@@ -36,7 +36,10 @@ struct IGemmParams {
     long long in_bs, wt_bs, out_bs, res_bs, bias_bs;
 };
 
-void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s);  // tile_hint: 0 auto, 1 = 128x128, 2 = 64x64, 3 = 256x32
+void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s);
+// conv_halo.hip: 3x3 stride-1 convs on large maps (16x16-pixel tiles, input halo staged once per channel chunk); tile_hint 5
+bool conv_halo_applicable(const IGemmParams& p);
+void launch_conv_halo(const IGemmParams& p, hipStream_t s);  // tile_hint: 0 auto, 1 = 128x128, 2 = 64x64, 3 = 256x32
 
 // GroupNorm over NHWC bf16 (fp32 statistics), optional fused SiLU.  ws: >= B*nchunk*G*2 floats.
 void launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps,

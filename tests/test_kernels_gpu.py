@@ -77,6 +77,35 @@ def test_conv3x3_s1(case, metric_log):
     check(f"conv3x3_s1{case}", nhwc_to_nchw(y), ref, metric_log)
 
 
+HALO_CASES = [
+    # B, H, W, Cin, Cout, ups, act, residual
+    (1, 16, 16, 64, 128, False, "none", False), (2, 32, 48, 128, 128, False, "none", True), (1, 40, 36, 256, 320, False, "none", True),
+    (1, 17, 23, 64, 64, False, "relu", False), (3, 16, 20, 192, 200, False, "silu", True), (1, 96, 96, 128, 128, False, "none", False),
+    (1, 8, 8, 128, 128, True, "none", False), (2, 12, 10, 64, 256, True, "none", False), (1, 24, 24, 320, 320, True, "relu", False),
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv3x3_halo_kernel(case, metric_log):
+    """conv_halo.hip (tile hint 5): 16x16-pixel tiles with the input halo staged once per channel chunk; also x2-upsample form."""
+    e = _eng()
+    b, h, w, cin, cout, ups, act, with_res = case
+    g = torch.Generator().manual_seed(sum(int(v) for v in case[:5]))
+    x = rbf(torch.randn(b, cin, h, w, generator=g))
+    wt = rbf(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
+    bias = torch.randn(cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    ref = F.conv2d(xin, wt, bias, padding=1)
+    res = rbf(torch.randn(ref.shape, generator=g)) if with_res else None
+    if with_res:
+        ref = ref + res
+    ref = {"none": lambda t: t, "relu": F.relu, "silu": F.silu}[act](ref)
+    d = _dev()
+    y = e.conv2d(e.to_nhwc_bf16(x.to(d)), e.pack_weight(wt, device=d), bias.to(d), cout, 3, ups_hw=(2 * h, 2 * w) if ups else None,
+                 residual=e.to_nhwc_bf16(res.to(d)) if with_res else None, act=act, tile=5)
+    check(f"conv_halo{case}", nhwc_to_nchw(y), ref, metric_log)
+
+
 def test_conv_small_cin_padded(metric_log):
     """conv_in-style layers: 3 (or 4) real input channels zero-padded to 64; small Cout zero-padded on store."""
     e = _eng()
