@@ -15,8 +15,12 @@
 #include "epilogue.h"
 #include "kernels.h"
 
+constexpr bool PRIO = true;   // s_setprio around the MFMA cluster made hipcc wait lgkmcnt(0) before the first MFMA
 template <int N>
 GP_DEV void halo_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+constexpr int HALO_LDS = 147456;   // 2 x 48 KiB halo + 3 x 16 KiB weights (>= the 128 KiB epilogue staging, also in the x2 case)
+constexpr int GN_MAXC = 2048;      // fused input transform: per-channel scale/shift of one image live in the last 16 KiB of LDS
 
 template <bool UPS>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IGemmParams p) {
@@ -30,6 +34,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IGemmParams p) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const a_lds = smem;
     char* const b_lds = smem + 2 * A_BUF;
+    float* const s_gn = (float*)(smem + HALO_LDS);      // [GN_MAXC] scale, [GN_MAXC] shift of this image (fused GroupNorm apply)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -78,6 +83,51 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IGemmParams p) 
         w_ptr[i] = p.wt + (long long)n * p.ldw + chunk_w * 8;
     }
 
+    // ---- fused input transform x -> act(x * scale[b][c] + shift[b][c]) applied to the staged halo (GroupNorm apply + SiLU) ----
+    // Padding pixels must stay exactly 0 (the reference pads the NORMALISED tensor), hence the per-item validity mask.
+    constexpr int T_IT = (HROWS * 8 + 511) / 512;      // 16-byte items per thread per halo
+    const bool fused = p.in_scale != nullptr;
+    unsigned t_ok = 0;
+    if (fused) {
+        for (int c = tid; c < Cin; c += 512) {
+            s_gn[c] = p.in_scale[(long long)b * Cin + c];
+            s_gn[GN_MAXC + c] = p.in_shift[(long long)b * Cin + c];
+        }
+#pragma unroll
+        for (int k = 0; k < T_IT; ++k) {
+            const int r = (tid + 512 * k) >> 3;
+            const int hy = r / HW_, hx = r - hy * HW_;
+            if (r < HROWS && (unsigned)(sy0 + hy) < (unsigned)Hi && (unsigned)(sx0 + hx) < (unsigned)Wi) t_ok |= 1u << k;
+        }
+        __syncthreads();  // before any LDS-DMA is in flight: a later __syncthreads would drain the DMA ring
+    }
+    auto transform = [&](int cc) {
+        char* buf = a_lds + (cc & 1) * A_BUF;
+        const float* sc = s_gn + (cc << 6);
+        const float* sh = s_gn + GN_MAXC + (cc << 6);
+#pragma unroll
+        for (int k = 0; k < T_IT; ++k) {
+            if (!((t_ok >> k) & 1u)) continue;
+            const int item = tid + 512 * k, r = item >> 3;
+            const int ls = ((item & 7) ^ ((r >> 1) & 7)) << 3;  // first channel (within the chunk) of this 16-byte slot
+            uint4* ptr = (uint4*)(buf + item * 16);
+            const uint4 raw = *ptr;
+            const float4 s0 = *(const float4*)(sc + ls), s1 = *(const float4*)(sc + ls + 4);
+            const float4 h0 = *(const float4*)(sh + ls), h1 = *(const float4*)(sh + ls + 4);
+            float v[8] = {bflo(raw.x) * s0.x + h0.x, bfhi(raw.x) * s0.y + h0.y, bflo(raw.y) * s0.z + h0.z, bfhi(raw.y) * s0.w + h0.w,
+                          bflo(raw.z) * s1.x + h1.x, bfhi(raw.z) * s1.y + h1.y, bflo(raw.w) * s1.z + h1.z, bfhi(raw.w) * s1.w + h1.w};
+            if (p.in_silu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+            }
+            uint4 o;
+            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+            *ptr = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my LDS writes are done ...
+        __builtin_amdgcn_s_barrier();                        // ... and so are everybody else's (raw: must not drain vmcnt)
+    };
+
     auto stage_halo = [&](int cc) {
         char* dst = a_lds + (cc & 1) * A_BUF;
 #pragma unroll
@@ -114,20 +164,24 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IGemmParams p) 
             if (UPS) row[j] = (((py + ky - 1) >> 1) + 1) * HW_ + (((a15 + kx - 1) >> 1) + 1);
             else row[j] = (py + ky) * HW_ + a15 + kx;
         }
+        bf16x8_t wf[2][FN], xf[2][FM];  // all 16 fragment reads first: the second k-half's LDS latency hides under the first half's MFMAs
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int sl = kk * 4 + (lane >> 4);
             const int so_w = (sl ^ xr_w) << 4;
-            bf16x8_t wf[FN], xf[FM];
 #pragma unroll
-            for (int i = 0; i < FN; ++i) wf[i] = *(const bf16x8_t*)(wb + w_row_off + (i >> 1) * 4096 + (i & 1) * 512 + so_w);
+            for (int i = 0; i < FN; ++i) wf[kk][i] = *(const bf16x8_t*)(wb + w_row_off + (i >> 1) * 4096 + (i & 1) * 512 + so_w);
 #pragma unroll
-            for (int j = 0; j < FM; ++j) xf[j] = *(const bf16x8_t*)(ab + row[j] * 128 + ((sl ^ ((row[j] >> 1) & 7)) << 4));
+            for (int j = 0; j < FM; ++j) xf[kk][j] = *(const bf16x8_t*)(ab + row[j] * 128 + ((sl ^ ((row[j] >> 1) & 7)) << 4));
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < FN; ++i)
 #pragma unroll
-                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        }
+                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- prologue: bias, halo of chunk 0, weight tiles of steps 0 and 1 ---------------------------------------
@@ -154,6 +208,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IGemmParams p) 
             if (issue_w) stage_w(slot2, t2, c2);
             if (issue_h) stage_halo(cc + 1);
         }
+        if (fused && tap == 0) transform(cc);
         compute(slot, cc, ky, kx);
         if (!second_half) {
             if (issue_w) stage_w(slot2, t2, c2);
@@ -176,6 +231,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IGemmParams p) 
 bool conv_halo_applicable(const IGemmParams& p) {
     if (p.ks != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.batch > 1 || p.out_fp32 || p.act == GP_ACT_GEGLU) return false;
     if (p.bias_mode == GP_BIAS_ROW || (p.ldo & 7)) return false;
+    if (p.in_scale && p.Cin > GN_MAXC) return false;
     if (p.ups) {
         if (p.Hu != 2 * p.Hi || p.Wu != 2 * p.Wi || p.Ho != p.Hu || p.Wo != p.Wu) return false;
     } else if (p.Ho != p.Hi || p.Wo != p.Wi) return false;
@@ -185,7 +241,7 @@ bool conv_halo_applicable(const IGemmParams& p) {
 void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
     const int tiles = ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16) * p.B * ((ncols + 127) / 128);
-    constexpr int LDS = 147456;  // 2 x 48 KiB halo + 3 x 16 KiB weights; also >= the 128 KiB epilogue staging in the x2 case
+    constexpr int LDS = HALO_LDS + 2 * GN_MAXC * (int)sizeof(float);  // 160 KiB: the whole LDS of a CU
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

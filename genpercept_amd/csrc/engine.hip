@@ -143,6 +143,7 @@ struct gp_engine {
     float* gn_ws = nullptr;
     size_t gn_ws_floats = 0;
     float* mm_ws = nullptr;
+    bool fuse_gn = true;   // GENPERCEPT_NO_GN_FUSION=1 keeps the separate apply pass (A/B measurements)
 
     std::unordered_map<std::string, PackedW> convs;
     std::unordered_map<std::string, NormW> norms;
@@ -363,6 +364,7 @@ struct gp_engine {
     void finalize() {
         if (finalized) throw std::logic_error("gp_finalize called twice");
         HIPCHK(hipSetDevice(cfg.device));
+        fuse_gn = getenv("GENPERCEPT_NO_GN_FUSION") == nullptr;
         {
             std::vector<bf16_t> z(2048, 0);
             zero = upload(z.data(), z.size());
@@ -524,14 +526,13 @@ struct gp_engine {
         int act = GP_ACT_NONE;
         int n_store = 0;        // 0: cout
     };
-    Act conv(const Act& x, const PackedW& w, const ConvOpt& o) {
+    IGemmParams conv_params(const Act& x, const PackedW& w, const ConvOpt& o, bf16_t* out) {
         if (x.C != w.cin_pad) throw std::logic_error("conv: channel mismatch (" + std::to_string(x.C) + " vs " + std::to_string(w.cin_pad) + ")");
         const int Hin = o.ups_h ? o.ups_h : x.H, Win = o.ups_w ? o.ups_w : x.W;
         const int Ho = o.Ho ? o.Ho : Hin, Wo = o.Wo ? o.Wo : Win;
         const int nst = o.n_store ? o.n_store : w.cout;
-        Act y = new_act(x.B, Ho, Wo, nst);
         IGemmParams p{};
-        p.in = x.p; p.wt = w.w; p.bias = w.bias; p.res = o.res; p.out = y.p; p.zero = zero;
+        p.in = x.p; p.wt = w.w; p.bias = w.bias; p.res = o.res; p.out = out; p.zero = zero;
         p.M = x.B * Ho * Wo; p.N = w.cout; p.Cin = w.cin_pad; p.n_rows = w.n_rows; p.ks = w.ks;
         p.B = x.B; p.Hi = x.H; p.Wi = x.W; p.Ho = Ho; p.Wo = Wo;
         p.stride = o.stride; p.pad_t = w.ks == 3 ? o.pad_t : 0; p.pad_l = w.ks == 3 ? o.pad_l : 0;
@@ -539,6 +540,14 @@ struct gp_engine {
         p.lda = x.C; p.ldo = nst; p.ldres = nst; p.ldw = (w.ks == 3 ? 9 : 1) * w.cin_pad;
         p.n_store = nst; p.out_fp32 = 0; p.act = o.act; p.bias_mode = w.bias ? GP_BIAS_COL : GP_BIAS_NONE;
         p.batch = 1;
+        return p;
+    }
+    Act conv(const Act& x, const PackedW& w, const ConvOpt& o, const float* in_scale = nullptr, const float* in_shift = nullptr, bool in_silu = false) {
+        IGemmParams p = conv_params(x, w, o, nullptr);
+        Act y = new_act(x.B, p.Ho, p.Wo, p.n_store);
+        p.out = y.p;
+        p.in_scale = in_scale; p.in_shift = in_shift; p.in_silu = in_silu ? 1 : 0;
+        if (in_scale && !conv_uses_halo(p, 0)) throw std::logic_error("fused GroupNorm input needs the halo conv kernel");
         run_igemm(p);
         return y;
     }
@@ -573,16 +582,39 @@ struct gp_engine {
     }
     Act groupnorm(const Act& x, const NormW& n, float eps, bool silu) {
         if (x.C != n.C) throw std::logic_error("groupnorm: channel mismatch");
-        const size_t need = (size_t)groupnorm_ws_floats(x.B, x.H * x.W, x.C, cfg.norm_groups);
+        float* ws = gn_workspace(x);
+        Act y = new_act(x.B, x.H, x.W, x.C);
+        launch_groupnorm(x.p, y.p, n.g, n.b, x.B, x.H * x.W, x.C, cfg.norm_groups, eps, silu ? 1 : 0, ws, st);
+        tm.n_launches += 3;
+        return y;
+    }
+    float* gn_workspace(const Act& x) {  // partial statistics + per-(image, channel) scale / shift
+        const size_t need = (size_t)groupnorm_ws_floats(x.B, x.H * x.W, x.C, cfg.norm_groups) + 2 * (size_t)x.B * x.C;
         if (need > gn_ws_floats) {
             if (gn_ws) pool.release(gn_ws);
             gn_ws = (float*)pool.alloc(need * 4 * 2);
             gn_ws_floats = need * 2;
         }
-        Act y = new_act(x.B, x.H, x.W, x.C);
-        launch_groupnorm(x.p, y.p, n.g, n.b, x.B, x.H * x.W, x.C, cfg.norm_groups, eps, silu ? 1 : 0, gn_ws, st);
+        return gn_ws;
+    }
+    // conv(act(GroupNorm(x))): statistics pass, then the normalisation is applied either inside the conv kernel on the staged
+    // input halo (conv_halo.hip) or, when that kernel does not take the layer, by the separate apply pass.
+    Act conv_gn(const Act& x, const NormW& n, float eps, bool silu, const PackedW& w, const ConvOpt& o) {
+        if (x.C != n.C) throw std::logic_error("groupnorm: channel mismatch");
+        float* ws = gn_workspace(x);
+        float* scale = ws + groupnorm_ws_floats(x.B, x.H * x.W, x.C, cfg.norm_groups);
+        float* shift = scale + (size_t)x.B * x.C;
+        launch_groupnorm_stats(x.p, n.g, n.b, x.B, x.H * x.W, x.C, cfg.norm_groups, eps, ws, scale, shift, st);
         tm.n_launches += 2;
-        return y;
+        IGemmParams p = conv_params(x, w, o, nullptr);
+        p.in_scale = scale; p.in_shift = shift; p.in_silu = silu ? 1 : 0;
+        if (fuse_gn && conv_uses_halo(p, 0)) return conv(x, w, o, scale, shift, silu);
+        Act y = new_act(x.B, x.H, x.W, x.C);
+        launch_groupnorm_apply(x.p, y.p, scale, shift, x.B, x.H * x.W, x.C, silu ? 1 : 0, st);
+        tm.n_launches++;
+        Act out = conv(y, w, o);
+        drop(y);
+        return out;
     }
     Act layernorm(const Act& x, const NormW& n) {
         Act y = new_act(x.B, x.H, x.W, x.C);
@@ -593,17 +625,13 @@ struct gp_engine {
 
     Act resnet(const Act& x, const std::string& name, float eps) {
         const ResW& r = resnets.at(name);
-        Act n1 = groupnorm(x, r.n1, eps, true);
-        Act h = conv(n1, r.c1, ConvOpt{});
-        drop(n1);
-        Act n2 = groupnorm(h, r.n2, eps, true);
-        drop(h);
+        Act h = conv_gn(x, r.n1, eps, true, r.c1, ConvOpt{});
         Act sc = x;
         if (r.has_sc) sc = linear(x, r.sc);
         ConvOpt o;
         o.res = sc.p;
-        Act y = conv(n2, r.c2, o);
-        drop(n2);
+        Act y = conv_gn(h, r.n2, eps, true, r.c2, o);
+        drop(h);
         if (r.has_sc) drop(sc);
         return y;
     }
@@ -1234,6 +1262,35 @@ gp_status gp_conv2d(const void* in, const void* w_packed, const float* bias, con
     } catch (...) { return GP_ERR_HIP; }
 }
 
+gp_status gp_conv2d_gn(const void* in, const void* w_packed, const float* bias, const void* residual, void* out, int B, int H, int W, int Cin,
+                       int Cout, int ups, int act, const float* gamma, const float* beta, int groups, float eps, int silu, void* stream) {
+    if (!in || !w_packed || !out || !gamma || !beta || (Cin % 64) || (Cin % groups)) return GP_ERR_INVALID;
+    try {
+        const int Ho = ups ? 2 * H : H, Wo = ups ? 2 * W : W;
+        IGemmParams p{};
+        p.in = (const bf16_t*)in; p.wt = (const bf16_t*)w_packed; p.bias = bias; p.res = (const bf16_t*)residual; p.out = out; p.zero = zero_page();
+        p.M = B * Ho * Wo; p.N = Cout; p.Cin = Cin; p.n_rows = gp_packed_rows(Cout); p.ks = 3;
+        p.B = B; p.Hi = H; p.Wi = W; p.Ho = Ho; p.Wo = Wo; p.stride = 1; p.pad_t = 1; p.pad_l = 1;
+        p.ups = ups ? 1 : 0; p.Hu = ups ? Ho : 0; p.Wu = ups ? Wo : 0;
+        p.lda = Cin; p.ldo = Cout; p.ldres = Cout; p.ldw = 9 * Cin; p.n_store = Cout; p.act = act;
+        p.bias_mode = bias ? GP_BIAS_COL : GP_BIAS_NONE; p.batch = 1;
+        const size_t need = (size_t)groupnorm_ws_floats(B, H * W, Cin, groups) + 2 * (size_t)B * Cin;
+        if (need > g_gn_ws_floats) {
+            if (g_gn_ws) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(g_gn_ws)); }
+            HIPCHK(hipMalloc((void**)&g_gn_ws, need * 4));
+            g_gn_ws_floats = need;
+        }
+        float* scale = g_gn_ws + groupnorm_ws_floats(B, H * W, Cin, groups);
+        float* shift = scale + (size_t)B * Cin;
+        launch_groupnorm_stats((const bf16_t*)in, gamma, beta, B, H * W, Cin, groups, eps, g_gn_ws, scale, shift, (hipStream_t)stream);
+        p.in_scale = scale; p.in_shift = shift; p.in_silu = silu;
+        if (!conv_uses_halo(p, 5)) return GP_ERR_INVALID;
+        launch_igemm(p, 5, (hipStream_t)stream);
+        HIPCHK(hipGetLastError());
+        return GP_OK;
+    } catch (...) { return GP_ERR_HIP; }
+}
+
 gp_status gp_gemm(const void* a, int lda, const void* bt, int ldb, const float* bias, int bias_mode, const void* residual, int ldres, void* out,
                   int ldo, int M, int N, int K, int n_rows_bt, int n_store, int act, int out_fp32, int batch, long long a_bs, long long bt_bs,
                   long long out_bs, int tile_hint, void* stream) {
@@ -1253,7 +1310,7 @@ gp_status gp_gemm(const void* a, int lda, const void* bt, int ldb, const float* 
 gp_status gp_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int silu, void* stream) {
     if (!x || !y || !gamma || !beta || (C % 8) || (C % G)) return GP_ERR_INVALID;
     try {
-        const size_t need = (size_t)groupnorm_ws_floats(B, HW, C, G);
+        const size_t need = (size_t)groupnorm_ws_floats(B, HW, C, G) + 2 * (size_t)B * C;
         if (need > g_gn_ws_floats) {
             if (g_gn_ws) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(g_gn_ws)); }
             HIPCHK(hipMalloc((void**)&g_gn_ws, need * 4));

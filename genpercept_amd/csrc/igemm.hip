@@ -21,6 +21,7 @@
 #include "epilogue.h"
 #include "kernels.h"
 
+constexpr bool PRIO = true;   // s_setprio around the MFMA cluster made hipcc wait lgkmcnt(0) before the first MFMA
 template <int N>
 GP_DEV void wait_vm_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -162,20 +163,26 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
     const int w_row_off = A_BYTES + (wn * TN + 8 * (a15 >> 2) + (a15 & 3)) * 128;
     auto compute = [&](int buf) {
         const char* sb = smem + buf * STAGE;
+        // all 2*(FN+FM) fragment reads are issued up front so the LDS latency of the second k-half hides under the first
+        // half's MFMAs (hipcc otherwise emits read-batch / lgkmcnt(0) / MFMA-batch with the latency exposed each time)
+        bf16x8_t wf[2][FN], xf[2][FM];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int sl = kk * 4 + (lane >> 4);
             const int so_a = (sl ^ xr_a) << 4, so_w = (sl ^ xr_w) << 4;
-            bf16x8_t wf[FN], xf[FM];
 #pragma unroll
-            for (int i = 0; i < FN; ++i) wf[i] = *(const bf16x8_t*)(sb + w_row_off + (i >> 1) * 4096 + (i & 1) * 512 + so_w);
+            for (int i = 0; i < FN; ++i) wf[kk][i] = *(const bf16x8_t*)(sb + w_row_off + (i >> 1) * 4096 + (i & 1) * 512 + so_w);
 #pragma unroll
-            for (int j = 0; j < FM; ++j) xf[j] = *(const bf16x8_t*)(sb + a_row_off + j * 2048 + so_a);
+            for (int j = 0; j < FM; ++j) xf[kk][j] = *(const bf16x8_t*)(sb + a_row_off + j * 2048 + so_a);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < FN; ++i)
 #pragma unroll
-                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        }
+                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- prologue: this lane's bias values, then fill NSTAGE-1 ring slots ---------------------------------------------------
@@ -239,17 +246,21 @@ static void launch_cfg(const IGemmParams& p, hipStream_t s) {
 
 // tile_hint: 0 auto, 1 = 128x128 (4 waves, 2-deep), 2 = 64x64 (4 waves, 3-deep), 3 = 256x32 (4 waves, 2-deep),
 //            4 = 256x128 (8 waves, 3-deep ring: the large-problem configuration)
+// true when launch_igemm(p, hint) hands the problem to conv_halo.hip (the only kernel that fuses IGemmParams::in_scale)
+bool conv_uses_halo(const IGemmParams& p, int tile_hint) {
+    if (!(tile_hint == 5 || tile_hint == 0) || !conv_halo_applicable(p)) return false;
+    const int ncols = p.N > p.n_store ? p.N : p.n_store;
+    const long long tiles = (long long)((p.Wo + 15) / 16) * ((p.Ho + 15) / 16) * p.B * ((ncols + 127) / 128);
+    return tile_hint == 5 || (tiles >= 160 && ncols > 32);
+}
+
 void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s) {
     int cfg = tile_hint;
-    if (cfg == 5 || (cfg == 0 && conv_halo_applicable(p))) {
-        const int ncols = p.N > p.n_store ? p.N : p.n_store;
-        const long long tiles = (long long)((p.Wo + 15) / 16) * ((p.Ho + 15) / 16) * p.B * ((ncols + 127) / 128);
-        if (conv_halo_applicable(p) && (cfg == 5 || (tiles >= 160 && ncols > 32))) {
-            launch_conv_halo(p, s);
-            return;
-        }
-        cfg = 0;
+    if (conv_uses_halo(p, cfg)) {
+        launch_conv_halo(p, s);
+        return;
     }
+    if (cfg == 5) cfg = 0;
     if (cfg == 0) {
         const int ncols = p.N > p.n_store ? p.N : p.n_store;
         const long long nb = p.batch > 0 ? p.batch : 1;

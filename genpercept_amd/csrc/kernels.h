@@ -19,6 +19,9 @@ struct IGemmParams {
     const bf16_t* res;    // residual [M][ldres] bf16 or nullptr
     void* out;            // bf16 or fp32 [M][ldo]
     const bf16_t* zero;   // >= 256 bytes of zeros (source for padding / out-of-range rows)
+    const float* in_scale;  // optional fused input transform x -> act(x * in_scale[b][c] + in_shift[b][c]) (GroupNorm apply);
+    const float* in_shift;  //   only honoured by conv_halo.hip (conv_halo_fuses_input())
+    int in_silu;
     int M, N, Cin;        // N = valid output channels (before GEGLU halving)
     int n_rows;           // rows of `wt` that may be read (>= N; rows beyond read the zero page)
     int ks;               // 1 or 3
@@ -38,10 +41,16 @@ struct IGemmParams {
 
 void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s);
 // conv_halo.hip: 3x3 stride-1 convs on large maps (16x16-pixel tiles, input halo staged once per channel chunk); tile_hint 5
-bool conv_halo_applicable(const IGemmParams& p);
-void launch_conv_halo(const IGemmParams& p, hipStream_t s);  // tile_hint: 0 auto, 1 = 128x128, 2 = 64x64, 3 = 256x32
+bool conv_halo_applicable(const IGemmParams& p);   // includes the Cin <= 2048 limit when in_scale is set
+void launch_conv_halo(const IGemmParams& p, hipStream_t s);
+bool conv_uses_halo(const IGemmParams& p, int tile_hint);  // what launch_igemm will do; callers that set in_scale must check it  // tile_hint: 0 auto, 1 = 128x128, 2 = 64x64, 3 = 256x32
 
-// GroupNorm over NHWC bf16 (fp32 statistics), optional fused SiLU.  ws: >= B*nchunk*G*2 floats.
+// GroupNorm over NHWC bf16 (fp32 statistics), optional fused SiLU.  Three passes: partial statistics, per-(image, channel)
+// scale/shift, apply; the apply pass is skipped when the consuming conv fuses it (IGemmParams::in_scale).
+// ws for launch_groupnorm: >= groupnorm_ws_floats() + 2*B*C floats.
+void launch_groupnorm_stats(const bf16_t* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, float* ws,
+                            float* scale, float* shift, hipStream_t s);
+void launch_groupnorm_apply(const bf16_t* x, bf16_t* y, const float* scale, const float* shift, int B, int HW, int C, int silu, hipStream_t s);
 void launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps,
                       int silu, float* ws, hipStream_t s);
 int groupnorm_ws_floats(int B, int HW, int C, int G);

@@ -70,15 +70,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
     }
 }
 
-// ---- pass 2: combine partials (Chan), fold gamma/beta into per-channel scale/shift, apply (+SiLU) ------------------
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, const float* __restrict__ ws, int HW, int C, int G,
-                                                        int nchunk, float eps, int silu) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // [G*2] mean/rstd, then [C] scale, [C] shift
-    float* s_stat = sm;
-    float* s_scale = sm + 2 * G;
-    float* s_shift = s_scale + C;
-    const int b = blockIdx.y, ck = blockIdx.x, tid = threadIdx.x;
+// ---- pass 2: combine partials (Chan) and fold gamma/beta into per-(image, channel) scale/shift -----------------------------
+//   y = x * scale[b][c] + shift[b][c],  scale = rstd_g * gamma_c,  shift = beta_c - mean_g * scale
+// The pair is consumed either by gn_apply_kernel or, fused, by the conv kernel that reads the tensor (conv_halo.hip).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
+                                                           int HW, int C, int G, int nchunk, float eps) {
+    __shared__ float s_stat[2 * 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int cpg = C / G;
     const int per = (HW + nchunk - 1) / nchunk;
     if (tid < G) {
@@ -103,8 +102,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     for (int c = tid; c < C; c += 256) {
         const int g = c / cpg;
         const float sc = s_stat[2 * g + 1] * gamma[c];
-        s_scale[c] = sc;
-        s_shift[c] = beta[c] - s_stat[2 * g] * sc;
+        scale[(long long)b * C + c] = sc;
+        shift[(long long)b * C + c] = beta[c] - s_stat[2 * g] * sc;
+    }
+}
+
+// ---- pass 3 (only when the consumer cannot fuse it): y = act(x * scale + shift) ----------------------------------------------
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int HW, int C, int nchunk, int silu) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [C] scale, [C] shift
+    float* s_scale = sm;
+    float* s_shift = sm + C;
+    const int b = blockIdx.y, ck = blockIdx.x, tid = threadIdx.x;
+    const int per = (HW + nchunk - 1) / nchunk;
+    for (int c = tid; c < C; c += 256) {
+        s_scale[c] = scale[(long long)b * C + c];
+        s_shift[c] = shift[(long long)b * C + c];
     }
     __syncthreads();
     const int nvec = C >> 3;
@@ -132,8 +145,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     }
 }
 
-void launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int silu,
-                      float* ws, hipStream_t s) {
+void launch_groupnorm_stats(const bf16_t* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, float* ws,
+                            float* scale, float* shift, hipStream_t s) {
     const int nchunk = gn_nchunk(HW);
     const int nvec = C / 8;
     const int vpt = (nvec + 255) / 256;           // 1 or 2 (C <= 4096)
@@ -143,8 +156,21 @@ void launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const floa
     dim3 grid(nchunk, B);
     if (vpt == 1) hipLaunchKernelGGL(gn_stats_kernel<1>, grid, dim3(256), lds1, s, x, ws, HW, C, G, nchunk, tpp, PL);
     else hipLaunchKernelGGL(gn_stats_kernel<2>, grid, dim3(256), lds1, s, x, ws, HW, C, G, nchunk, tpp, PL);
-    const size_t lds2 = (size_t)(2 * G + 2 * C) * sizeof(float);
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), lds2, s, x, y, gamma, beta, (const float*)ws, HW, C, G, nchunk, eps, silu);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, (const float*)ws, gamma, beta, scale, shift, HW, C, G, nchunk, eps);
+}
+
+void launch_groupnorm_apply(const bf16_t* x, bf16_t* y, const float* scale, const float* shift, int B, int HW, int C, int silu, hipStream_t s) {
+    const int nchunk = gn_nchunk(HW);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(256), (size_t)2 * C * sizeof(float), s, x, y, scale, shift, HW, C, nchunk, silu);
+}
+
+// ws: >= groupnorm_ws_floats() + 2*B*C floats (partials, then scale, then shift)
+void launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int silu,
+                      float* ws, hipStream_t s) {
+    float* scale = ws + groupnorm_ws_floats(B, HW, C, G);
+    float* shift = scale + (size_t)B * C;
+    launch_groupnorm_stats(x, gamma, beta, B, HW, C, G, eps, ws, scale, shift, s);
+    launch_groupnorm_apply(x, y, scale, shift, B, HW, C, silu, s);
 }
 
 // ---- LayerNorm: one wave per row, row kept in registers (C <= 4096), exact two-pass statistics -------------------

@@ -69,6 +69,7 @@ SYMBOLS = {
     "gp_dpt_out_size": (_i, [_i]),
     "gp_pack_weight": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "gp_conv2d": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 17 + [_vp]),
+    "gp_conv2d_gn": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 7 + [_vp, _vp, _i, _f, _i, _vp]),
     "gp_gemm": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
     "gp_groupnorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "gp_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
@@ -311,6 +312,20 @@ def conv2d(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
                        pad_t if ks == 3 else 0, pad_l if ks == 3 else 0, ho, wo, uh, uw, ACT[act], nst, int(out_fp32), tile, _stream_ptr())
     if st != GP_OK:
         raise RuntimeError(f"gp_conv2d failed ({st})")
+    return out
+
+
+def conv2d_gn(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
+              silu: bool, ups: bool = False, residual=None, act: str = "none") -> torch.Tensor:
+    """conv3x3(act(GroupNorm(x))) with the GroupNorm apply fused into the conv kernel's input staging."""
+    lib = load_library()
+    b, h, w, cin = x_nhwc.shape
+    ho, wo = (2 * h, 2 * w) if ups else (h, w)
+    out = torch.empty((b, ho, wo, cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    st = lib.gp_conv2d_gn(x_nhwc.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), b, h, w, cin, cout, int(ups), ACT[act],
+                          gamma.data_ptr(), beta.data_ptr(), groups, eps, int(silu), _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_conv2d_gn failed ({st})")
     return out
 
 

@@ -110,6 +110,10 @@ gp_status gp_pack_weight(const float* w_oihw_host, int cout, int cin, int ks, in
 gp_status gp_conv2d(const void* in, const void* w_packed, const float* bias, const void* residual, void* out, int B, int Hi, int Wi, int Cin,
                     int Cout, int ks, int stride, int pad_t, int pad_l, int Ho, int Wo, int ups_h, int ups_w, int act, int n_store,
                     int out_fp32, int tile_hint, void* stream);
+/* conv3x3(act(GroupNorm(in))) with the normalisation applied inside the conv kernel (statistics pass + fused apply);
+ * stride 1, pad 1, optional nearest x2 upsample of the normalised input; H, W >= 16 (x2: >= 8). */
+gp_status gp_conv2d_gn(const void* in, const void* w_packed, const float* bias, const void* residual, void* out, int B, int H, int W, int Cin,
+                       int Cout, int ups, int act, const float* gamma, const float* beta, int groups, float eps, int silu, void* stream);
 /* out[M][N] = A[M][K] * Bt[N][K]^T (+bias per column / per row), batched over `batch` with element strides. */
 gp_status gp_gemm(const void* a, int lda, const void* bt, int ldb, const float* bias, int bias_mode, const void* residual, int ldres, void* out,
                   int ldo, int M, int N, int K, int n_rows_bt, int n_store, int act, int out_fp32, int batch, long long a_bs, long long bt_bs,

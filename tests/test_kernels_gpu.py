@@ -106,6 +106,29 @@ def test_conv3x3_halo_kernel(case, metric_log):
     check(f"conv_halo{case}", nhwc_to_nchw(y), ref, metric_log)
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 128, 128, False, True), (1, 40, 24, 320, 192, False, True), (2, 16, 16, 64, 128, False, False),
+                                  (1, 12, 16, 256, 128, True, True), (1, 17, 21, 960, 64, False, True)])
+def test_conv3x3_fused_groupnorm_input(case, metric_log):
+    """GroupNorm apply (+SiLU) fused into the halo conv's input staging; zero padding applies to the NORMALISED tensor."""
+    e = _eng()
+    b, h, w, cin, cout, ups, silu = case
+    g = torch.Generator().manual_seed(cin + h)
+    x = rbf(torch.randn(b, cin, h, w, generator=g) * 1.5 + 0.5)
+    gamma, beta = 1 + 0.2 * torch.randn(cin, generator=g), 0.3 * torch.randn(cin, generator=g)
+    wt = rbf(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
+    bias = torch.randn(cout, generator=g)
+    n = F.group_norm(x, 32, gamma, beta, 1e-6)
+    if silu:
+        n = F.silu(n)
+    n = rbf(n)  # the kernel rounds the normalised value to bf16 before the MFMA, like the unfused path stores it
+    if ups:
+        n = F.interpolate(n, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(n, wt, bias, padding=1)
+    d = _dev()
+    y = e.conv2d_gn(e.to_nhwc_bf16(x.to(d)), e.pack_weight(wt, device=d), bias.to(d), cout, gamma.to(d), beta.to(d), 32, 1e-6, silu, ups=ups)
+    check(f"conv_gn_fused{case}", nhwc_to_nchw(y), ref, metric_log)
+
+
 def test_conv_small_cin_padded(metric_log):
     """conv_in-style layers: 3 (or 4) real input channels zero-padded to 64; small Cout zero-padded on store."""
     e = _eng()
