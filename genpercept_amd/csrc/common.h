@@ -28,7 +28,7 @@ GP_DEV uint2 pack_bf16x4(float a, float b, float c, float d) {
 }
 GP_DEV bf16_t f2bf(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
-GP_DEV float silu_f(float x) { return x / (1.f + __expf(-x)); }
+GP_DEV float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }  // v_exp + v_rcp (1 ulp), no IEEE division sequence
 GP_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
 // Asynchronous 16-byte-per-lane global -> LDS copy (LDS-DMA).  The LDS destination is wave-uniform base + lane*16,

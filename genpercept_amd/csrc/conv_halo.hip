@@ -2,39 +2,55 @@
 // UNet feature maps, where the generic implicit GEMM (igemm.hip) is bound by operand loads: it re-fetches every input
 // pixel once per tap.  Here a workgroup owns a 16x16 OUTPUT-PIXEL tile x 128 output channels and, per 64-channel chunk,
 // stages the 18x18 input halo (10x10 source pixels in the x2-upsample case) in LDS ONCE; the nine taps then read shifted
-// rows of that halo.  Only the weight tiles ([128 cout][64 cin] per tap) stream per K-step, through a 3-deep LDS-DMA ring.
+// rows of that halo.  Only the weight tiles ([128 cout][64 cin] per tap) stream per K-step, through a 4-deep LDS-DMA ring.
 //
-//   LDS: 2 x halo buffer (48 KiB, double-buffered across channel chunks) + 3 x 16 KiB weight ring = 144 KiB, 1 workgroup/CU,
-//        8 waves (4 pixel-rows-of-4 x 2 channel halves), each wave 64 pixels x 64 channels (16 accumulator tiles 16x16).
-//   Per K-step (tap, chunk) and wave: 2 weight DMAs (+ 6 halo DMAs once per chunk), 16 ds_read_b128, 32 MFMAs
-//        (v_mfma_f32_16x16x32_bf16) -- 5.0 KB of operand traffic per MFLOP instead of 11-15 in the generic kernel.
-//   Sync: counted s_waitcnt vmcnt + one raw s_barrier per K-step; waves 4-7 issue their DMA before their MFMAs, waves 0-3
+//   LDS: 2 x 41 KiB halo (double-buffered across channel chunks) + 4 x 16 KiB weight ring + 1 KiB dump + 12 KiB GroupNorm
+//        scale/shift = 158 KiB, 1 workgroup/CU, 8 waves (4 groups of 4 pixel rows x 2 channel halves), each wave 64 pixels x
+//        64 channels = 16 accumulator tiles of v_mfma_f32_16x16x32_bf16.
+//   K-step = (chunk, tap): 2 weight DMAs per wave (+ 6 halo DMAs once per chunk), 16 ds_read_b128, 32 MFMAs.
+//   Software pipeline: the barrier at the top of step s certifies the operands of step s+1, so all 16 fragments of step s+1
+//        are read from LDS while step s's 32 MFMAs issue from registers (ping-pong register sets, loop unrolled by two);
+//        LDS latency never sits between a barrier and an MFMA.
+//   Sync: counted s_waitcnt vmcnt + ONE raw s_barrier per K-step; waves 4-7 issue their DMA before their MFMAs, waves 0-3
 //        after (role split), so each SIMD overlaps one wave's matrix work with its partner's memory work.
+//   Optional fused input transform x -> act(x * scale[b][c] + shift[b][c]) (GroupNorm apply + SiLU) on the staged halo of the
+//        NEXT chunk, one 16-byte item per thread per K-step, hidden under the MFMA steps; padding stays exactly zero.
 //   Epilogue: epilogue.h (LDS-staged coalesced stores, fused bias / residual / activation).
 #include "common.h"
 #include "epilogue.h"
 #include "kernels.h"
 
-constexpr bool PRIO = true;   // s_setprio around the MFMA cluster made hipcc wait lgkmcnt(0) before the first MFMA
 template <int N>
 GP_DEV void halo_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-constexpr int HALO_LDS = 147456;   // 2 x 48 KiB halo + 3 x 16 KiB weights (>= the 128 KiB epilogue staging, also in the x2 case)
-constexpr int GN_MAXC = 2048;      // fused input transform: per-channel scale/shift of one image live in the last 16 KiB of LDS
+constexpr int GN_MAXC = 1536;      // fused input transform: per-channel scale/shift of one image live in 12 KiB of LDS
+constexpr int HALO_NB = 4;         // weight ring depth
+
+template <bool UPS>
+struct HaloGeom {
+    static constexpr int HW_ = UPS ? 10 : 18;              // halo edge (source pixels)
+    static constexpr int HROWS = HW_ * HW_;                // 100 / 324 halo pixels = LDS rows of 128 B
+    static constexpr int GROUPS = (HROWS + 7) / 8;         // 13 / 41 DMA groups of 8 rows
+    static constexpr int A_IT = (GROUPS + 7) / 8;          // 2 / 6 DMA instructions per wave per halo (extra ones hit the dump)
+    static constexpr int A_BUF = GROUPS * 1024;            // 13 / 41 KiB
+    static constexpr int B_OFF = 2 * A_BUF;
+    static constexpr int DUMP_OFF = B_OFF + HALO_NB * 16384;
+    static constexpr int GN_OFF = DUMP_OFF + 1024;
+    static constexpr int LDS_MIN = GN_OFF + 2 * GN_MAXC * 4;
+    static constexpr int LDS = LDS_MIN > 131072 ? LDS_MIN : 131072;  // the epilogue stages 128 KiB
+};
 
 template <bool UPS>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IGemmParams p) {
-    constexpr int BM = 256, BN = 128, WM = 4, WN = 2, NW = 8, TM = 64, TN = 64, FM = 4, FN = 4, FP = 2;
-    constexpr int HW_ = UPS ? 10 : 18;                 // halo edge (source pixels)
-    constexpr int HROWS = HW_ * HW_;                   // 100 / 324 halo pixels = LDS rows of 128 B
-    constexpr int A_IT = (HROWS + 63) / 64;            // 8-row DMA groups per wave: 2 / 6 (tail groups hit the zero page)
-    constexpr int A_BUF = A_IT * 8 * 1024;             // 16 KiB / 48 KiB
-    constexpr int NB = 3, B_STAGE = BN * 128;          // weight ring
-    constexpr int B_IT = 2;                            // weight DMA groups per wave per stage
+    using G = HaloGeom<UPS>;
+    constexpr int BM = 256, BN = 128, WM = 4, WN = 2, NW = 8, TN = 64, FM = 4, FN = 4, FP = 2;
+    constexpr int HW_ = G::HW_, HROWS = G::HROWS, A_IT = G::A_IT, A_BUF = G::A_BUF;
+    constexpr int NB = HALO_NB, B_STAGE = BN * 128, B_IT = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const a_lds = smem;
-    char* const b_lds = smem + 2 * A_BUF;
-    float* const s_gn = (float*)(smem + HALO_LDS);      // [GN_MAXC] scale, [GN_MAXC] shift of this image (fused GroupNorm apply)
+    char* const b_lds = smem + G::B_OFF;
+    char* const dump = smem + G::DUMP_OFF;
+    float* const s_gn = (float*)(smem + G::GN_OFF);  // [GN_MAXC] scale, [GN_MAXC] shift of this image
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,9 +99,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IGemmParams p) 
         w_ptr[i] = p.wt + (long long)n * p.ldw + chunk_w * 8;
     }
 
-    // ---- fused input transform x -> act(x * scale[b][c] + shift[b][c]) applied to the staged halo (GroupNorm apply + SiLU) ----
+    // ---- fused input transform (GroupNorm apply + SiLU) -----------------------------------------------------------------------
     // Padding pixels must stay exactly 0 (the reference pads the NORMALISED tensor), hence the per-item validity mask.
-    constexpr int T_IT = (HROWS * 8 + 511) / 512;      // 16-byte items per thread per halo
+    constexpr int T_IT = (HROWS * 8 + 511) / 512;      // 16-byte items per thread per halo: 2 / 6
     const bool fused = p.in_scale != nullptr;
     unsigned t_ok = 0;
     if (fused) {
@@ -101,39 +117,48 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IGemmParams p) 
         }
         __syncthreads();  // before any LDS-DMA is in flight: a later __syncthreads would drain the DMA ring
     }
-    auto transform = [&](int cc) {
+    auto transform_part = [&](int cc, int k) {  // part k = 16-byte item tid + 512*k of the halo buffer
+        if (!((t_ok >> k) & 1u)) return;
         char* buf = a_lds + (cc & 1) * A_BUF;
         const float* sc = s_gn + (cc << 6);
         const float* sh = s_gn + GN_MAXC + (cc << 6);
+        const int item = tid + 512 * k, r = item >> 3;
+        const int ls = ((item & 7) ^ ((r >> 1) & 7)) << 3;  // first channel (within the chunk) of this 16-byte slot
+        // All LDS traffic of the transform goes through inline asm: compiler-visible reads/writes of the DMA-written array make
+        // hipcc drain vmcnt(0) first (it cannot prove they do not alias an LDS-DMA in flight), which would stall the weight
+        // ring every step.  This slot's DMA landed before the barrier of tap 3 (see kstep); the reads are waited for inside
+        // the statement, the write by the s_waitcnt lgkmcnt(0) ahead of the next barrier.
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        const unsigned a_item = (unsigned)(unsigned long long)(buf + item * 16);
+        const unsigned a_sc = (unsigned)(unsigned long long)(sc + ls), a_sh = (unsigned)(unsigned long long)(sh + ls);
+        u32x4_t raw;
+        f4_t s0, s1, h0, h1;
+        asm volatile(
+            "ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\tds_read_b128 %3, %7\n\t"
+            "ds_read_b128 %4, %7 offset:16\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(raw), "=&v"(s0), "=&v"(s1), "=&v"(h0), "=&v"(h1)
+            : "v"(a_item), "v"(a_sc), "v"(a_sh)
+            : "memory");
+        float v[8] = {bflo(raw.x) * s0.x + h0.x, bfhi(raw.x) * s0.y + h0.y, bflo(raw.y) * s0.z + h0.z, bfhi(raw.y) * s0.w + h0.w,
+                      bflo(raw.z) * s1.x + h1.x, bfhi(raw.z) * s1.y + h1.y, bflo(raw.w) * s1.z + h1.z, bfhi(raw.w) * s1.w + h1.w};
+        if (p.in_silu) {
 #pragma unroll
-        for (int k = 0; k < T_IT; ++k) {
-            if (!((t_ok >> k) & 1u)) continue;
-            const int item = tid + 512 * k, r = item >> 3;
-            const int ls = ((item & 7) ^ ((r >> 1) & 7)) << 3;  // first channel (within the chunk) of this 16-byte slot
-            uint4* ptr = (uint4*)(buf + item * 16);
-            const uint4 raw = *ptr;
-            const float4 s0 = *(const float4*)(sc + ls), s1 = *(const float4*)(sc + ls + 4);
-            const float4 h0 = *(const float4*)(sh + ls), h1 = *(const float4*)(sh + ls + 4);
-            float v[8] = {bflo(raw.x) * s0.x + h0.x, bfhi(raw.x) * s0.y + h0.y, bflo(raw.y) * s0.z + h0.z, bfhi(raw.y) * s0.w + h0.w,
-                          bflo(raw.z) * s1.x + h1.x, bfhi(raw.z) * s1.y + h1.y, bflo(raw.w) * s1.z + h1.z, bfhi(raw.w) * s1.w + h1.w};
-            if (p.in_silu) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-            }
-            uint4 o;
-            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-            *ptr = o;
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my LDS writes are done ...
-        __builtin_amdgcn_s_barrier();                        // ... and so are everybody else's (raw: must not drain vmcnt)
+        uint4 o;
+        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+        const u32x4_t ov = {o.x, o.y, o.z, o.w};
+        asm volatile("ds_write_b128 %0, %1" ::"v"(a_item), "v"(ov) : "memory");
     };
 
     auto stage_halo = [&](int cc) {
         char* dst = a_lds + (cc & 1) * A_BUF;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
+            const int g = wave + NW * i;  // groups beyond the halo land in the dump KiB (keeps the per-wave DMA count uniform)
             const bf16_t* src = ((h_ok >> i) & 1u) ? h_ptr[i] + (cc << 6) : zsrc_a;
-            glds16(src, dst + (wave + NW * i) * 1024);
+            glds16(src, g < G::GROUPS ? dst + g * 1024 : dump);
         }
     };
     auto stage_w = [&](int slot, int tap, int cc) {
@@ -152,73 +177,113 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IGemmParams p) 
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    struct Frags { bf16x8_t w[FN], x[FM]; };
     const int xr_w = ((a15 >> 1) & 1) | (((a15 >> 2) & 1) << 1) | (((a15 >> 3) & 1) << 2);
     const int w_row_off = (wn * TN + 8 * (a15 >> 2) + (a15 & 3)) * 128;
-    auto compute = [&](int slot, int cc, int ky, int kx) {
+    // fragments of k-half kk of step (slot, chunk cc, tap ky/kx)
+    auto load_frags = [&](Frags& f, int slot, int cc, int ky, int kx, int kk) {
         const char* ab = a_lds + (cc & 1) * A_BUF;
         const char* wb = b_lds + slot * B_STAGE;
-        int row[FM];
+        const int sl = kk * 4 + (lane >> 4);
+        const int so_w = (sl ^ xr_w) << 4;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) f.w[i] = *(const bf16x8_t*)(wb + w_row_off + (i >> 1) * 4096 + (i & 1) * 512 + so_w);
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
             const int py = 4 * wm + j;
-            if (UPS) row[j] = (((py + ky - 1) >> 1) + 1) * HW_ + (((a15 + kx - 1) >> 1) + 1);
-            else row[j] = (py + ky) * HW_ + a15 + kx;
+            int row;
+            if (UPS) row = (((py + ky - 1) >> 1) + 1) * HW_ + (((a15 + kx - 1) >> 1) + 1);
+            else row = (py + ky) * HW_ + a15 + kx;
+            f.x[j] = *(const bf16x8_t*)(ab + row * 128 + ((sl ^ ((row >> 1) & 7)) << 4));
         }
-        bf16x8_t wf[2][FN], xf[2][FM];  // all 16 fragment reads first: the second k-half's LDS latency hides under the first half's MFMAs
+    };
+    auto mfma16 = [&](const Frags& f) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int sl = kk * 4 + (lane >> 4);
-            const int so_w = (sl ^ xr_w) << 4;
+        for (int i = 0; i < FN; ++i)
 #pragma unroll
-            for (int i = 0; i < FN; ++i) wf[kk][i] = *(const bf16x8_t*)(wb + w_row_off + (i >> 1) * 4096 + (i & 1) * 512 + so_w);
-#pragma unroll
-            for (int j = 0; j < FM; ++j) xf[kk][j] = *(const bf16x8_t*)(ab + row[j] * 128 + ((sl ^ ((row[j] >> 1) & 7)) << 4));
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < FN; ++i)
-#pragma unroll
-                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[i], f.x[j], acc[i][j], 0, 0, 0);
     };
 
-    // ---- prologue: bias, halo of chunk 0, weight tiles of steps 0 and 1 ---------------------------------------
+    // ---- prologue: bias, halo of chunk 0, weight tiles of steps 0..2 ------------------------------------------------------------
     // (bias first: an ordinary load issued while LDS-DMA is in flight makes hipcc drain vmcnt to 0 at its first use)
     float bcol[FP][8];
     load_bias_cols<FP>(p, 0, n0 + wn * TN, 8 * (lane >> 4), bcol);
     stage_halo(0);
     stage_w(0, 0, 0);
-    stage_w(1, 1, 0);  // ns >= 9 always
+    stage_w(1, 1, 0);
+    stage_w(2, 2, 0);  // ns >= 9 always
 
-    // ---- main loop over (chunk, tap) ------------------------------------------------------------------------------------------
-    int tap = 0, cc = 0, ky = 0, kx = 0;            // current step
-    int t2 = 2, c2 = 0;                             // (tap, chunk) of step s + 2
-    int slot = 0, slot2 = 2;
-    for (int s = 0; s < ns; ++s) {
-        // loads issued after B(s) that may stay in flight: B(s+1), and halo(cc+1) when it was issued at this chunk's tap 0
-        const bool more_w = s + 1 < ns;
+    // ---- main loop over (chunk, tap) ------------------------------------------------------------------------------------------------
+    int tap = 0, cc = 0, ky = 0, kx = 0;            // step s
+    int tap1 = 1, cc1 = 0, ky1 = 0, kx1 = 1;        // step s + 1 (prefetched)
+    int t3 = 3, c3 = 0;                             // (tap, chunk) of step s + 3 (its weights are issued in step s)
+    int slot = 0, slot1 = 1, slot3 = 3;
+    int s = 0;
+    Frags f0, f1a, f1b;  // f0: k-half 0 of the current step; f1a / f1b ping-pong: k-half 1 of the current / next step
+
+    // One K-step.  On entry f0 and `cur1` hold BOTH k-halves of step s (read from LDS during step s-1), so the 32 MFMAs never
+    // wait for LDS; the 16 fragment reads of step s+1 are issued between the two MFMA batches (f0 is dead by then, `nxt1` is free).
+    auto kstep = [&](Frags& cur1, Frags& nxt1) {
+        // Barrier(s) certifies B(s+1) (and every halo issued before it).  Loads issued after B(s+1) that may stay in flight:
+        // B(s+2), and halo(cc+1) while it was issued one or two steps ago (this chunk's tap 0).
+        const bool more_w = s + 2 < ns;
         const bool halo_fly = (tap == 1 || tap == 2) && cc + 1 < cpt;
         if (halo_fly) { if (more_w) halo_wait_vm<A_IT + B_IT>(); else halo_wait_vm<A_IT>(); }
         else { if (more_w) halo_wait_vm<B_IT>(); else halo_wait_vm<0>(); }
+        if (fused) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my transform writes of the previous step are in LDS
         __builtin_amdgcn_s_barrier();
-        const bool issue_w = s + 2 < ns, issue_h = tap == 0 && cc + 1 < cpt;
+        if (s == 0) {
+            if (fused) {  // chunk 0 has nothing to hide under: normalise it here, all parts, then re-synchronise
+#pragma unroll
+                for (int k = 0; k < T_IT; ++k) transform_part(0, k);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            load_frags(f0, 0, 0, 0, 0, 0);
+            load_frags(cur1, 0, 0, 0, 0, 1);
+        }
+        const bool issue_w = s + 3 < ns, issue_h = tap == 0 && cc + 1 < cpt;
         if (second_half) {
-            if (issue_w) stage_w(slot2, t2, c2);
+            if (issue_w) stage_w(slot3, t3, c3);
             if (issue_h) stage_halo(cc + 1);
         }
-        if (fused && tap == 0) transform(cc);
-        compute(slot, cc, ky, kx);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < ns) {
+            load_frags(f0, slot1, cc1, ky1, kx1, 0);
+            load_frags(nxt1, slot1, cc1, ky1, kx1, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(cur1);
+        __builtin_amdgcn_sched_barrier(0);
+        // chunk cc+1's halo is complete for everybody from the barrier of tap 3 on (issued at tap 0, i.e. before B(s+1) of tap 2);
+        // it is first READ by the prefetch in tap 8, so its T_IT transform parts run in taps 3..7, hidden under MFMA steps
+        if (fused && cc + 1 < cpt) {
+            if (T_IT == 6) {
+                if (tap == 3) { transform_part(cc + 1, 0); transform_part(cc + 1, 1); }
+                else if (tap >= 4 && tap <= 7) transform_part(cc + 1, tap - 2);
+            } else {
+                if (tap == 3) transform_part(cc + 1, 0);
+                else if (tap == 4) transform_part(cc + 1, 1);
+            }
+        }
         if (!second_half) {
-            if (issue_w) stage_w(slot2, t2, c2);
+            if (issue_w) stage_w(slot3, t3, c3);
             if (issue_h) stage_halo(cc + 1);
         }
-        slot = slot == NB - 1 ? 0 : slot + 1;
-        slot2 = slot2 == NB - 1 ? 0 : slot2 + 1;
-        if (++kx == 3) { kx = 0; ++ky; }
-        if (++tap == 9) { tap = 0; ky = 0; ++cc; }
-        if (++t2 == 9) { t2 = 0; ++c2; }
+        slot = slot1;
+        slot1 = slot1 == NB - 1 ? 0 : slot1 + 1;
+        slot3 = slot3 == NB - 1 ? 0 : slot3 + 1;
+        tap = tap1; cc = cc1; ky = ky1; kx = kx1;
+        if (++kx1 == 3) { kx1 = 0; ++ky1; }
+        if (++tap1 == 9) { tap1 = 0; ky1 = 0; ++cc1; }
+        if (++t3 == 9) { t3 = 0; ++c3; }
+        ++s;
+    };
+    while (s < ns) {
+        kstep(f1a, f1b);
+        if (s < ns) kstep(f1b, f1a);
     }
 
     // ---- epilogue --------------------------------------------------------------------------------------------------------------
@@ -241,13 +306,12 @@ bool conv_halo_applicable(const IGemmParams& p) {
 void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
     const int tiles = ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16) * p.B * ((ncols + 127) / 128);
-    constexpr int LDS = HALO_LDS + 2 * GN_MAXC * (int)sizeof(float);  // 160 KiB: the whole LDS of a CU
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<false>::LDS);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<true>::LDS);
         attr = true;
     }
-    if (p.ups) hipLaunchKernelGGL(conv3x3_halo_kernel<true>, dim3(tiles), dim3(512), LDS, s, p);
-    else hipLaunchKernelGGL(conv3x3_halo_kernel<false>, dim3(tiles), dim3(512), LDS, s, p);
+    if (p.ups) hipLaunchKernelGGL(conv3x3_halo_kernel<true>, dim3(tiles), dim3(512), HaloGeom<true>::LDS, s, p);
+    else hipLaunchKernelGGL(conv3x3_halo_kernel<false>, dim3(tiles), dim3(512), HaloGeom<false>::LDS, s, p);
 }
