@@ -13,6 +13,10 @@
 #include "common.h"
 #include "kernels.h"
 
+// 32-row MFMA fragments (rows = lane & 31, slots s / s+1 for the two half-waves) are conflict-free with slot ^ ((row >> 1) & 7);
+// the conv kernels' slot ^ (row & 7) is not for this pattern (checked exhaustively), so the attention tiles keep their own swizzle.
+GP_DEV int attn_off128(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
 __global__ __launch_bounds__(256) void flash_attn64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                             const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
                                                             const bf16_t* __restrict__ zero, int T, int heads, int ldq, int ldk, int Tpad,
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(const bf16_t* __restr
             const int row = kb * 32 + l31;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8_t kf = *(const bf16x8_t*)(sb + lds_off128(row, ks * 2 + hh));
+                const bf16x8_t kf = *(const bf16x8_t*)(sb + attn_off128(row, ks * 2 + hh));
                 s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc[kb], 0, 0, 0);
             }
         }

@@ -40,9 +40,10 @@ GP_DEV void glds16(const void* gsrc, void* lds_wave_base) {
 GP_DEV void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // LDS tiles are [rows][64 bf16] = 128-byte rows split into eight 16-byte slots.  Logical slot c of row r lives at
-// physical slot c ^ ((r >> 1) & 7): sixteen consecutive rows at one logical slot then cover all sixteen 16-byte
-// positions of a 256-byte bank row, so a ds_read_b128 fragment read is conflict-free.
-GP_DEV int swz_slot(int row, int slot) { return slot ^ ((row >> 1) & 7); }
+// physical slot c ^ (r & 7): with ds_read_b128's lane groups ({0-3,12-15,20-27}, ...) any window of sixteen consecutive
+// rows read at slots (c, c+1) is conflict-free, whatever its first row (checked exhaustively; (r >> 1) & 7 is only
+// conflict-free for windows starting at multiples of 4, which cost the halo conv 28 % of its LDS cycles).
+GP_DEV int swz_slot(int row, int slot) { return slot ^ (row & 7); }
 GP_DEV int lds_off128(int row, int slot) { return row * 128 + (swz_slot(row, slot) << 4); }
 
 // XCD-aware bijective remap of a linear workgroup id: workgroup b runs on XCD b % 8 (observed), so give each XCD a

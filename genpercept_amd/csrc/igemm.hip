@@ -57,9 +57,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
     const int nk = (CONV ? 9 : 1) * cpt;
 
     // this lane's 16-byte source chunk inside a 128-byte row (swizzled; identical for every DMA group of the wave)
-    //   pixel tile:  slot ^ ((row >> 1) & 7)                       rows read 16-consecutive
+    //   pixel tile:  slot ^ (row & 7)                              rows read 16-consecutive (conflict-free for any start row)
     //   weight tile: slot ^ (b1 | b3 << 1 | b4 << 2) of the row    rows read as {8q + 4h + r}
-    const int chunk_a = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
+    const int chunk_a = (lane & 7) ^ (lane >> 3);
     const int chunk_w = (lane & 7) ^ (((lane >> 4) & 1) | ((wave & 1) << 1) | (((wave >> 1) & 1) << 2));
     const bf16_t* zsrc_a = p.zero + chunk_a * 8;
     const bf16_t* zsrc_w = p.zero + chunk_w * 8;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
     // 32*ip + 8*(a>>2) + 4*(i&1) + (a&3) for MFMA row a = lane&15, i.e. accumulator (q = lane>>4, r) of fragments
     // (2ip, 2ip+1) are output channels 32*ip + 8q + r and 32*ip + 8q + 4 + r: 8 consecutive channels per lane.
     const int a15 = lane & 15;
-    const int xr_a = (lane >> 1) & 7;
+    const int xr_a = lane & 7;
     const int xr_w = ((a15 >> 1) & 1) | (((a15 >> 2) & 1) << 1) | (((a15 >> 3) & 1) << 2);
     const int a_row_off = (wm * TM + a15) * 128;
     const int w_row_off = A_BYTES + (wn * TN + 8 * (a15 >> 2) + (a15 & 3)) * 128;

@@ -76,18 +76,24 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
                                                            int HW, int C, int G, int nchunk, float eps) {
-    __shared__ float s_stat[2 * 64];
+    // 8 lanes per group (G <= 32) walk the chunk partials in a fixed order and combine by xor-shuffles: deterministic, and
+    // ~30x shorter than one thread per group looping over up to 256 chunks (that version cost 3.5 ms per forward pass).
+    __shared__ float s_stat[2 * 32];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int cpg = C / G;
     const int per = (HW + nchunk - 1) / nchunk;
-    if (tid < G) {
-        const float* w = ws + ((long long)b * nchunk * G + tid) * 2;
-        float tot = 0.f;
-        for (int k = 0; k < nchunk; ++k) tot += w[(long long)k * G * 2];
-        const float n_all = (float)HW * (float)cpg;
-        const float mean = tot / n_all;
-        float m2 = 0.f;
-        for (int k = 0; k < nchunk; ++k) {
+    const int g = tid >> 3, sub = tid & 7;
+    const bool act = g < G;
+    const float* w = ws + ((long long)b * nchunk * G + (act ? g : 0)) * 2;
+    float tot = 0.f;
+    if (act)
+        for (int k = sub; k < nchunk; k += 8) tot += w[(long long)k * G * 2];
+    tot += __shfl_xor(tot, 1); tot += __shfl_xor(tot, 2); tot += __shfl_xor(tot, 4);
+    const float n_all = (float)HW * (float)cpg;
+    const float mean = tot / n_all;
+    float m2 = 0.f;
+    if (act)
+        for (int k = sub; k < nchunk; k += 8) {
             const int cnt_px = min(HW, (k + 1) * per) - min(HW, k * per);
             if (cnt_px <= 0) continue;
             const float nk = (float)cnt_px * (float)cpg;
@@ -95,15 +101,17 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
             const float mk = sk / nk;
             m2 += fmaxf(qk - sk * mk, 0.f) + nk * (mk - mean) * (mk - mean);
         }
-        s_stat[2 * tid] = mean;
-        s_stat[2 * tid + 1] = rsqrtf(m2 / n_all + eps);
+    m2 += __shfl_xor(m2, 1); m2 += __shfl_xor(m2, 2); m2 += __shfl_xor(m2, 4);
+    if (act && sub == 0) {
+        s_stat[2 * g] = mean;
+        s_stat[2 * g + 1] = rsqrtf(m2 / n_all + eps);
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
-        const int g = c / cpg;
-        const float sc = s_stat[2 * g + 1] * gamma[c];
+        const int gg = c / cpg;
+        const float sc = s_stat[2 * gg + 1] * gamma[c];
         scale[(long long)b * C + c] = sc;
-        shift[(long long)b * C + c] = beta[c] - s_stat[2 * g] * sc;
+        shift[(long long)b * C + c] = beta[c] - s_stat[2 * gg] * sc;
     }
 }
 
