@@ -25,6 +25,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TFLOP_PER_IMAGE_768_DPT = 5.473  # VAE-enc 2.609 + UNet 2.137 + DPT head 0.726
 TFLOP_PER_IMAGE_768 = 10.50  # VAE-enc 2.609 + UNet 2.137 + VAE-dec 5.754 (2*MAC of conv/linear/QK^T/PV)
 PEAK_BF16_TFLOPS = 2500.0    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
@@ -44,7 +45,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4, help="images per GPU per step")
     ap.add_argument("--res", type=int, default=768)
-    ap.add_argument("--mode", default="depth")
+    ap.add_argument("--mode", default="depth", help="depth | normal | ... (VAE-decoder head); use --head dpt for the DPT disparity head")
+    ap.add_argument("--head", default="vae", choices=["vae", "dpt"], help="BASELINE.json configs[1]/[2] = vae (depth/normal), configs[3] = dpt")
     ap.add_argument("--cpu-res", type=int, default=384, help="edge of the single image timed on the CPU oracle (BASELINE.json configs[0])")
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads for the baseline leg (256 oversubscribes badly)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -62,18 +64,24 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    ucfg, vcfg = gc.UNetConfig(), gc.VAEConfig()
+    dpt = args.head == "dpt"
+    if dpt:
+        args.mode = "disparity"
+    ucfg, vcfg = gc.UNetConfig(has_out=not dpt), gc.VAEConfig()
+    dcfg = gc.DPTConfig() if dpt else None
     t0 = time.time()
     usd = gw.synth_state_dict(gw.unet_manifest(ucfg), seed=0)
     vsd = gw.synth_state_dict(gw.vae_manifest(vcfg), seed=1)
     ctx = torch.randn(2, ucfg.cross_attention_dim, generator=torch.Generator().manual_seed(2))
-    eng = Engine(local_rank, ucfg, vcfg, None)
+    eng = Engine(local_rank, ucfg, vcfg, dcfg)
     eng.load_state_dict("vae", vsd)
     eng.load_state_dict("unet", usd)
+    if dpt:
+        eng.load_state_dict("dpt", gw.synth_state_dict(gw.dpt_manifest(dcfg), seed=3))
     eng.set_context(ctx)
     eng.finalize()
     t_load = time.time() - t0
-    if not (rank == 0 and n_gpus == 1 and not args.no_cpu):
+    if not (rank == 0 and n_gpus == 1 and not args.no_cpu and not dpt):
         del usd  # the CPU-baseline leg needs the fp32 weights
 
     lo, hi = gd.shard_range(args.batch * n_gpus, rank, n_gpus)
@@ -103,7 +111,7 @@ def main():
         eng.infer(rgb, args.mode)
         tm = eng.timings()
         eng.set_profile(0)
-        scale = (args.res / 768.0) ** 2
+        scale = (args.res / 768.0) ** 2 * ((TFLOP_PER_IMAGE_768_DPT / TFLOP_PER_IMAGE_768) if dpt else 1.0)
         if tm["ms_igemm"] > 0:
             ach = tm["flops_igemm"] / (tm["ms_igemm"] * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x32_bf16)",
@@ -118,7 +126,7 @@ def main():
                   "algorithmic_tflop_counted": round((tm["flops_igemm"] + tm["flops_attn"]) / 1e12 / args.batch, 3)}
 
     cpu = None
-    if rank == 0 and n_gpus == 1 and not args.no_cpu:
+    if rank == 0 and n_gpus == 1 and not args.no_cpu and not dpt:
         from oracle import pipeline as opipe  # CPU baseline leg only
         from oracle import sd21 as osd
         nthr = max(1, min(os.cpu_count(), args.cpu_threads))
@@ -136,11 +144,12 @@ def main():
         assert torch.isfinite(ref).all()
 
     if rank == 0:
-        line = {"metric": "images/sec at 768x768 bf16 (depth head)", "value": round(value, 3), "unit": "images/sec", "n_gpus": n_gpus,
+        head_name = "DPT disparity head" if dpt else f"{args.mode} head"
+        line = {"metric": f"images/sec at 768x768 bf16 ({'depth' if not dpt and args.mode == 'depth' else head_name})", "value": round(value, 3), "unit": "images/sec", "n_gpus": n_gpus,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                "config": {"workload": f"depth head, SD2.1 VAE-enc + UNet(t=1) + VAE-dec, {args.res}x{args.res}, batch {args.batch}/GPU "
-                                       "(BASELINE.json configs[1])", "global_batch": args.batch * n_gpus, "resolution": args.res,
+                "config": {"workload": (f"{head_name}, SD2.1 VAE-enc + UNet(t=1) + " + ("DPT neck/head" if dpt else "VAE-dec") +
+                                        f", {args.res}x{args.res}, batch {args.batch}/GPU (BASELINE.json configs[{3 if dpt else (1 if args.mode == 'depth' else 2)}])"), "global_batch": args.batch * n_gpus, "resolution": args.res,
                            "parallelism": f"dp{n_gpus} (batch-sharded, weights replicated, no data-path collective)",
                            "weights": "random-init SD2.1 architecture (865.9M + 83.7M params)", "load_s": round(t_load, 1)},
                 "roofline": roofline, "cpu_baseline": cpu, "stages": stages}

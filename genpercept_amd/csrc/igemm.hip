@@ -17,6 +17,8 @@
 //  * The MFMA takes the WEIGHTS as A operand and the PIXELS as B operand, and the weight-fragment rows are chosen so that
 //    a lane ends up with 8 consecutive output channels of one pixel: bias is two float4 loaded before the K loop, the
 //    bf16 store is 16 bytes per lane, the residual one 16-byte load.
+#include <cstdlib>
+
 #include "common.h"
 #include "epilogue.h"
 #include "kernels.h"
@@ -248,6 +250,8 @@ static void launch_cfg(const IGemmParams& p, hipStream_t s) {
 //            4 = 256x128 (8 waves, 3-deep ring: the large-problem configuration)
 // true when launch_igemm(p, hint) hands the problem to conv_halo.hip (the only kernel that fuses IGemmParams::in_scale)
 bool conv_uses_halo(const IGemmParams& p, int tile_hint) {
+    static const bool no_halo = getenv("GENPERCEPT_NO_HALO") != nullptr;  // A/B switch: generic implicit GEMM everywhere
+    if (no_halo && tile_hint != 5) return false;
     if (!(tile_hint == 5 || tile_hint == 0) || !conv_halo_applicable(p)) return false;
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
     const long long tiles = (long long)((p.Wo + 15) / 16) * ((p.Ho + 15) / 16) * p.B * ((ncols + 127) / 128);

@@ -32,7 +32,8 @@ SHAPES = {
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--tiles", default="0")
     ap.add_argument("--dbg", default="0", help="comma list of GENPERCEPT_IGEMM_DBG ablation values")
@@ -46,18 +47,24 @@ def main():
         wp = e.pack_weight(wt, device=d)
         bias = torch.randn(cout, generator=g).to(d)
         flops = 2.0 * b * h * w * cout * cin * ks * ks
-        for tile, dbg in [(int(t), dv) for t in args.tiles.split(",") for dv in args.dbg.split(",")]:
-            os.environ["GENPERCEPT_IGEMM_DBG"] = dbg
-            y = e.conv2d(x, wp, bias, cout, ks, tile=tile)
-            torch.cuda.synchronize()
-            st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            st.record()
-            for _ in range(args.iters):
-                y = e.conv2d(x, wp, bias, cout, ks, tile=tile)
-            en.record()
-            torch.cuda.synchronize()
-            ms = st.elapsed_time(en) / args.iters
-            print(f"{name:14s} tile={tile} dbg={dbg} M={b*h*w:8d} N={cout:5d} K={cin*ks*ks:6d}  {ms*1e3:9.1f} us  {flops/ms/1e9:8.1f} TFLOP/s", flush=True)
+        variants = [(int(t), dv) for t in args.tiles.split(",") for dv in args.dbg.split(",")]
+        times = {v: [] for v in variants}
+        for rnd in range(args.rounds + 1):  # round 0 = warm-up; variants interleaved inside every round (DVFS drifts between runs)
+            for tile, dbg in variants:
+                os.environ["GENPERCEPT_IGEMM_DBG"] = dbg
+                st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                st.record()
+                for _ in range(args.iters):
+                    y = e.conv2d(x, wp, bias, cout, ks, tile=tile)
+                en.record()
+                torch.cuda.synchronize()
+                if rnd:
+                    times[(tile, dbg)].append(st.elapsed_time(en) / args.iters)
+        for (tile, dbg), ts in times.items():
+            ts.sort()
+            med, mn = ts[len(ts) // 2], ts[0]
+            print(f"{name:14s} tile={tile} dbg={dbg:>3s} M={b*h*w:8d} N={cout:5d} K={cin*ks*ks:6d}  median {med*1e3:8.1f} us  min {mn*1e3:8.1f} us  "
+                  f"{flops/med/1e9:7.1f} TFLOP/s", flush=True)
         del x, wp, y
 
 
