@@ -304,7 +304,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IGemmParams p) 
     conv_epilogue<BM, BN, WM, WN, 512>(p, acc, bcol, n0, 0, wave, lane, smem, [&](int pr) {
         const int oy = ty * 16 + (pr >> 4), ox = tx * 16 + (pr & 15);
         return (oy < Ho && ox < Wo) ? (b * Ho + oy) * Wo + ox : -1;
-    });
+    }, (b * tiles_y + ty) * tiles_x + tx);
 }
 
 bool conv_halo_applicable(const IGemmParams& p) {

@@ -94,6 +94,9 @@ struct Pool {
 struct Act {
     bf16_t* p = nullptr;
     int B = 0, H = 0, W = 0, C = 0;  // C = allocated channels (row stride)
+    // GroupNorm partial statistics written by the producing conv's epilogue ([pixel tile][C][2] fp32; owned with p)
+    float* st = nullptr;
+    int st_mode = 0, st_bm = 0;
     long long pixels() const { return (long long)B * H * W; }
 };
 
@@ -144,6 +147,7 @@ struct gp_engine {
     size_t gn_ws_floats = 0;
     float* mm_ws = nullptr;
     bool fuse_gn = true;   // GENPERCEPT_NO_GN_FUSION=1 keeps the separate apply pass (A/B measurements)
+    bool fuse_stats = true;  // GENPERCEPT_NO_STATS_FUSION=1 keeps the separate statistics pass
 
     std::unordered_map<std::string, PackedW> convs;
     std::unordered_map<std::string, NormW> norms;
@@ -365,6 +369,7 @@ struct gp_engine {
         if (finalized) throw std::logic_error("gp_finalize called twice");
         HIPCHK(hipSetDevice(cfg.device));
         fuse_gn = getenv("GENPERCEPT_NO_GN_FUSION") == nullptr;
+        fuse_stats = getenv("GENPERCEPT_NO_STATS_FUSION") == nullptr;
         {
             std::vector<bf16_t> z(2048, 0);
             zero = upload(z.data(), z.size());
@@ -489,7 +494,20 @@ struct gp_engine {
     }
     void drop(Act& a) {
         pool.release(a.p);
+        if (a.st) pool.release(a.st);
         a.p = nullptr;
+        a.st = nullptr;
+    }
+    // ask the kernel that is about to write `y` to leave per-tile channel statistics behind (next GroupNorm skips its read pass)
+    void attach_stats(Act& y, IGemmParams& p) {
+        if (!fuse_stats) return;
+        int mode = 0, bm = 0;
+        const int nt = igemm_tile_info(p, 0, &mode, &bm);
+        if (nt <= 0) return;
+        y.st = (float*)pool.alloc((size_t)nt * p.N * 2 * sizeof(float));
+        y.st_mode = mode;
+        y.st_bm = bm;
+        p.stats_out = y.st;
     }
     void prof_begin(int kind) {
         if (prof < 2) return;
@@ -525,6 +543,7 @@ struct gp_engine {
         const bf16_t* res = nullptr;
         int act = GP_ACT_NONE;
         int n_store = 0;        // 0: cout
+        bool want_stats = false;  // the output feeds a GroupNorm
     };
     IGemmParams conv_params(const Act& x, const PackedW& w, const ConvOpt& o, bf16_t* out) {
         if (x.C != w.cin_pad) throw std::logic_error("conv: channel mismatch (" + std::to_string(x.C) + " vs " + std::to_string(w.cin_pad) + ")");
@@ -548,11 +567,13 @@ struct gp_engine {
         p.out = y.p;
         p.in_scale = in_scale; p.in_shift = in_shift; p.in_silu = in_silu ? 1 : 0;
         if (in_scale && !conv_uses_halo(p, 0)) throw std::logic_error("fused GroupNorm input needs the halo conv kernel");
+        if (o.want_stats) attach_stats(y, p);
         run_igemm(p);
         return y;
     }
     // y[M][N] = x[M][K] W^T (+bias) (+res), N = w.cout (GEGLU halves it)
-    Act linear(const Act& x, const PackedW& w, const bf16_t* res = nullptr, int act = GP_ACT_NONE, bf16_t* out_inplace = nullptr) {
+    Act linear(const Act& x, const PackedW& w, const bf16_t* res = nullptr, int act = GP_ACT_NONE, bf16_t* out_inplace = nullptr,
+               bool want_stats = false) {
         if (x.C != w.cin_pad) throw std::logic_error("linear: channel mismatch");
         const int nout = act == GP_ACT_GEGLU ? w.cout / 2 : w.cout;
         Act y;
@@ -564,6 +585,7 @@ struct gp_engine {
         p.B = x.B; p.Hi = x.H; p.Wi = x.W; p.Ho = x.H; p.Wo = x.W; p.stride = 1;
         p.lda = x.C; p.ldo = nout; p.ldres = nout; p.ldw = w.cin_pad; p.n_store = nout; p.act = act;
         p.bias_mode = w.bias ? GP_BIAS_COL : GP_BIAS_NONE; p.batch = 1;
+        if (want_stats && !out_inplace) attach_stats(y, p);
         run_igemm(p);
         return y;
     }
@@ -580,12 +602,26 @@ struct gp_engine {
         run_igemm(p);
         return vt;
     }
-    Act groupnorm(const Act& x, const NormW& n, float eps, bool silu) {
+    // statistics -> per-(image, channel) scale / shift in the GN workspace; from the producer's tile partials when it left some
+    void gn_scale_shift(const Act& x, const NormW& n, float eps, float*& scale, float*& shift) {
         if (x.C != n.C) throw std::logic_error("groupnorm: channel mismatch");
         float* ws = gn_workspace(x);
+        scale = ws + groupnorm_ws_floats(x.B, x.H * x.W, x.C, cfg.norm_groups);
+        shift = scale + (size_t)x.B * x.C;
+        if (x.st) {
+            launch_groupnorm_from_partials(x.st, x.st_mode, x.st_bm, x.B, x.H, x.W, x.C, cfg.norm_groups, eps, n.g, n.b, scale, shift, st);
+            tm.n_launches++;
+        } else {
+            launch_groupnorm_stats(x.p, n.g, n.b, x.B, x.H * x.W, x.C, cfg.norm_groups, eps, ws, scale, shift, st);
+            tm.n_launches += 2;
+        }
+    }
+    Act groupnorm(const Act& x, const NormW& n, float eps, bool silu) {
+        float *scale, *shift;
+        gn_scale_shift(x, n, eps, scale, shift);
         Act y = new_act(x.B, x.H, x.W, x.C);
-        launch_groupnorm(x.p, y.p, n.g, n.b, x.B, x.H * x.W, x.C, cfg.norm_groups, eps, silu ? 1 : 0, ws, st);
-        tm.n_launches += 3;
+        launch_groupnorm_apply(x.p, y.p, scale, shift, x.B, x.H * x.W, x.C, silu ? 1 : 0, st);
+        tm.n_launches++;
         return y;
     }
     float* gn_workspace(const Act& x) {  // partial statistics + per-(image, channel) scale / shift
@@ -600,12 +636,8 @@ struct gp_engine {
     // conv(act(GroupNorm(x))): statistics pass, then the normalisation is applied either inside the conv kernel on the staged
     // input halo (conv_halo.hip) or, when that kernel does not take the layer, by the separate apply pass.
     Act conv_gn(const Act& x, const NormW& n, float eps, bool silu, const PackedW& w, const ConvOpt& o) {
-        if (x.C != n.C) throw std::logic_error("groupnorm: channel mismatch");
-        float* ws = gn_workspace(x);
-        float* scale = ws + groupnorm_ws_floats(x.B, x.H * x.W, x.C, cfg.norm_groups);
-        float* shift = scale + (size_t)x.B * x.C;
-        launch_groupnorm_stats(x.p, n.g, n.b, x.B, x.H * x.W, x.C, cfg.norm_groups, eps, ws, scale, shift, st);
-        tm.n_launches += 2;
+        float *scale, *shift;
+        gn_scale_shift(x, n, eps, scale, shift);
         IGemmParams p = conv_params(x, w, o, nullptr);
         p.in_scale = scale; p.in_shift = shift; p.in_silu = silu ? 1 : 0;
         if (fuse_gn && conv_uses_halo(p, 0)) return conv(x, w, o, scale, shift, silu);
@@ -625,11 +657,14 @@ struct gp_engine {
 
     Act resnet(const Act& x, const std::string& name, float eps) {
         const ResW& r = resnets.at(name);
-        Act h = conv_gn(x, r.n1, eps, true, r.c1, ConvOpt{});
+        ConvOpt o1;
+        o1.want_stats = true;
+        Act h = conv_gn(x, r.n1, eps, true, r.c1, o1);
         Act sc = x;
         if (r.has_sc) sc = linear(x, r.sc);
         ConvOpt o;
         o.res = sc.p;
+        o.want_stats = true;
         Act y = conv_gn(h, r.n2, eps, true, r.c2, o);
         drop(h);
         if (r.has_sc) drop(sc);
@@ -668,7 +703,7 @@ struct gp_engine {
         }
         pool.release(P);
         pool.release(vt);
-        Act y = linear(o, a.o, x.p);
+        Act y = linear(o, a.o, x.p, GP_ACT_NONE, nullptr, true);
         drop(o);
         return y;
     }
@@ -712,7 +747,7 @@ struct gp_engine {
         drop(l3);
         linear(ff, t.ff2, y.p, GP_ACT_NONE, y.p);
         drop(ff);
-        Act out = linear(y, t.proj_out, x.p);
+        Act out = linear(y, t.proj_out, x.p, GP_ACT_NONE, nullptr, true);
         drop(y);
         return out;
     }
@@ -723,7 +758,9 @@ struct gp_engine {
         Act x = new_act(B, Hh, Ww, 64);
         launch_rgb_prologue(rgb, is_u8, x.p, B, Hh, Ww, 64, st);
         tm.n_launches++;
-        Act h = conv(x, convs.at("vae.encoder.conv_in"), ConvOpt{});
+        ConvOpt oin;
+        oin.want_stats = true;
+        Act h = conv(x, convs.at("vae.encoder.conv_in"), oin);
         drop(x);
         for (int i = 0; i < 4; ++i) {
             for (int j = 0; j < cfg.vae_layers_per_block; ++j) {
@@ -733,7 +770,7 @@ struct gp_engine {
             }
             if (i != 3) {
                 ConvOpt o;  // pad (0,1,0,1) then stride-2 conv without padding (Appendix B.6)
-                o.stride = 2; o.pad_t = 0; o.pad_l = 0;
+                o.stride = 2; o.pad_t = 0; o.pad_l = 0; o.want_stats = true;
                 o.Ho = (h.H + 1 - 3) / 2 + 1; o.Wo = (h.W + 1 - 3) / 2 + 1;
                 Act y = conv(h, convs.at("vae.encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv"), o);
                 drop(h);
@@ -757,7 +794,9 @@ struct gp_engine {
         std::vector<Act> skips;
         const int nup = 3;
         const bool fwd_size = (latent.H % (1 << nup)) != 0 || (latent.W % (1 << nup)) != 0;
-        Act x = conv(latent, convs.at("unet.conv_in"), ConvOpt{});
+        ConvOpt oin;
+        oin.want_stats = true;
+        Act x = conv(latent, convs.at("unet.conv_in"), oin);
         skips.push_back(x);
         Act cur = x;  // `cur` aliases the top of the skip stack until replaced
         for (int i = 0; i < 4; ++i) {
@@ -774,7 +813,7 @@ struct gp_engine {
             }
             if (i != 3) {
                 ConvOpt o;
-                o.stride = 2;
+                o.stride = 2; o.want_stats = true;
                 o.Ho = (cur.H + 2 - 3) / 2 + 1; o.Wo = (cur.W + 2 - 3) / 2 + 1;
                 Act y = conv(cur, convs.at(bp + ".downsamplers.0.conv"), o);
                 skips.push_back(y);
@@ -840,7 +879,9 @@ struct gp_engine {
         Act z = new_act(z_in.B, z_in.H, z_in.W, 64);
         launch_pointwise_small(z_in.p, z.p, pq_w_dev, pq_b_dev, z_in.pixels(), L, L, z_in.C, 64, in_scale, st);
         tm.n_launches++;
-        Act h = conv(z, convs.at("vae.decoder.conv_in"), ConvOpt{});
+        ConvOpt oin;
+        oin.want_stats = true;
+        Act h = conv(z, convs.at("vae.decoder.conv_in"), oin);
         drop(z);
         Act y = resnet(h, "vae.decoder.mid_block.resnets.0", cfg.vae_norm_eps); drop(h); h = y;
         y = vae_attention(h, "vae.decoder.mid_block.attentions.0"); drop(h); h = y;
@@ -853,7 +894,7 @@ struct gp_engine {
             }
             if (i != 3) {
                 ConvOpt o;
-                o.ups_h = h.H * 2; o.ups_w = h.W * 2;
+                o.ups_h = h.H * 2; o.ups_w = h.W * 2; o.want_stats = true;
                 y = conv(h, convs.at("vae.decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv"), o);
                 drop(h);
                 h = y;

@@ -15,7 +15,7 @@
 
 template <int BM, int BN, int WM, int WN, int NTHREADS, typename RowMap>
 GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(BM / WM) / 16], float (&bcol)[(BN / WN) / 32][8], int n0, int z,
-                          int wave, int lane, char* smem, RowMap row_to_m) {
+                          int wave, int lane, char* smem, RowMap row_to_m, int tile_row = 0) {
     constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FP = TN / 32;
     constexpr int SL = BN / 8;  // 8-channel slots per tile row
     const int wm = wave / WN, wn = wave % WN;
@@ -48,6 +48,12 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
         __syncthreads();
         bf16_t* outp = (bf16_t*)p.out + (long long)z * p.out_bs;
         const bool res_vec = res && (p.ldres & 7) == 0;
+        // GroupNorm statistics of the tensor being written (NTHREADS % SL == 0: a thread always handles the same 8 channels)
+        static_assert(NTHREADS % SL == 0, "stats: a thread must keep its channel slot");
+        const bool want_stats = p.stats_out != nullptr;
+        float st_s[8], st_q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
         for (int idx = threadIdx.x; idx < BM * SL; idx += NTHREADS) {
             const int pr = idx / SL, s = idx - pr * SL;
             const int col = n0 + s * 8;
@@ -75,14 +81,45 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
                 if (col + e >= n_out) v[e] = 0.f;
             }
             bf16_t* o = outp + (long long)m * p.ldo + col;
+            uint4 pk;
+            pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
             if (col + 7 < p.n_store) {
-                uint4 pk;
-                pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
                 *(uint4*)o = pk;
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (col + e < p.n_store) o[e] = f2bf(v[e]);
+            }
+            if (want_stats) {  // of the values as stored (bf16-rounded), exactly what a read pass would see
+                const float r[8] = {bflo(pk.x), bfhi(pk.x), bflo(pk.y), bfhi(pk.y), bflo(pk.z), bfhi(pk.z), bflo(pk.w), bfhi(pk.w)};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { st_s[e] += r[e]; st_q[e] += r[e] * r[e]; }
+            }
+        }
+        if (want_stats) {
+            // deterministic tree: lanes of a wave sharing a slot (xor-shuffles), then the waves through LDS (the staging area is
+            // free once everybody has left the store loop), then one thread per channel writes this tile's partial
+#pragma unroll
+            for (int off = 32; off >= SL; off >>= 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { st_s[e] += __shfl_xor(st_s[e], off); st_q[e] += __shfl_xor(st_q[e], off); }
+            }
+            __syncthreads();
+            constexpr int NWV = NTHREADS / 64;
+            float* red = (float*)smem;  // [NWV][SL][16]
+            if (lane < SL) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { red[(wave * SL + lane) * 16 + e] = st_s[e]; red[(wave * SL + lane) * 16 + 8 + e] = st_q[e]; }
+            }
+            __syncthreads();
+            for (int c = threadIdx.x; c < BN; c += NTHREADS) {
+                if (n0 + c >= n_out) continue;
+                float ss = 0.f, qq = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) { ss += red[(w * SL + (c >> 3)) * 16 + (c & 7)]; qq += red[(w * SL + (c >> 3)) * 16 + 8 + (c & 7)]; }
+                float* so = p.stats_out + ((long long)tile_row * p.N + n0 + c) * 2;
+                so[0] = ss;
+                so[1] = qq;
             }
         }
         return;

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
     conv_epilogue<BM, BN, WM, WN, 64 * NW>(p, acc, bcol, n0, z, wave, lane, smem, [&](int pr) {
         const int m = m0 + pr;
         return m < p.M ? m : -1;
-    });
+    }, sid / tiles_n);
 }
 
 template <int BM, int BN, int WM, int WN, int KS, int NSTAGE>
@@ -258,13 +258,8 @@ bool conv_uses_halo(const IGemmParams& p, int tile_hint) {
     return tile_hint == 5 || (tiles >= 160 && ncols > 32);
 }
 
-void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s) {
-    int cfg = tile_hint;
-    if (conv_uses_halo(p, cfg)) {
-        launch_conv_halo(p, s);
-        return;
-    }
-    if (cfg == 5) cfg = 0;
+static int select_cfg(const IGemmParams& p, int tile_hint) {
+    int cfg = tile_hint == 5 ? 0 : tile_hint;
     if (cfg == 0) {
         const int ncols = p.N > p.n_store ? p.N : p.n_store;
         const long long nb = p.batch > 0 ? p.batch : 1;
@@ -275,6 +270,31 @@ void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s) {
         else if (t256 >= 256) cfg = 4;
         else cfg = 1;
     }
+    return cfg;
+}
+
+int igemm_tile_info(const IGemmParams& p, int tile_hint, int* mode, int* bm) {
+    // the staged epilogue is the only one that accumulates statistics (epilogue.h)
+    if (p.out_fp32 || p.act == GP_ACT_GEGLU || (p.ldo & 7) || p.batch > 1 || p.N != p.n_store) return 0;
+    if (conv_uses_halo(p, tile_hint)) {
+        *mode = 1;
+        *bm = 256;
+        return ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16) * p.B;
+    }
+    const int cfg = select_cfg(p, tile_hint);
+    *mode = 0;
+    *bm = cfg == 1 ? 128 : cfg == 2 ? 64 : 256;
+    const int hw = p.M / (p.B > 0 ? p.B : 1);
+    if (p.B < 1 || hw * p.B != p.M || hw % *bm) return 0;  // a tile must not straddle two images
+    return p.M / *bm;
+}
+
+void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s) {
+    if (conv_uses_halo(p, tile_hint)) {
+        launch_conv_halo(p, s);
+        return;
+    }
+    const int cfg = select_cfg(p, tile_hint);
     if (cfg == 1) launch_cfg<128, 128, 2, 2, 2>(p, s);
     else if (cfg == 2) launch_cfg<64, 64, 2, 2, 3>(p, s);
     else if (cfg == 3) launch_cfg<256, 32, 4, 1, 2>(p, s);

@@ -22,6 +22,8 @@ struct IGemmParams {
     const float* in_scale;  // optional fused input transform x -> act(x * in_scale[b][c] + in_shift[b][c]) (GroupNorm apply);
     const float* in_shift;  //   only honoured by conv_halo.hip (conv_halo_fuses_input())
     int in_silu;
+    float* stats_out;     // optional: per-(tile, output channel) {sum, sum of squares} of the STORED bf16 values, [tile_rows][N][2] fp32,
+                          //   tile_rows = pixel tiles in launch order (igemm_tile_info); feeds the next GroupNorm without a read pass
     int M, N, Cin;        // N = valid output channels (before GEGLU halving)
     int n_rows;           // rows of `wt` that may be read (>= N; rows beyond read the zero page)
     int ks;               // 1 or 3
@@ -43,7 +45,13 @@ void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s);
 // conv_halo.hip: 3x3 stride-1 convs on large maps (16x16-pixel tiles, input halo staged once per channel chunk); tile_hint 5
 bool conv_halo_applicable(const IGemmParams& p);   // includes the Cin <= 2048 limit when in_scale is set
 void launch_conv_halo(const IGemmParams& p, hipStream_t s);
-bool conv_uses_halo(const IGemmParams& p, int tile_hint);  // what launch_igemm will do; callers that set in_scale must check it  // tile_hint: 0 auto, 1 = 128x128, 2 = 64x64, 3 = 256x32
+bool conv_uses_halo(const IGemmParams& p, int tile_hint);
+// Pixel tiling launch_igemm(p, tile_hint) will use: mode 1 = 16x16 halo tiles per image, mode 0 = BM consecutive rows; returns the number
+// of pixel tiles, or 0 when that kernel path cannot produce stats_out (direct epilogue, GEGLU, fp32 output, ...).
+int igemm_tile_info(const IGemmParams& p, int tile_hint, int* mode, int* bm);
+// scale/shift from per-tile channel partials written by a conv epilogue (instead of launch_groupnorm_stats)
+void launch_groupnorm_from_partials(const float* partials, int mode, int bm, int B, int H, int W, int C, int G, float eps, const float* gamma,
+                                    const float* beta, float* scale, float* shift, hipStream_t s);  // what launch_igemm will do; callers that set in_scale must check it  // tile_hint: 0 auto, 1 = 128x128, 2 = 64x64, 3 = 256x32
 
 // GroupNorm over NHWC bf16 (fp32 statistics), optional fused SiLU.  Three passes: partial statistics, per-(image, channel)
 // scale/shift, apply; the apply pass is skipped when the consuming conv fuses it (IGemmParams::in_scale).

@@ -181,6 +181,64 @@ void launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const floa
     launch_groupnorm_apply(x, y, scale, shift, B, HW, C, silu, s);
 }
 
+// ---- scale/shift from the per-(pixel tile, channel) partials a conv epilogue wrote (IGemmParams::stats_out) --------------------
+// One workgroup per (group, image): 256 threads walk the group's (tile, channel) partials in a fixed order; tile pixel counts
+// come from the tiling (mode 0: bm consecutive rows; mode 1: 16x16 tiles clipped at the image edge); Chan-combined variance.
+__global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __restrict__ part, int mode, int bm, int H, int W, int C, int G,
+                                                                 float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ float red[8];
+    __shared__ float s_mean, s_rstd;
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / G;
+    const int tiles_x = (W + 15) >> 4, tiles_y = (H + 15) >> 4;
+    const int ntile = mode ? tiles_x * tiles_y : (H * W) / bm;
+    const float* pb = part + (long long)b * ntile * C * 2;
+    const int items = ntile * cpg;
+    auto tile_px = [&](int t) -> float {
+        if (!mode) return (float)bm;
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        return (float)(min(16, H - ty * 16) * min(16, W - tx * 16));
+    };
+    float tot = 0.f;
+    for (int i = tid; i < items; i += 256) {
+        const int t = i / cpg, c = g * cpg + (i - t * cpg);
+        tot += pb[((long long)t * C + c) * 2];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    if ((tid & 63) == 0) red[tid >> 6] = tot;
+    __syncthreads();
+    const float n_all = (float)H * (float)W * (float)cpg;
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / n_all;
+    float m2 = 0.f;
+    for (int i = tid; i < items; i += 256) {
+        const int t = i / cpg, c = g * cpg + (i - t * cpg);
+        const float nk = tile_px(t), sk = pb[((long long)t * C + c) * 2], qk = pb[((long long)t * C + c) * 2 + 1];
+        const float mk = sk / nk;
+        m2 += fmaxf(qk - sk * mk, 0.f) + nk * (mk - mean) * (mk - mean);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = m2;
+    __syncthreads();
+    if (tid == 0) {
+        s_mean = mean;
+        s_rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / n_all + eps);
+    }
+    __syncthreads();
+    for (int c = g * cpg + tid; c < (g + 1) * cpg; c += 256) {
+        const float sc = s_rstd * gamma[c];
+        scale[(long long)b * C + c] = sc;
+        shift[(long long)b * C + c] = beta[c] - s_mean * sc;
+    }
+}
+
+void launch_groupnorm_from_partials(const float* partials, int mode, int bm, int B, int H, int W, int C, int G, float eps, const float* gamma,
+                                    const float* beta, float* scale, float* shift, hipStream_t s) {
+    hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(G, B), dim3(256), 0, s, partials, mode, bm, H, W, C, G, eps, gamma, beta, scale, shift);
+}
+
 // ---- LayerNorm: one wave per row, row kept in registers (C <= 4096), exact two-pass statistics -------------------
 template <int VPT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* __restrict__ gamma,
