@@ -247,7 +247,7 @@ static void launch_cfg(const IGemmParams& p, hipStream_t s) {
 }
 
 // tile_hint: 0 auto, 1 = 128x128 (4 waves, 2-deep), 2 = 64x64 (4 waves, 3-deep), 3 = 256x32 (4 waves, 2-deep),
-//            4 = 256x128 (8 waves, 3-deep ring: the large-problem configuration)
+//            4 = 256x128 (8 waves, 3-deep ring: the large-problem configuration), 5 = conv_halo.hip, 6 = 128x64 (4 waves, 2-deep)
 // true when launch_igemm(p, hint) hands the problem to conv_halo.hip (the only kernel that fuses IGemmParams::in_scale)
 bool conv_uses_halo(const IGemmParams& p, int tile_hint) {
     static const bool no_halo = getenv("GENPERCEPT_NO_HALO") != nullptr;  // A/B switch: generic implicit GEMM everywhere
@@ -265,8 +265,10 @@ static int select_cfg(const IGemmParams& p, int tile_hint) {
         const long long nb = p.batch > 0 ? p.batch : 1;
         const long long t128 = (long long)((p.M + 127) / 128) * ((ncols + 127) / 128) * nb;
         const long long t256 = (long long)((p.M + 255) / 256) * ((ncols + 127) / 128) * nb;
+        const int nk = (p.ks == 3 ? 9 : 1) * (p.Cin >> 6);
         if (ncols <= 32) cfg = 3;
         else if (ncols <= 64 || t128 < 192) cfg = 2;
+        else if (p.ks == 1 && nk <= 20 && nb == 1) cfg = 6;  // short-K GEMMs are bound by per-tile fixed cost: 3 small workgroups per CU overlap it
         else if (t256 >= 256) cfg = 4;
         else cfg = 1;
     }
@@ -283,7 +285,7 @@ int igemm_tile_info(const IGemmParams& p, int tile_hint, int* mode, int* bm) {
     }
     const int cfg = select_cfg(p, tile_hint);
     *mode = 0;
-    *bm = cfg == 1 ? 128 : cfg == 2 ? 64 : 256;
+    *bm = (cfg == 1 || cfg == 6) ? 128 : cfg == 2 ? 64 : 256;
     const int hw = p.M / (p.B > 0 ? p.B : 1);
     if (p.B < 1 || hw * p.B != p.M || hw % *bm) return 0;  // a tile must not straddle two images
     return p.M / *bm;
@@ -298,5 +300,6 @@ void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s) {
     if (cfg == 1) launch_cfg<128, 128, 2, 2, 2>(p, s);
     else if (cfg == 2) launch_cfg<64, 64, 2, 2, 3>(p, s);
     else if (cfg == 3) launch_cfg<256, 32, 4, 1, 2>(p, s);
+    else if (cfg == 6) launch_cfg<128, 64, 2, 2, 2>(p, s);   // 48 KiB of LDS -> 3 workgroups per CU
     else launch_cfg<256, 128, 4, 2, 3>(p, s);
 }
