@@ -307,6 +307,736 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IGemmParams p) 
     }, (b * tiles_y + ty) * tiles_x + tx);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Second-generation kernel: the same tiling, ring and synchronisation, with the nine taps unrolled at compile time.
+// In the first kernel (above, kept for A/B measurements behind IGemmParams::dbg bit 128) every ds_read_b128 address was
+// recomputed per step from run-time (tap, chunk, ring slot): ~80 VALU + ~90 SALU instructions per 32 MFMAs, executed by both
+// waves of a SIMD at the same time, i.e. with the matrix pipe idle (PMC: 2.6 VALU per MFMA, MFMA busy 38 %).  Here
+//   * the swizzle key of a halo row depends on its COLUMN hx only, so a lane needs six pixel-fragment base addresses
+//     (3 kx x 2 k-halves) and two weight-fragment bases; tap row, pixel row, halo buffer and ring slot (3-deep ring: slot =
+//     tap % 3) are ds_read immediates;
+//   * the weight-tile source pointers advance by a scalar stride per step (no per-step multiply), and
+//   * each MFMA batch is interleaved with the LDS reads of a register set that is dead during that batch.
+template <int V>
+struct IC { static constexpr int value = V; };
+
+typedef const __attribute__((address_space(3))) bf16x8_t* lds_frag_ptr;
+GP_DEV bf16x8_t lds_frag(unsigned base, int imm) { return *(lds_frag_ptr)(base + (unsigned)imm); }
+
+// swizzle key of halo column hx.  18-wide halo: hx & 7 (any 16 consecutive columns are conflict-free); 10-wide halo of the
+// x2-upsample case (lane pairs share a column): table found by exhaustive search, one nibble per column.
+template <bool UPS>
+GP_DEV int halo_key(int hx) { return UPS ? (int)((0x4016642254ull >> (4 * hx)) & 7) : (hx & 7); }
+
+template <bool UPS>
+__global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const IGemmParams p) {
+    using G = HaloGeom<UPS>;
+    constexpr int BM = 256, BN = 128, WM = 4, WN = 2, NW = 8, TN = 64, FM = 4, FN = 4, FP = 2;
+    constexpr int HW_ = G::HW_, HROWS = G::HROWS, A_IT = G::A_IT, A_BUF = G::A_BUF;
+    constexpr int B_STAGE = BN * 128, B_IT = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const a_lds = smem;
+    char* const b_lds = smem + G::B_OFF;
+    char* const dump = smem + G::DUMP_OFF;
+    float* const s_gn = (float*)(smem + G::GN_OFF);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const bool second_half = wave >= NW / 2;
+    const int a15 = lane & 15;
+
+    const int Ho = p.Ho, Wo = p.Wo, Hi = p.Hi, Wi = p.Wi, Cin = p.Cin;
+    const int tiles_x = (Wo + 15) >> 4, tiles_y = (Ho + 15) >> 4;
+    const int ncols = p.N > p.n_store ? p.N : p.n_store;
+    const int tiles_n = (ncols + BN - 1) / BN;
+    const int sid = xcd_remap(blockIdx.x, tiles_x * tiles_y * p.B * tiles_n);
+    const int nt = sid % tiles_n;
+    int sp = sid / tiles_n;
+    const int tx = sp % tiles_x;
+    sp /= tiles_x;
+    const int ty = sp % tiles_y, b = sp / tiles_y;
+    const int n0 = nt * BN;
+    const int cpt = Cin >> 6;
+
+    // ---- DMA sources -----------------------------------------------------------------------------------------------------------
+    const int sy0 = UPS ? ty * 8 - 1 : ty * 16 - 1, sx0 = UPS ? tx * 8 - 1 : tx * 16 - 1;
+    const bf16_t* h_ptr[A_IT];
+    unsigned h_ok = 0;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int r = (wave + NW * i) * 8 + (lane >> 3);
+        const int hy = r / HW_, hx = r - hy * HW_;
+        const int iy = sy0 + hy, ix = sx0 + hx;
+        const bool ok = r < HROWS && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+        const int chunk = (lane & 7) ^ halo_key<UPS>(hx < HW_ ? hx : 0);
+        h_ptr[i] = p.in + (((long long)b * Hi + iy) * Wi + ix) * Cin + chunk * 8;
+        if (ok) h_ok |= 1u << i;
+    }
+    const bf16_t* zsrc_a = p.zero;
+    const int chunk_w = (lane & 7) ^ (((lane >> 4) & 1) | ((wave & 1) << 1) | (((wave >> 1) & 1) << 2));
+    // weight rows n0 .. n0+127 always exist (launch_conv_halo checks n_rows); wq[i] walks the (chunk, tap) tiles in issue order
+    const bf16_t* wq[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) wq[i] = p.wt + (long long)(n0 + (wave + NW * i) * 8 + (lane >> 3)) * p.ldw + chunk_w * 8;
+    const int w_step = Cin, w_wrap = 64 - 8 * Cin;  // elements: next tap / first tap of the next chunk
+
+    // ---- fused input transform (GroupNorm apply + SiLU), see the first kernel ------------------------------------------------------
+    constexpr int T_IT = (HROWS * 8 + 511) / 512;
+    const bool fused = p.in_scale != nullptr;
+    unsigned t_ok = 0;
+    if (fused) {
+        for (int c = tid; c < Cin; c += 512) {
+            s_gn[c] = p.in_scale[(long long)b * Cin + c];
+            s_gn[GN_MAXC + c] = p.in_shift[(long long)b * Cin + c];
+        }
+#pragma unroll
+        for (int k = 0; k < T_IT; ++k) {
+            const int r = (tid + 512 * k) >> 3;
+            const int hy = r / HW_, hx = r - hy * HW_;
+            if (r < HROWS && (unsigned)(sy0 + hy) < (unsigned)Hi && (unsigned)(sx0 + hx) < (unsigned)Wi) t_ok |= 1u << k;
+        }
+        __syncthreads();
+    }
+    const unsigned a_base = (unsigned)(unsigned long long)a_lds, b_base = (unsigned)(unsigned long long)b_lds;
+    const unsigned gn_base = (unsigned)(unsigned long long)s_gn;
+    auto transform_part = [&](int buf, int cc, int k) {  // part k = 16-byte item tid + 512*k of halo buffer `buf`, channels of chunk cc
+        if (!((t_ok >> k) & 1u)) return;
+        const int item = tid + 512 * k, r = item >> 3;
+        const int ls = ((item & 7) ^ halo_key<UPS>(r % HW_)) << 3;
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        const unsigned a_item = a_base + buf * A_BUF + item * 16;
+        const unsigned a_sc = gn_base + ((cc << 6) + ls) * 4, a_sh = a_sc + GN_MAXC * 4;
+        u32x4_t raw;
+        f4_t s0, s1, h0, h1;
+        asm volatile(
+            "ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\tds_read_b128 %3, %7\n\t"
+            "ds_read_b128 %4, %7 offset:16\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(raw), "=&v"(s0), "=&v"(s1), "=&v"(h0), "=&v"(h1)
+            : "v"(a_item), "v"(a_sc), "v"(a_sh)
+            : "memory");
+        float v[8] = {bflo(raw.x) * s0.x + h0.x, bfhi(raw.x) * s0.y + h0.y, bflo(raw.y) * s0.z + h0.z, bfhi(raw.y) * s0.w + h0.w,
+                      bflo(raw.z) * s1.x + h1.x, bfhi(raw.z) * s1.y + h1.y, bflo(raw.w) * s1.z + h1.z, bfhi(raw.w) * s1.w + h1.w};
+        if (p.in_silu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+        }
+        const u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        asm volatile("ds_write_b128 %0, %1" ::"v"(a_item), "v"(ov) : "memory");
+    };
+
+    auto stage_halo = [&](int buf, int cc) {
+        char* dst = a_lds + buf * A_BUF;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int g = wave + NW * i;
+            const bf16_t* src = ((h_ok >> i) & 1u) ? h_ptr[i] + (cc << 6) : zsrc_a;
+            glds16(src, g < G::GROUPS ? dst + g * 1024 : dump);
+        }
+    };
+    auto stage_w = [&](int slot, bool wrap) {  // next tile in (chunk, tap) order
+        char* dst = b_lds + slot * B_STAGE;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            glds16(wq[i], dst + (wave + NW * i) * 1024);
+            wq[i] += wrap ? w_wrap : w_step;
+        }
+    };
+
+    f32x4_t acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment base addresses (LDS byte offsets) ----------------------------------------------------------------------------------
+    struct Half { bf16x8_t w[FN], x[FM]; };  // fragments of one k-half (32 channels) of one step
+    unsigned xb[3][2], wb[2];
+    {
+        const int xr_w = ((a15 >> 1) & 1) | (((a15 >> 2) & 1) << 1) | (((a15 >> 3) & 1) << 2);
+        const int w_row_off = (wn * TN + 8 * (a15 >> 2) + (a15 & 3)) * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int sl = kk * 4 + (lane >> 4);
+            wb[kk] = b_base + w_row_off + ((sl ^ xr_w) << 4);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int hx = UPS ? ((a15 + kx - 1) >> 1) + 1 : a15 + kx;
+                const int hy0 = UPS ? 2 * wm : 4 * wm;
+                xb[kx][kk] = a_base + (hy0 * HW_ + hx) * 128 + ((sl ^ halo_key<UPS>(hx)) << 4);
+            }
+        }
+    }
+    // k-half KK of step (TAP, halo buffer PAR): every offset below is an immediate
+    auto load_half = [&](Half& f, auto tapc, auto parc, auto kkc) {
+        constexpr int TAP = decltype(tapc)::value, PAR = decltype(parc)::value, KK = decltype(kkc)::value;
+        constexpr int KY = TAP / 3, KX = TAP % 3, SLOT = TAP % 3;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) f.w[i] = lds_frag(wb[KK], SLOT * B_STAGE + (i >> 1) * 4096 + (i & 1) * 512);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int hy = UPS ? ((j + KY - 1) >> 1) + 1 : j + KY;  // relative to the wave's first halo row
+            f.x[j] = lds_frag(xb[KX][KK], PAR * A_BUF + hy * HW_ * 128);
+        }
+    };
+    auto mfma16 = [&](const Half& f) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[i], f.x[j], acc[i][j], 0, 0, 0);
+    };
+    // 16 MFMAs interleaved with 8 LDS reads (2 : 1), pinned
+    auto interleave = [&]() {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+        }
+    };
+
+    // ---- prologue ----------------------------------------------------------------------------------------------------------------------
+    float bcol[FP][8];
+    load_bias_cols<FP>(p, 0, n0 + wn * TN, 8 * (lane >> 4), bcol);
+    stage_halo(0, 0);
+    stage_w(0, false);
+    stage_w(1, false);
+    stage_w(2, false);
+    Half f0, f1a, f1b;  // f0: k-half 0 of the current step; f1a / f1b ping-pong: k-half 1 of the current / next step
+    halo_wait_vm<B_IT>();  // halo 0 and the tiles of taps 0, 1 have landed
+    __builtin_amdgcn_s_barrier();
+    if (fused) {
+#pragma unroll
+        for (int k = 0; k < T_IT; ++k) transform_part(0, 0, k);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    load_half(f0, IC<0>{}, IC<0>{}, IC<0>{});
+    load_half(f1a, IC<0>{}, IC<0>{}, IC<1>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everybody holds its step-0 fragments: ring slot 0 may be refilled (3-deep ring)
+
+    // ---- main loop -------------------------------------------------------------------------------------------------------------------
+    // Invariant at the top of step s = (cc, TAP): the barrier that certified the operands of step s+1 has been passed, f0 / cur1
+    // hold both k-halves of step s, weight tiles up to step s+2 are issued.  The step issues tile s+3 into slot TAP % 3 (its
+    // previous content, tile s, was read during step s-1), at tap 0 the halo of chunk cc+1, and reads the fragments of step s+1.
+    int cc = 0;
+    bool last = cpt == 1;
+    auto kstep = [&](auto tapc, auto parc, Half& cur1, Half& nxt1) {
+        constexpr int TAP = decltype(tapc)::value, PAR = decltype(parc)::value;
+        constexpr int TAP1 = (TAP + 1) % 9, PAR1 = TAP == 8 ? PAR ^ 1 : PAR;
+        const bool issue_w = !(last && TAP >= 6), issue_h = TAP == 0 && !last;
+        if (second_half) {
+            if (issue_w) stage_w(TAP % 3, (TAP + 3) % 9 == 8);
+            if (issue_h) stage_halo(PAR ^ 1, cc + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TAP < 8) {
+            load_half(nxt1, IC<TAP1>{}, IC<PAR1>{}, IC<1>{});
+            mfma16(f0);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            load_half(f0, IC<TAP1>{}, IC<PAR1>{}, IC<0>{});
+            mfma16(cur1);
+            interleave();
+        } else {  // chunk boundary: the next step exists only if another chunk follows (single MFMA site either way)
+            mfma16(f0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!last) {
+                load_half(f0, IC<TAP1>{}, IC<PAR1>{}, IC<0>{});
+                load_half(nxt1, IC<TAP1>{}, IC<PAR1>{}, IC<1>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(cur1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (fused && !last) {  // the halo of chunk cc+1 is complete for everybody from the barrier before tap 3 on; first read in tap 8
+            if (T_IT == 6) {
+                if (TAP == 3) { transform_part(PAR ^ 1, cc + 1, 0); transform_part(PAR ^ 1, cc + 1, 1); }
+                else if (TAP >= 4 && TAP <= 7) transform_part(PAR ^ 1, cc + 1, TAP - 2);
+            } else {
+                if (TAP == 3) transform_part(PAR ^ 1, cc + 1, 0);
+                else if (TAP == 4) transform_part(PAR ^ 1, cc + 1, 1);
+            }
+        }
+        if (!second_half) {
+            if (issue_w) stage_w(TAP % 3, (TAP + 3) % 9 == 8);
+            if (issue_h) stage_halo(PAR ^ 1, cc + 1);
+        }
+        // barrier(s+1): tile s+2 (and every halo issued before it) must have landed; tile s+3 and, while it was issued in
+        // tap 0 of this chunk (i.e. after tile s+2 or s+3 ...), the halo of chunk cc+1 may stay in flight.
+        if (TAP == 8 && last) return;
+        if (TAP <= 1) { if (!last) halo_wait_vm<A_IT + B_IT>(); else halo_wait_vm<B_IT>(); }
+        else if (TAP < 6) halo_wait_vm<B_IT>();
+        else { if (last) halo_wait_vm<0>(); else halo_wait_vm<B_IT>(); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // next step's fragments (and my transform writes) are done
+        __builtin_amdgcn_s_barrier();
+    };
+    auto chunk = [&](auto parc, Half& fa, Half& fb) {
+        kstep(IC<0>{}, parc, fa, fb); kstep(IC<1>{}, parc, fb, fa); kstep(IC<2>{}, parc, fa, fb);
+        kstep(IC<3>{}, parc, fb, fa); kstep(IC<4>{}, parc, fa, fb); kstep(IC<5>{}, parc, fb, fa);
+        kstep(IC<6>{}, parc, fa, fb); kstep(IC<7>{}, parc, fb, fa); kstep(IC<8>{}, parc, fa, fb);
+        ++cc;
+        last = cc + 1 == cpt;
+    };
+    while (true) {
+        chunk(IC<0>{}, f1a, f1b);
+        if (cc == cpt) break;
+        chunk(IC<1>{}, f1b, f1a);
+        if (cc == cpt) break;
+    }
+
+    conv_epilogue<BM, BN, WM, WN, 512>(p, acc, bcol, n0, 0, wave, lane, smem, [&](int pr) {
+        const int oy = ty * 16 + (pr >> 4), ox = tx * 16 + (pr & 15);
+        return (oy < Ho && ox < Wo) ? (b * Ho + oy) * Wo + ox : -1;
+    }, (b * tiles_y + ty) * tiles_x + tx);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Persistent variant: one workgroup per CU walks a list of spatial tiles of ONE image and ONE 128-channel slice, so the (tile,
+// chunk, tap) step stream never stops: the first halo and the first three weight tiles of the next tile are fetched during the
+// last chunk of the current one (they are simply "chunk cc+1"), and the output stores of a tile drain while the next tile
+// computes.  In the one-tile-per-workgroup kernels the prologue (launch, address setup, first HBM round trip) and the epilogue
+// (LDS staging, store drain) were serial with the K loop and with each other: 57 % of the time of a 128->128 layer at 768^2
+// (K = 1152; measured by ablation), which at 604 MB written + 756 MB read per call is also HBM-relevant, not only MFMA work.
+//   * bias, GroupNorm scale/shift and the weight slice are per-workgroup constants (grid = B x J, J a multiple of tiles_n);
+//   * the epilogue is per WAVE: four passes of [16 px][64 ch] fp32 through a private 4 KiB LDS window (the halo buffer the
+//     finished chunk just released), no workgroup barrier; residual rows are prefetched before the first pass;
+//   * GroupNorm partial statistics: per-wave sums -> 4 KiB LDS -> combined after the step barrier that follows.
+template <bool UPS>
+struct Halo3Geom {
+    static constexpr int A_BUF = HaloGeom<UPS>::A_BUF;
+    static constexpr int B_OFF = 2 * A_BUF;
+    static constexpr int DUMP_OFF = B_OFF + 3 * 16384;
+    static constexpr int GN_OFF = DUMP_OFF + 1024;
+    static constexpr int ST_OFF = GN_OFF + 2 * GN_MAXC * 4;  // [8 waves][64 ch][sum, sumsq]
+    static constexpr int BIAS_OFF = ST_OFF + 4096;           // [128] bias of the workgroup's channel slice
+    static constexpr int EP_OFF = BIAS_OFF + 512;            // x2-upsample geometry: its halo buffers are smaller than 32 KiB
+    static constexpr int LDS = UPS ? EP_OFF + 32768 : EP_OFF;
+};
+
+// ABL: compile-time ablations for profiling (1 no epilogue, 2 no MFMA, 4 no output stores, 8 no halo DMA, 16 no weight DMA)
+template <bool UPS, int ABL = 0>
+__global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p) {
+    using G = HaloGeom<UPS>;
+    using G3 = Halo3Geom<UPS>;
+    constexpr int BN = 128, NW = 8, TN = 64, FM = 4, FN = 4, FP = 2;
+    constexpr int HW_ = G::HW_, HROWS = G::HROWS, A_IT = G::A_IT, A_BUF = G::A_BUF;
+    constexpr int B_STAGE = BN * 128, B_IT = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const a_lds = smem;
+    char* const b_lds = smem + G3::B_OFF;
+    char* const dump = smem + G3::DUMP_OFF;
+    float* const s_gn = (float*)(smem + G3::GN_OFF);
+    float* const s_st = (float*)(smem + G3::ST_OFF);
+    float* const s_bias = (float*)(smem + G3::BIAS_OFF);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const bool second_half = wave >= NW / 2;
+    const int a15 = lane & 15;
+
+    const int Ho = p.Ho, Wo = p.Wo, Hi = p.Hi, Wi = p.Wi, Cin = p.Cin;
+    const int tiles_x = (Wo + 15) >> 4, tiles_y = (Ho + 15) >> 4, tiles_sp = tiles_x * tiles_y;
+    const int ncols = p.N > p.n_store ? p.N : p.n_store;
+    const int tiles_n = (ncols + BN - 1) / BN;
+    const int J = gridDim.x / p.B;                  // workgroups per image, a multiple of tiles_n
+    const int b = blockIdx.x / J;
+    int jw = blockIdx.x - b * J;
+    if ((J & 7) == 0) jw = (jw & 7) * (J >> 3) + (jw >> 3);  // workgroups of one XCD (id % 8) take neighbouring tiles
+    const int nt = jw % tiles_n, sp_stride = J / tiles_n;
+    int sp_cur = jw / tiles_n;                       // spatial tile being computed
+    const int n0 = nt * BN;
+    const int cpt = Cin >> 6;
+    const bf16_t* const in_b = p.in + (long long)b * Hi * Wi * Cin;
+
+    // ---- fetch state: the tile whose halo is being staged / normalised (one chunk ahead of the compute) ----------------------------
+    constexpr int T_IT = (HROWS * 8 + 511) / 512;
+    const bool fused = p.in_scale != nullptr;
+    int h_off[A_IT];
+    unsigned h_ok = 0, t_ok = 0;
+    auto setup_fetch = [&](int sp) __attribute__((always_inline)) {
+        const int fty = sp / tiles_x, ftx = sp - fty * tiles_x;
+        const int sy0 = UPS ? fty * 8 - 1 : fty * 16 - 1, sx0 = UPS ? ftx * 8 - 1 : ftx * 16 - 1;
+        h_ok = 0;
+        t_ok = 0;
+        int lane_o = lane, tid_o = tid;
+        asm volatile("" : "+v"(lane_o), "+v"(tid_o));  // opaque (see epilogue)
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int r = (wave + NW * i) * 8 + (lane_o >> 3);
+            const int hy = r / HW_, hx = r - hy * HW_;
+            const int iy = sy0 + hy, ix = sx0 + hx;
+            const bool ok = r < HROWS && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+            h_off[i] = (iy * Wi + ix) * Cin + (((lane_o & 7) ^ halo_key<UPS>(hx)) << 3);
+            if (ok) h_ok |= 1u << i;
+        }
+        if (fused) {
+#pragma unroll
+            for (int k = 0; k < T_IT; ++k) {
+                const int r = (tid_o + 512 * k) >> 3;
+                const int hy = r / HW_, hx = r - hy * HW_;
+                if (r < HROWS && (unsigned)(sy0 + hy) < (unsigned)Hi && (unsigned)(sx0 + hx) < (unsigned)Wi) t_ok |= 1u << k;
+            }
+        }
+    };
+    const bf16_t* zsrc_a = p.zero;
+    const int chunk_w = (lane & 7) ^ (((lane >> 4) & 1) | ((wave & 1) << 1) | (((wave >> 1) & 1) << 2));
+    const bf16_t* wq[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) wq[i] = p.wt + (long long)(n0 + (wave + NW * i) * 8 + (lane >> 3)) * p.ldw + chunk_w * 8;
+    const int w_step = Cin, w_wrap = 64 - 8 * Cin, w_tile_wrap = -8 * Cin - (cpt - 1) * 64;  // next tap / next chunk / first tile again
+
+    if (fused) {
+        for (int c = tid; c < Cin; c += 512) {
+            s_gn[c] = p.in_scale[(long long)b * Cin + c];
+            s_gn[GN_MAXC + c] = p.in_shift[(long long)b * Cin + c];
+        }
+        __syncthreads();
+    }
+    const unsigned a_base = (unsigned)(unsigned long long)a_lds, b_base = (unsigned)(unsigned long long)b_lds;
+    const unsigned gn_base = (unsigned)(unsigned long long)s_gn;
+    auto transform_part = [&](int buf, int cc, int k) __attribute__((always_inline)) {
+        if (!((t_ok >> k) & 1u)) return;
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));  // opaque: recompute the few address values here instead of carrying them through the loop
+        const int item = tid_o + 512 * k, r = item >> 3;
+        const int ls = ((item & 7) ^ halo_key<UPS>(r % HW_)) << 3;
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        const unsigned a_item = a_base + buf * A_BUF + item * 16;
+        const unsigned a_sc = gn_base + ((cc << 6) + ls) * 4, a_sh = a_sc + GN_MAXC * 4;
+        u32x4_t raw;
+        f4_t s0, s1, h0, h1;
+        asm volatile(
+            "ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\tds_read_b128 %3, %7\n\t"
+            "ds_read_b128 %4, %7 offset:16\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(raw), "=&v"(s0), "=&v"(s1), "=&v"(h0), "=&v"(h1)
+            : "v"(a_item), "v"(a_sc), "v"(a_sh)
+            : "memory");
+        float v[8] = {bflo(raw.x) * s0.x + h0.x, bfhi(raw.x) * s0.y + h0.y, bflo(raw.y) * s0.z + h0.z, bfhi(raw.y) * s0.w + h0.w,
+                      bflo(raw.z) * s1.x + h1.x, bfhi(raw.z) * s1.y + h1.y, bflo(raw.w) * s1.z + h1.z, bfhi(raw.w) * s1.w + h1.w};
+        if (p.in_silu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+        }
+        const u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        asm volatile("ds_write_b128 %0, %1" ::"v"(a_item), "v"(ov) : "memory");
+    };
+    auto stage_halo = [&](int buf, int cc) __attribute__((always_inline)) {
+        char* dst = a_lds + buf * A_BUF;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int g = wave + NW * i;
+            const bf16_t* src = ((h_ok >> i) & 1u) ? in_b + (h_off[i] + (cc << 6)) : zsrc_a;
+            if (!(ABL & 8)) glds16(src, g < G::GROUPS ? dst + g * 1024 : dump);
+        }
+    };
+    auto stage_w = [&](int slot, int adv) __attribute__((always_inline)) {  // next weight tile in (tile, chunk, tap) order, then advance by `adv` elements
+        char* dst = b_lds + slot * B_STAGE;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            if (!(ABL & 16)) glds16(wq[i], dst + (wave + NW * i) * 1024);
+            wq[i] += adv;
+        }
+    };
+
+    f32x4_t acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    struct Half { bf16x8_t w[FN], x[FM]; };
+    unsigned xb[3][2], wb[2];
+    {
+        const int xr_w = ((a15 >> 1) & 1) | (((a15 >> 2) & 1) << 1) | (((a15 >> 3) & 1) << 2);
+        const int w_row_off = (wn * TN + 8 * (a15 >> 2) + (a15 & 3)) * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int sl = kk * 4 + (lane >> 4);
+            wb[kk] = b_base + w_row_off + ((sl ^ xr_w) << 4);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int hx = UPS ? ((a15 + kx - 1) >> 1) + 1 : a15 + kx;
+                const int hy0 = UPS ? 2 * wm : 4 * wm;
+                xb[kx][kk] = a_base + (hy0 * HW_ + hx) * 128 + ((sl ^ halo_key<UPS>(hx)) << 4);
+            }
+        }
+    }
+    auto load_half = [&](Half& f, auto tapc, auto parc, auto kkc) __attribute__((always_inline)) {
+        constexpr int TAP = decltype(tapc)::value, PAR = decltype(parc)::value, KK = decltype(kkc)::value;
+        constexpr int KY = TAP / 3, KX = TAP % 3, SLOT = TAP % 3;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) f.w[i] = lds_frag(wb[KK], SLOT * B_STAGE + (i >> 1) * 4096 + (i & 1) * 512);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int hy = UPS ? ((j + KY - 1) >> 1) + 1 : j + KY;
+            f.x[j] = lds_frag(xb[KX][KK], PAR * A_BUF + hy * HW_ * 128);
+        }
+    };
+    auto mfma16 = [&](const Half& f) __attribute__((always_inline)) {
+        if (ABL & 2) {  // keep the fragment reads alive
+            asm volatile("" ::"v"(f.w[0]), "v"(f.w[1]), "v"(f.w[2]), "v"(f.w[3]), "v"(f.x[0]), "v"(f.x[1]), "v"(f.x[2]), "v"(f.x[3]));
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[i], f.x[j], acc[i][j], 0, 0, 0);
+    };
+    auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    };
+
+    // bias of this workgroup's 128 channels: LDS (512 B in the dump KiB's tail is not free -> own slot after the statistics)
+    if (tid < BN) s_bias[tid] = (p.bias && p.bias_mode == GP_BIAS_COL && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+    __syncthreads();
+
+    // ---- per-wave epilogue of the finished tile (sp_cur); `stg` = 4 KiB private LDS window ---------------------------------------------
+    const int n_out = p.N;
+    const bool want_stats = p.stats_out != nullptr;
+    // All LDS traffic below goes through integer-addressed address_space(3) accesses (like lds_frag): accesses the compiler can
+    // trace back to `smem` make it wait for vmcnt(0) first (possible alias with an LDS-DMA in flight), i.e. for the residual
+    // loads just issued and for the previous pass's stores -- four exposed HBM round trips per tile when measured.
+    // Launch-time guarantees (launch_conv_halo): n_store, ldo (and ldres) multiples of 8, so every 8-channel slot is stored whole.
+    typedef __attribute__((address_space(3))) f32x4_t* lds_f4_ptr;
+    typedef __attribute__((address_space(3))) float* lds_f_ptr;
+    const unsigned st_base = (unsigned)(unsigned long long)s_st, bias_base = (unsigned)(unsigned long long)s_bias;
+    // Specialised at compile time on (activation present, residual present, statistics wanted): with run-time checks per element
+    // the epilogue was ~2000 VALU + 130 scalar branches per wave and tile, as much SIMD time as the 18 K-steps of a K = 1152 layer.
+    auto epilogue_body = [&](unsigned stg, auto actc, auto resc, auto statc) __attribute__((always_inline)) {
+        constexpr bool ACT = decltype(actc)::value != 0, RES = decltype(resc)::value != 0, STATS = decltype(statc)::value != 0;
+        const int ty = sp_cur / tiles_x, tx = sp_cur - ty * tiles_x;
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));  // opaque copy: keeps the address arithmetic below inside the epilogue (hoisted out of the
+                                          // tile loop it occupied ~40 VGPRs for the whole K loop and pushed the kernel into spills)
+        const int q = lane_o >> 4, a15 = lane_o & 15;
+        const int pl = lane_o >> 3, sl8 = lane_o & 7;      // read-back role: pixels pl and pl + 8 of a tile row, channel slot sl8
+        const int col = n0 + wn * TN + 8 * sl8;
+        const bool col_ok = col < p.n_store;
+        const bool tail = col + 7 >= n_out;                // slot reaches into the zero-padded channels
+        bf16_t* outp = (bf16_t*)p.out;
+        int m2[FM][2];
+        uint4 rv[FM][2];
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // residual rows first: their latency hides under the LDS round trips
+                const int oy = ty * 16 + 4 * wm + j, ox = tx * 16 + pl + 8 * h;
+                m2[j][h] = (oy < Ho && ox < Wo && col_ok) ? (b * Ho + oy) * Wo + ox : -1;
+                if (RES) {
+                    rv[j][h] = make_uint4(0u, 0u, 0u, 0u);
+                    if (m2[j][h] >= 0 && p.res) rv[j][h] = *(const uint4*)(p.res + (long long)m2[j][h] * p.ldres + col);
+                }
+            }
+        f32x4_t bv[FP][2];
+#pragma unroll
+        for (int ip = 0; ip < FP; ++ip) {
+            bv[ip][0] = *(lds_f4_ptr)(bias_base + (wn * TN + 32 * ip + 8 * q) * 4);
+            bv[ip][1] = *(lds_f4_ptr)(bias_base + (wn * TN + 32 * ip + 8 * q) * 4 + 16);
+        }
+        float st_s[8], st_q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+#pragma unroll
+            for (int ip = 0; ip < FP; ++ip) {
+                const unsigned d = stg + (a15 * 64 + (((4 * ip + q) ^ (a15 & 7)) << 3)) * 4;
+                *(lds_f4_ptr)d = acc[2 * ip][j] + bv[ip][0];
+                *(lds_f4_ptr)(d + 16) = acc[2 * ip + 1][j] + bv[ip][1];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pr = pl + 8 * h;
+                const unsigned sa = stg + (pr * 64 + ((sl8 ^ (pr & 7)) << 3)) * 4;
+                const f32x4_t x0 = *(lds_f4_ptr)sa, x1 = *(lds_f4_ptr)(sa + 16);
+                const long long m = m2[j][h];
+                if (m >= 0) {
+                    float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    if (RES) {
+                        const uint4 r4 = rv[j][h];
+                        v[0] += bflo(r4.x); v[1] += bfhi(r4.x); v[2] += bflo(r4.y); v[3] += bfhi(r4.y);
+                        v[4] += bflo(r4.z); v[5] += bfhi(r4.z); v[6] += bflo(r4.w); v[7] += bfhi(r4.w);
+                    }
+                    if (ACT) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (p.act == GP_ACT_SILU) v[e] = silu_f(v[e]);
+                            else if (p.act == GP_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                        }
+                    }
+                    if (tail) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (col + e >= n_out) v[e] = 0.f;
+                    }
+                    uint4 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+                    if (!(ABL & 4)) *(uint4*)(outp + m * p.ldo + col) = pk;
+                    else asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
+                    if (STATS) {
+                        const float r[8] = {bflo(pk.x), bfhi(pk.x), bflo(pk.y), bfhi(pk.y), bflo(pk.z), bfhi(pk.z), bflo(pk.w), bfhi(pk.w)};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { st_s[e] += r[e]; st_q[e] += r[e] * r[e]; }
+                    }
+                }
+            }
+        }
+        if (STATS) {
+#pragma unroll
+            for (int off = 32; off >= 8; off >>= 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { st_s[e] += __shfl_xor(st_s[e], off); st_q[e] += __shfl_xor(st_q[e], off); }
+            }
+            if (lane_o < 8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    *(lds_f_ptr)(st_base + ((wave * 64 + 8 * lane_o + e) * 2) * 4) = st_s[e];
+                    *(lds_f_ptr)(st_base + ((wave * 64 + 8 * lane_o + e) * 2 + 1) * 4) = st_q[e];
+                }
+            }
+        }
+    };
+    const int ep_variant = (p.act != GP_ACT_NONE ? 4 : 0) | (p.res ? 2 : 0) | (want_stats ? 1 : 0);
+    auto epilogue = [&](unsigned stg) __attribute__((always_inline)) {
+        switch (ep_variant) {
+            case 0: epilogue_body(stg, IC<0>{}, IC<0>{}, IC<0>{}); break;
+            case 1: epilogue_body(stg, IC<0>{}, IC<0>{}, IC<1>{}); break;
+            case 2: epilogue_body(stg, IC<0>{}, IC<1>{}, IC<0>{}); break;
+            case 3: epilogue_body(stg, IC<0>{}, IC<1>{}, IC<1>{}); break;
+            default: epilogue_body(stg, IC<1>{}, IC<1>{}, IC<1>{}); break;  // (rare: activation fused into a halo conv)
+        }
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    };
+    auto flush_stats = [&](int tile_row) __attribute__((always_inline)) {  // after a workgroup barrier that follows epilogue(): waves (wm, wn) -> channel sums
+        if (tid < BN && n0 + tid < n_out) {
+            // (inline asm: a compiler-visible LDS read here would make hipcc drain the DMA ring first, see transform_part)
+            const unsigned a = st_base + (unsigned)tid * 8u;  // [(wm * 2 + wn) * 64 + ch][2] floats, tid = wn * 64 + ch
+            f32x2_t v0, v1, v2, v3;
+            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:1024\n\tds_read_b64 %2, %4 offset:2048\n\t"
+                         "ds_read_b64 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
+            float* so = p.stats_out + ((long long)tile_row * p.N + n0 + tid) * 2;
+            so[0] = ((v0.x + v1.x) + v2.x) + v3.x;
+            so[1] = ((v0.y + v1.y) + v2.y) + v3.y;
+        }
+    };
+
+    // ---- prologue (first tile) ---------------------------------------------------------------------------------------------------------
+    setup_fetch(sp_cur);
+    stage_halo(0, 0);
+    stage_w(0, w_step);
+    stage_w(1, w_step);
+    stage_w(2, w_step);
+    Half f0, f1a, f1b;
+    halo_wait_vm<B_IT>();
+    __builtin_amdgcn_s_barrier();
+    if (fused) {
+#pragma unroll
+        for (int k = 0; k < T_IT; ++k) transform_part(0, 0, k);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    load_half(f0, IC<0>{}, IC<0>{}, IC<0>{});
+    load_half(f1a, IC<0>{}, IC<0>{}, IC<1>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- main loop over (tile, chunk), nine unrolled taps each --------------------------------------------------------------------------
+    int cc = 0;
+    bool tile_end = cpt == 1;                                    // this chunk is the last of its tile
+    bool final_ = tile_end && sp_cur + sp_stride >= tiles_sp;    // ... and of the workgroup
+    auto kstep = [&](auto tapc, auto parc, Half& cur1, Half& nxt1) __attribute__((always_inline)) {
+        constexpr int TAP = decltype(tapc)::value, PAR = decltype(parc)::value;
+        constexpr int TAP1 = (TAP + 1) % 9, PAR1 = TAP == 8 ? PAR ^ 1 : PAR;
+        const bool issue_w = !(final_ && TAP >= 6), issue_h = TAP == 0 && !final_;
+        const int fcc = tile_end ? 0 : cc + 1;  // chunk (of the fetch tile) staged at tap 0 and normalised in taps 3..7
+        const int adv = (TAP + 3) % 9 == 8 ? (tile_end ? w_tile_wrap : w_wrap) : w_step;
+        if (second_half) {
+            if (issue_w) stage_w(TAP % 3, adv);
+            if (issue_h) stage_halo(PAR ^ 1, fcc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TAP < 8) {
+            load_half(nxt1, IC<TAP1>{}, IC<PAR1>{}, IC<1>{});
+            mfma16(f0);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            load_half(f0, IC<TAP1>{}, IC<PAR1>{}, IC<0>{});
+            mfma16(cur1);
+            interleave();
+        } else {
+            mfma16(f0);
+            mfma16(cur1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tile_end) {
+                halo_wait_vm<0>();  // everything this wave has in flight has landed: stores issued below cannot delay a certification
+                if (!(ABL & 1)) epilogue((UPS ? a_base + G3::EP_OFF : a_base + PAR * A_BUF) + wave * 4096);
+                else if (tid == 0 && acc[0][0][0] == 1.2345f) ((float*)p.out)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];
+            }
+            if (!final_) {
+                load_half(f0, IC<TAP1>{}, IC<PAR1>{}, IC<0>{});
+                load_half(nxt1, IC<TAP1>{}, IC<PAR1>{}, IC<1>{});
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (fused && !final_) {
+            if (T_IT == 6) {
+                if (TAP == 3) { transform_part(PAR ^ 1, fcc, 0); transform_part(PAR ^ 1, fcc, 1); }
+                else if (TAP >= 4 && TAP <= 7) transform_part(PAR ^ 1, fcc, TAP - 2);
+            } else {
+                if (TAP == 3) transform_part(PAR ^ 1, fcc, 0);
+                else if (TAP == 4) transform_part(PAR ^ 1, fcc, 1);
+            }
+        }
+        if (!second_half) {
+            if (issue_w) stage_w(TAP % 3, adv);
+            if (issue_h) stage_halo(PAR ^ 1, fcc);
+        }
+        if (TAP == 8 && final_) return;
+        if (TAP <= 1) { if (!final_) halo_wait_vm<A_IT + B_IT>(); else halo_wait_vm<B_IT>(); }
+        else if (TAP < 6) halo_wait_vm<B_IT>();
+        else if (TAP < 8) { if (final_) halo_wait_vm<0>(); else halo_wait_vm<B_IT>(); }
+        else if (!tile_end) halo_wait_vm<B_IT>();  // (tile end: certified by the vmcnt(0) ahead of the epilogue)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto chunk = [&](auto parc, Half& fa, Half& fb) __attribute__((always_inline)) {
+        if (tile_end && !final_) setup_fetch(sp_cur + sp_stride);  // from here on halo staging / normalisation belong to the next tile
+        kstep(IC<0>{}, parc, fa, fb); kstep(IC<1>{}, parc, fb, fa); kstep(IC<2>{}, parc, fa, fb);
+        kstep(IC<3>{}, parc, fb, fa); kstep(IC<4>{}, parc, fa, fb); kstep(IC<5>{}, parc, fb, fa);
+        kstep(IC<6>{}, parc, fa, fb); kstep(IC<7>{}, parc, fb, fa); kstep(IC<8>{}, parc, fa, fb);
+        if (tile_end) {
+            if (want_stats) {
+                if (final_) __syncthreads();  // (nothing in flight any more)
+                flush_stats(b * tiles_sp + sp_cur);
+            }
+            sp_cur += sp_stride;
+            cc = 0;
+        } else {
+            ++cc;
+        }
+        tile_end = cc == cpt - 1;
+        final_ = tile_end && sp_cur + sp_stride >= tiles_sp;
+    };
+    while (true) {
+        chunk(IC<0>{}, f1a, f1b);
+        if (sp_cur >= tiles_sp) break;
+        chunk(IC<1>{}, f1b, f1a);
+        if (sp_cur >= tiles_sp) break;
+    }
+}
+
 bool conv_halo_applicable(const IGemmParams& p) {
     if (p.ks != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.batch > 1 || p.out_fp32 || p.act == GP_ACT_GEGLU) return false;
     if (p.bias_mode == GP_BIAS_ROW || (p.ldo & 7)) return false;
@@ -328,12 +1058,48 @@ void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<true>::LDS);
         attr = true;
     }
-    const bool pipe = (p.dbg & 128) == 0;  // default on: measured 17 % faster in within-process A/B (dbg bit 128 turns it off)
-    if (p.ups) {
-        if (pipe) hipLaunchKernelGGL((conv3x3_halo_kernel<true, true>), dim3(tiles), dim3(512), HaloGeom<true>::LDS, s, p);
-        else hipLaunchKernelGGL((conv3x3_halo_kernel<true, false>), dim3(tiles), dim3(512), HaloGeom<true>::LDS, s, p);
-    } else {
-        if (pipe) hipLaunchKernelGGL((conv3x3_halo_kernel<false, true>), dim3(tiles), dim3(512), HaloGeom<false>::LDS, s, p);
-        else hipLaunchKernelGGL((conv3x3_halo_kernel<false, false>), dim3(tiles), dim3(512), HaloGeom<false>::LDS, s, p);
+    static bool attr2 = false;
+    if (!attr2) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<false>::LDS);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<true>::LDS);
+        attr2 = true;
     }
+    const bool rows_ok = ((ncols + 127) / 128) * 128 <= p.n_rows;  // the unrolled kernels read whole 128-row weight tiles
+    const bool slots_ok = (p.n_store & 7) == 0 && (p.ldo & 7) == 0 && (!p.res || ((p.ldres & 7) == 0 && p.ldres >= p.n_store));
+    if (rows_ok && slots_ok && !(p.dbg & (128 | 256))) {
+        // persistent kernel: B x J workgroups, J = workgroups per image (a multiple of tiles_n, about #CU / B)
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0;
+            hipDeviceProp_t pr;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+            if (ncu <= 0) ncu = 256;
+            (void)hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo3Geom<false>::LDS);
+            (void)hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo3Geom<true>::LDS);
+        }
+        const int tiles_n = (ncols + 127) / 128, tiles_sp = ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
+        int per_img = ncu / p.B;
+        if (per_img < 1) per_img = 1;
+        int J = (per_img / tiles_n) * tiles_n;
+        if (J < tiles_n) J = tiles_n;
+        if (J > tiles_sp * tiles_n) J = tiles_sp * tiles_n;
+        if (p.ups) hipLaunchKernelGGL((conv3x3_halo3_kernel<true>), dim3(p.B * J), dim3(512), Halo3Geom<true>::LDS, s, p);
+        else {
+            switch ((p.dbg >> 9) & 31) {  // profiling ablations (GENPERCEPT_IGEMM_DBG = 512 * ABL)
+#define GP_H3_ABL(A) case A: { static bool at = false; if (!at) { (void)hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<false, A>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo3Geom<false>::LDS); at = true; } \
+                hipLaunchKernelGGL((conv3x3_halo3_kernel<false, A>), dim3(p.B * J), dim3(512), Halo3Geom<false>::LDS, s, p); break; }
+                GP_H3_ABL(1) GP_H3_ABL(2) GP_H3_ABL(3) GP_H3_ABL(4) GP_H3_ABL(8) GP_H3_ABL(16) GP_H3_ABL(24) GP_H3_ABL(26)
+#undef GP_H3_ABL
+                default: hipLaunchKernelGGL((conv3x3_halo3_kernel<false>), dim3(p.B * J), dim3(512), Halo3Geom<false>::LDS, s, p);
+            }
+        }
+        return;
+    }
+    if (rows_ok && !(p.dbg & 128)) {  // dbg bit 256: one tile per workgroup; bit 128: first-generation kernel (A/B measurements)
+        if (p.ups) hipLaunchKernelGGL((conv3x3_halo2_kernel<true>), dim3(tiles), dim3(512), HaloGeom<true>::LDS, s, p);
+        else hipLaunchKernelGGL((conv3x3_halo2_kernel<false>), dim3(tiles), dim3(512), HaloGeom<false>::LDS, s, p);
+        return;
+    }
+    if (p.ups) hipLaunchKernelGGL((conv3x3_halo_kernel<true, true>), dim3(tiles), dim3(512), HaloGeom<true>::LDS, s, p);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<false, true>), dim3(tiles), dim3(512), HaloGeom<false>::LDS, s, p);
 }

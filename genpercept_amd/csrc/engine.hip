@@ -1332,6 +1332,40 @@ gp_status gp_conv2d_gn(const void* in, const void* w_packed, const float* bias, 
     } catch (...) { return GP_ERR_HIP; }
 }
 
+gp_status gp_conv2d_stats(const void* in, const void* w_packed, const float* bias, const void* residual, void* out, int B, int H, int W, int Cin,
+                          int Cout, int ks, int ups, int tile_hint, const float* gamma, const float* beta, int groups, float eps,
+                          float* scale_out, float* shift_out, void* stream) {
+    if (!in || !w_packed || !out || !gamma || !beta || !scale_out || !shift_out || (Cin % 64) || (ks != 1 && ks != 3) || groups < 1 || (Cout % groups))
+        return GP_ERR_INVALID;
+    try {
+        const int Ho = ups ? 2 * H : H, Wo = ups ? 2 * W : W;
+        IGemmParams p{};
+        p.in = (const bf16_t*)in; p.wt = (const bf16_t*)w_packed; p.bias = bias; p.res = (const bf16_t*)residual; p.out = out; p.zero = zero_page();
+        p.M = B * Ho * Wo; p.N = Cout; p.Cin = Cin; p.n_rows = gp_packed_rows(Cout); p.ks = ks;
+        p.B = B; p.Hi = H; p.Wi = W; p.Ho = Ho; p.Wo = Wo; p.stride = 1; p.pad_t = ks == 3; p.pad_l = ks == 3;
+        p.ups = ups ? 1 : 0; p.Hu = ups ? Ho : 0; p.Wu = ups ? Wo : 0;
+        p.lda = Cin; p.ldo = Cout; p.ldres = Cout; p.ldw = (ks == 3 ? 9 : 1) * Cin; p.n_store = Cout;
+        p.bias_mode = bias ? GP_BIAS_COL : GP_BIAS_NONE; p.batch = 1;
+        if (const char* dbg = getenv("GENPERCEPT_IGEMM_DBG")) p.dbg = atoi(dbg);
+        int mode = 0, bm = 0;
+        const int nt = igemm_tile_info(p, tile_hint, &mode, &bm);
+        if (nt <= 0) return GP_ERR_INVALID;
+        const size_t need = (size_t)nt * Cout * 2;
+        static float* part = nullptr;
+        static size_t part_floats = 0;
+        if (need > part_floats) {
+            if (part) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(part)); }
+            HIPCHK(hipMalloc((void**)&part, need * 4));
+            part_floats = need;
+        }
+        p.stats_out = part;
+        launch_igemm(p, tile_hint, (hipStream_t)stream);
+        launch_groupnorm_from_partials(part, mode, bm, B, Ho, Wo, Cout, groups, eps, gamma, beta, scale_out, shift_out, (hipStream_t)stream);
+        HIPCHK(hipGetLastError());
+        return GP_OK;
+    } catch (...) { return GP_ERR_HIP; }
+}
+
 gp_status gp_gemm(const void* a, int lda, const void* bt, int ldb, const float* bias, int bias_mode, const void* residual, int ldres, void* out,
                   int ldo, int M, int N, int K, int n_rows_bt, int n_store, int act, int out_fp32, int batch, long long a_bs, long long bt_bs,
                   long long out_bs, int tile_hint, void* stream) {

@@ -70,6 +70,7 @@ SYMBOLS = {
     "gp_pack_weight": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "gp_conv2d": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 17 + [_vp]),
     "gp_conv2d_gn": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 7 + [_vp, _vp, _i, _f, _i, _vp]),
+    "gp_conv2d_stats": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp, _vp, _i, _f, _vp, _vp, _vp]),
     "gp_gemm": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
     "gp_groupnorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "gp_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
@@ -327,6 +328,22 @@ def conv2d_gn(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, gam
     if st != GP_OK:
         raise RuntimeError(f"gp_conv2d_gn failed ({st})")
     return out
+
+
+def conv2d_stats(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, ks: int, gamma: torch.Tensor, beta: torch.Tensor, groups: int,
+                 eps: float, ups: bool = False, residual=None, tile: int = 0):
+    """conv whose epilogue leaves the GroupNorm statistics of its output; returns (out, scale[b][c], shift[b][c])."""
+    lib = load_library()
+    b, h, w, cin = x_nhwc.shape
+    ho, wo = (2 * h, 2 * w) if ups else (h, w)
+    out = torch.empty((b, ho, wo, cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    scale = torch.empty((b, cout), dtype=torch.float32, device=x_nhwc.device)
+    shift = torch.empty((b, cout), dtype=torch.float32, device=x_nhwc.device)
+    st = lib.gp_conv2d_stats(x_nhwc.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), b, h, w, cin, cout, ks, int(ups),
+                             tile, gamma.data_ptr(), beta.data_ptr(), groups, eps, scale.data_ptr(), shift.data_ptr(), _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_conv2d_stats failed ({st})")
+    return out, scale, shift
 
 
 def gemm(a: torch.Tensor, bt: torch.Tensor, bias=None, bias_mode: int = 1, residual=None, act: str = "none", out_fp32: bool = False,

@@ -114,6 +114,14 @@ gp_status gp_conv2d(const void* in, const void* w_packed, const float* bias, con
  * stride 1, pad 1, optional nearest x2 upsample of the normalised input; H, W >= 16 (x2: >= 8). */
 gp_status gp_conv2d_gn(const void* in, const void* w_packed, const float* bias, const void* residual, void* out, int B, int H, int W, int Cin,
                        int Cout, int ups, int act, const float* gamma, const float* beta, int groups, float eps, int silu, void* stream);
+/* conv (3x3 pad 1 or 1x1, stride 1, optional nearest x2 upsample) whose epilogue also leaves the GroupNorm statistics of the tensor it
+ * writes (per-tile channel sums), finalised to the affine form the next GroupNorm applies: scale[b][c] = gamma[c] * rstd[b][g(c)],
+ * shift[b][c] = beta[c] - mean[b][g(c)] * scale[b][c].  This is how the engine skips the statistics read pass of
+ * diffusers' ResnetBlock2D.norm2 / the following block's norm1 (resnet.py forward: norm -> nonlinearity -> conv).
+ * Returns GP_ERR_INVALID when the selected kernel cannot produce statistics for this shape. */
+gp_status gp_conv2d_stats(const void* in, const void* w_packed, const float* bias, const void* residual, void* out, int B, int H, int W, int Cin,
+                          int Cout, int ks, int ups, int tile_hint, const float* gamma, const float* beta, int groups, float eps,
+                          float* scale_out, float* shift_out, void* stream);
 /* out[M][N] = A[M][K] * Bt[N][K]^T (+bias per column / per row), batched over `batch` with element strides. */
 gp_status gp_gemm(const void* a, int lda, const void* bt, int ldb, const float* bias, int bias_mode, const void* residual, int ldres, void* out,
                   int ldo, int M, int N, int K, int n_rows_bt, int n_store, int act, int out_fp32, int batch, long long a_bs, long long bt_bs,

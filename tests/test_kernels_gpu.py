@@ -106,6 +106,47 @@ def test_conv3x3_halo_kernel(case, metric_log):
     check(f"conv_halo{case}", nhwc_to_nchw(y), ref, metric_log)
 
 
+@pytest.mark.parametrize("case", [
+    # (B, H, W, Cin, Cout, ks, ups, residual, tile hint): halo kernels (5: persistent, several tiles per workgroup when B*tiles > #CU) and
+    # the generic implicit GEMM (0 -> heuristic tile, 1 = 128x128, 4 = 256x128)
+    (2, 32, 32, 128, 128, 3, False, True, 5), (1, 40, 24, 64, 192, 3, False, False, 5), (4, 144, 160, 64, 128, 3, False, True, 5),
+    (1, 24, 24, 128, 128, 3, True, True, 5), (3, 112, 112, 64, 256, 3, False, False, 5),
+    (2, 32, 32, 128, 128, 3, False, True, 4), (2, 32, 32, 128, 256, 1, False, True, 1), (1, 16, 16, 320, 320, 3, False, False, 0),
+])
+def test_conv_epilogue_groupnorm_statistics(case, metric_log):
+    """GroupNorm statistics accumulated in the conv epilogue (per-tile channel sums of the bf16 values as stored) and finalised to
+    scale/shift: must equal the statistics of the tensor the conv wrote (diffusers resnet.py: norm2(conv1(...)) etc.)."""
+    e = _eng()
+    b, h, w, cin, cout, ks, ups, with_res, tile = case
+    groups, eps = 32, 1e-6
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = rbf(torch.randn(b, cin, h, w, generator=g))
+    wt = rbf(torch.randn(cout, cin, ks, ks, generator=g) / math.sqrt(cin * ks * ks))
+    bias = torch.randn(cout, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(cout, generator=g), 0.3 * torch.randn(cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    ref = F.conv2d(xin, wt, bias, padding=ks // 2)
+    res = rbf(torch.randn(ref.shape, generator=g)) if with_res else None
+    if with_res:
+        ref = ref + res
+    d = _dev()
+    y, scale, shift = e.conv2d_stats(e.to_nhwc_bf16(x.to(d)), e.pack_weight(wt, device=d), bias.to(d), cout, ks, gamma.to(d), beta.to(d), groups, eps,
+                                     ups=ups, residual=e.to_nhwc_bf16(res.to(d)) if with_res else None, tile=tile)
+    check(f"conv_stats_out{case}", nhwc_to_nchw(y), ref, metric_log)
+    # statistics of exactly what was stored
+    ys = nhwc_to_nchw(y).float().cpu()
+    yg = ys.reshape(b, groups, -1)
+    mean, var = yg.mean(dim=2), yg.var(dim=2, unbiased=False)
+    rstd = (var + eps).rsqrt()
+    cpg = cout // groups
+    sc_ref = gamma[None, :] * rstd.repeat_interleave(cpg, dim=1)
+    sh_ref = beta[None, :] - mean.repeat_interleave(cpg, dim=1) * sc_ref
+    e_sc = ((scale.cpu() - sc_ref).abs() / sc_ref.abs().clamp_min(1e-3)).max().item()
+    e_sh = (shift.cpu() - sh_ref).abs().max().item()
+    metric_log(f"conv_stats{case}", scale_rel=e_sc, shift_abs=e_sh)
+    assert e_sc < 2e-4 and e_sh < 2e-4, (e_sc, e_sh)
+
+
 @pytest.mark.parametrize("case", [(2, 32, 32, 128, 128, False, True), (1, 40, 24, 320, 192, False, True), (2, 16, 16, 64, 128, False, False),
                                   (1, 12, 16, 256, 128, True, True), (1, 17, 21, 960, 64, False, True)])
 def test_conv3x3_fused_groupnorm_input(case, metric_log):
