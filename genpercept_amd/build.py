@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgenpercept_hip.so")
-SOURCES = ["igemm.hip", "conv_halo.hip", "norm.hip", "attention.hip", "elementwise.hip", "engine.hip"]
+SOURCES = ["igemm.hip", "conv_halo.hip", "pgemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

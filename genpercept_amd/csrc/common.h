@@ -53,3 +53,22 @@ GP_DEV int xcd_remap(int bid, int nwg) {
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
+
+template <int N>
+GP_DEV void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// compile-time integer tag (generic lambdas instantiated per tap / ring slot / parity)
+template <int V>
+struct IC { static constexpr int value = V; };
+
+// LDS accesses through INTEGER byte addresses: (a) a constant added to the address becomes the instruction's immediate offset,
+// (b) hipcc does not treat them as possibly aliasing an LDS-DMA in flight (accesses it can trace to the `extern __shared__` array
+// make it wait for vmcnt(0) first).  Ordering against the DMA ring is therefore entirely the kernel's business.
+typedef const __attribute__((address_space(3))) bf16x8_t* lds_frag_ptr;
+typedef __attribute__((address_space(3))) f32x4_t* lds_f4_ptr;
+typedef __attribute__((address_space(3))) float* lds_f_ptr;
+GP_DEV bf16x8_t lds_frag(unsigned base, int imm) { return *(lds_frag_ptr)(base + (unsigned)imm); }
+
+// one group of the scheduler's instruction pattern (masks: 0x002 VALU, 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x400 transcendental)
+template <int MASK, int N>
+GP_DEV void sgb() { __builtin_amdgcn_sched_group_barrier(MASK, N, 0); }

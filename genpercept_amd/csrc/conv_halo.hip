@@ -21,7 +21,7 @@
 #include "kernels.h"
 
 template <int N>
-GP_DEV void halo_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+GP_DEV void halo_wait_vm() { wait_vm<N>(); }
 
 constexpr int GN_MAXC = 1536;      // fused input transform: per-channel scale/shift of one image live in 12 KiB of LDS
 constexpr int HALO_NB = 4;         // weight ring depth
@@ -40,289 +40,16 @@ struct HaloGeom {
     static constexpr int LDS = LDS_MIN > 131072 ? LDS_MIN : 131072;  // the epilogue stages 128 KiB
 };
 
-// PIPE: cross-step fragment prefetch (see kstep); selectable at run time (IGemmParams::dbg & 128) for A/B measurements
-template <bool UPS, bool PIPE>
-__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const IGemmParams p) {
-    using G = HaloGeom<UPS>;
-    constexpr int BM = 256, BN = 128, WM = 4, WN = 2, NW = 8, TN = 64, FM = 4, FN = 4, FP = 2;
-    constexpr int HW_ = G::HW_, HROWS = G::HROWS, A_IT = G::A_IT, A_BUF = G::A_BUF;
-    constexpr int NB = HALO_NB, B_STAGE = BN * 128, B_IT = 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const a_lds = smem;
-    char* const b_lds = smem + G::B_OFF;
-    char* const dump = smem + G::DUMP_OFF;
-    float* const s_gn = (float*)(smem + G::GN_OFF);  // [GN_MAXC] scale, [GN_MAXC] shift of this image
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const bool second_half = wave >= NW / 2;
-    const int a15 = lane & 15;
-
-    // ---- tile coordinates -------------------------------------------------------------------------------------------------
-    const int Ho = p.Ho, Wo = p.Wo, Hi = p.Hi, Wi = p.Wi, Cin = p.Cin;
-    const int tiles_x = (Wo + 15) >> 4, tiles_y = (Ho + 15) >> 4;
-    const int ncols = p.N > p.n_store ? p.N : p.n_store;
-    const int tiles_n = (ncols + BN - 1) / BN;
-    const int sid = xcd_remap(blockIdx.x, tiles_x * tiles_y * p.B * tiles_n);
-    const int nt = sid % tiles_n;
-    int sp = sid / tiles_n;
-    const int tx = sp % tiles_x;
-    sp /= tiles_x;
-    const int ty = sp % tiles_y, b = sp / tiles_y;
-    const int n0 = nt * BN;
-    const int cpt = Cin >> 6, ns = 9 * cpt;
-
-    const int chunk_a = (lane & 7) ^ (lane >> 3);  // pixel rows: slot ^ (row & 7) (a DMA group is 8 rows), conflict-free for ANY 16-row window
-    const int chunk_w = (lane & 7) ^ (((lane >> 4) & 1) | ((wave & 1) << 1) | (((wave >> 1) & 1) << 2));
-
-    // ---- halo row descriptors: LDS row r <-> source pixel (sy0 + r / HW_, sx0 + r % HW_) --------------------------------------
-    const int sy0 = UPS ? ty * 8 - 1 : ty * 16 - 1, sx0 = UPS ? tx * 8 - 1 : tx * 16 - 1;
-    const bf16_t* h_ptr[A_IT];
-    unsigned h_ok = 0;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        const int r = (wave + NW * i) * 8 + (lane >> 3);
-        const int hy = r / HW_, hx = r - hy * HW_;
-        const int iy = sy0 + hy, ix = sx0 + hx;
-        const bool ok = r < HROWS && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
-        h_ptr[i] = p.in + (((long long)b * Hi + iy) * Wi + ix) * Cin + chunk_a * 8;
-        if (ok) h_ok |= 1u << i;
-    }
-    const bf16_t* zsrc_a = p.zero + chunk_a * 8;
-    const bf16_t* zsrc_w = p.zero + chunk_w * 8;
-    const bf16_t* w_ptr[B_IT];
-    bool w_ok[B_IT];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-        const int n = n0 + (wave + NW * i) * 8 + (lane >> 3);
-        w_ok[i] = n < p.n_rows;
-        w_ptr[i] = p.wt + (long long)n * p.ldw + chunk_w * 8;
-    }
-
-    // ---- fused input transform (GroupNorm apply + SiLU) -----------------------------------------------------------------------
-    // Padding pixels must stay exactly 0 (the reference pads the NORMALISED tensor), hence the per-item validity mask.
-    constexpr int T_IT = (HROWS * 8 + 511) / 512;      // 16-byte items per thread per halo: 2 / 6
-    const bool fused = p.in_scale != nullptr;
-    unsigned t_ok = 0;
-    if (fused) {
-        for (int c = tid; c < Cin; c += 512) {
-            s_gn[c] = p.in_scale[(long long)b * Cin + c];
-            s_gn[GN_MAXC + c] = p.in_shift[(long long)b * Cin + c];
-        }
-#pragma unroll
-        for (int k = 0; k < T_IT; ++k) {
-            const int r = (tid + 512 * k) >> 3;
-            const int hy = r / HW_, hx = r - hy * HW_;
-            if (r < HROWS && (unsigned)(sy0 + hy) < (unsigned)Hi && (unsigned)(sx0 + hx) < (unsigned)Wi) t_ok |= 1u << k;
-        }
-        __syncthreads();  // before any LDS-DMA is in flight: a later __syncthreads would drain the DMA ring
-    }
-    auto transform_part = [&](int cc, int k) {  // part k = 16-byte item tid + 512*k of the halo buffer
-        if (!((t_ok >> k) & 1u)) return;
-        char* buf = a_lds + (cc & 1) * A_BUF;
-        const float* sc = s_gn + (cc << 6);
-        const float* sh = s_gn + GN_MAXC + (cc << 6);
-        const int item = tid + 512 * k, r = item >> 3;
-        const int ls = ((item & 7) ^ (r & 7)) << 3;  // first channel (within the chunk) of this 16-byte slot
-        // All LDS traffic of the transform goes through inline asm: compiler-visible reads/writes of the DMA-written array make
-        // hipcc drain vmcnt(0) first (it cannot prove they do not alias an LDS-DMA in flight), which would stall the weight
-        // ring every step.  This slot's DMA landed before the barrier of tap 3 (see kstep); the reads are waited for inside
-        // the statement, the write by the s_waitcnt lgkmcnt(0) ahead of the next barrier.
-        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-        typedef float f4_t __attribute__((ext_vector_type(4)));
-        const unsigned a_item = (unsigned)(unsigned long long)(buf + item * 16);
-        const unsigned a_sc = (unsigned)(unsigned long long)(sc + ls), a_sh = (unsigned)(unsigned long long)(sh + ls);
-        u32x4_t raw;
-        f4_t s0, s1, h0, h1;
-        asm volatile(
-            "ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\tds_read_b128 %3, %7\n\t"
-            "ds_read_b128 %4, %7 offset:16\n\ts_waitcnt lgkmcnt(0)"
-            : "=&v"(raw), "=&v"(s0), "=&v"(s1), "=&v"(h0), "=&v"(h1)
-            : "v"(a_item), "v"(a_sc), "v"(a_sh)
-            : "memory");
-        float v[8] = {bflo(raw.x) * s0.x + h0.x, bfhi(raw.x) * s0.y + h0.y, bflo(raw.y) * s0.z + h0.z, bfhi(raw.y) * s0.w + h0.w,
-                      bflo(raw.z) * s1.x + h1.x, bfhi(raw.z) * s1.y + h1.y, bflo(raw.w) * s1.z + h1.z, bfhi(raw.w) * s1.w + h1.w};
-        if (p.in_silu) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-        }
-        uint4 o;
-        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-        const u32x4_t ov = {o.x, o.y, o.z, o.w};
-        asm volatile("ds_write_b128 %0, %1" ::"v"(a_item), "v"(ov) : "memory");
-    };
-
-    auto stage_halo = [&](int cc) {
-        char* dst = a_lds + (cc & 1) * A_BUF;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int g = wave + NW * i;  // groups beyond the halo land in the dump KiB (keeps the per-wave DMA count uniform)
-            const bf16_t* src = ((h_ok >> i) & 1u) ? h_ptr[i] + (cc << 6) : zsrc_a;
-            glds16(src, g < G::GROUPS ? dst + g * 1024 : dump);
-        }
-    };
-    auto stage_w = [&](int slot, int tap, int cc) {
-        char* dst = b_lds + slot * B_STAGE;
-        const int woff = tap * Cin + (cc << 6);
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const bf16_t* src = w_ok[i] ? w_ptr[i] + woff : zsrc_w;
-            glds16(src, dst + (wave + NW * i) * 1024);
-        }
-    };
-
-    f32x4_t acc[FN][FM];
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    struct Frags { bf16x8_t w[FN], x[FM]; };
-    const int xr_w = ((a15 >> 1) & 1) | (((a15 >> 2) & 1) << 1) | (((a15 >> 3) & 1) << 2);
-    const int w_row_off = (wn * TN + 8 * (a15 >> 2) + (a15 & 3)) * 128;
-    // fragments of k-half kk of step (slot, chunk cc, tap ky/kx)
-    auto load_frags = [&](Frags& f, int slot, int cc, int ky, int kx, int kk) {
-        const char* ab = a_lds + (cc & 1) * A_BUF;
-        const char* wb = b_lds + slot * B_STAGE;
-        const int sl = kk * 4 + (lane >> 4);
-        const int so_w = (sl ^ xr_w) << 4;
-#pragma unroll
-        for (int i = 0; i < FN; ++i) f.w[i] = *(const bf16x8_t*)(wb + w_row_off + (i >> 1) * 4096 + (i & 1) * 512 + so_w);
-#pragma unroll
-        for (int j = 0; j < FM; ++j) {
-            const int py = 4 * wm + j;
-            int row;
-            if (UPS) row = (((py + ky - 1) >> 1) + 1) * HW_ + (((a15 + kx - 1) >> 1) + 1);
-            else row = (py + ky) * HW_ + a15 + kx;
-            f.x[j] = *(const bf16x8_t*)(ab + row * 128 + ((sl ^ (row & 7)) << 4));
-        }
-    };
-    auto mfma16 = [&](const Frags& f) {
-#pragma unroll
-        for (int i = 0; i < FN; ++i)
-#pragma unroll
-            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[i], f.x[j], acc[i][j], 0, 0, 0);
-    };
-
-    // ---- prologue: bias, halo of chunk 0, weight tiles of steps 0..2 ------------------------------------------------------------
-    // (bias first: an ordinary load issued while LDS-DMA is in flight makes hipcc drain vmcnt to 0 at its first use)
-    float bcol[FP][8];
-    load_bias_cols<FP>(p, 0, n0 + wn * TN, 8 * (lane >> 4), bcol);
-    stage_halo(0);
-    stage_w(0, 0, 0);
-    stage_w(1, 1, 0);
-    stage_w(2, 2, 0);  // ns >= 9 always
-
-    // ---- main loop over (chunk, tap) ------------------------------------------------------------------------------------------------
-    int tap = 0, cc = 0, ky = 0, kx = 0;            // step s
-    int tap1 = 1, cc1 = 0, ky1 = 0, kx1 = 1;        // step s + 1 (prefetched)
-    int t3 = 3, c3 = 0;                             // (tap, chunk) of step s + 3 (its weights are issued in step s)
-    int slot = 0, slot1 = 1, slot3 = 3;
-    int s = 0;
-    Frags f0, f1a, f1b;  // f0: k-half 0 of the current step; f1a / f1b ping-pong: k-half 1 of the current / next step
-
-    // One K-step.  On entry f0 and `cur1` hold BOTH k-halves of step s (read from LDS during step s-1), so the 32 MFMAs never
-    // wait for LDS; the 16 fragment reads of step s+1 are issued between the two MFMA batches (f0 is dead by then, `nxt1` is free).
-    auto kstep = [&](Frags& cur1, Frags& nxt1) {
-        // Barrier(s) certifies B(s+1) (and every halo issued before it).  Loads issued after B(s+1) that may stay in flight:
-        // B(s+2), and halo(cc+1) while it was issued one or two steps ago (this chunk's tap 0).
-        const bool more_w = s + 2 < ns;
-        const bool halo_fly = (tap == 1 || tap == 2) && cc + 1 < cpt;
-        if (halo_fly) { if (more_w) halo_wait_vm<A_IT + B_IT>(); else halo_wait_vm<A_IT>(); }
-        else { if (more_w) halo_wait_vm<B_IT>(); else halo_wait_vm<0>(); }
-        if (fused) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my transform writes of the previous step are in LDS
-        __builtin_amdgcn_s_barrier();
-        if (s == 0) {
-            if (fused) {  // chunk 0 has nothing to hide under: normalise it here, all parts, then re-synchronise
-#pragma unroll
-                for (int k = 0; k < T_IT; ++k) transform_part(0, k);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            if (PIPE) {
-                load_frags(f0, 0, 0, 0, 0, 0);
-                load_frags(cur1, 0, 0, 0, 0, 1);
-            }
-        }
-        const bool issue_w = s + 3 < ns, issue_h = tap == 0 && cc + 1 < cpt;
-        if (second_half) {
-            if (issue_w) stage_w(slot3, t3, c3);
-            if (issue_h) stage_halo(cc + 1);
-        }
-        if (PIPE) {
-            __builtin_amdgcn_sched_barrier(0);
-            mfma16(f0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < ns) {
-                load_frags(f0, slot1, cc1, ky1, kx1, 0);
-                load_frags(nxt1, slot1, cc1, ky1, kx1, 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mfma16(cur1);
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            // measured faster than the cross-step register pipeline above (which needs 256 VGPRs and pinned scheduling):
-            // read this step's 16 fragments, then issue its 32 MFMAs at raised priority while the partner wave does its DMA
-            load_frags(f0, slot, cc, ky, kx, 0);
-            load_frags(cur1, slot, cc, ky, kx, 1);
-            __builtin_amdgcn_s_setprio(1);
-            mfma16(f0);
-            mfma16(cur1);
-            __builtin_amdgcn_s_setprio(0);
-        }
-        // chunk cc+1's halo is complete for everybody from the barrier of tap 3 on (issued at tap 0, i.e. before B(s+1) of tap 2);
-        // it is first READ by the prefetch in tap 8, so its T_IT transform parts run in taps 3..7, hidden under MFMA steps
-        if (fused && cc + 1 < cpt) {
-            if (T_IT == 6) {
-                if (tap == 3) { transform_part(cc + 1, 0); transform_part(cc + 1, 1); }
-                else if (tap >= 4 && tap <= 7) transform_part(cc + 1, tap - 2);
-            } else {
-                if (tap == 3) transform_part(cc + 1, 0);
-                else if (tap == 4) transform_part(cc + 1, 1);
-            }
-        }
-        if (!second_half) {
-            if (issue_w) stage_w(slot3, t3, c3);
-            if (issue_h) stage_halo(cc + 1);
-        }
-        slot = slot1;
-        slot1 = slot1 == NB - 1 ? 0 : slot1 + 1;
-        slot3 = slot3 == NB - 1 ? 0 : slot3 + 1;
-        tap = tap1; cc = cc1; ky = ky1; kx = kx1;
-        if (++kx1 == 3) { kx1 = 0; ++ky1; }
-        if (++tap1 == 9) { tap1 = 0; ky1 = 0; ++cc1; }
-        if (++t3 == 9) { t3 = 0; ++c3; }
-        ++s;
-    };
-    while (s < ns) {
-        kstep(f1a, f1b);
-        if (s < ns) kstep(f1b, f1a);
-    }
-
-    // ---- epilogue --------------------------------------------------------------------------------------------------------------
-    conv_epilogue<BM, BN, WM, WN, 512>(p, acc, bcol, n0, 0, wave, lane, smem, [&](int pr) {
-        const int oy = ty * 16 + (pr >> 4), ox = tx * 16 + (pr & 15);
-        return (oy < Ho && ox < Wo) ? (b * Ho + oy) * Wo + ox : -1;
-    }, (b * tiles_y + ty) * tiles_x + tx);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------
-// Second-generation kernel: the same tiling, ring and synchronisation, with the nine taps unrolled at compile time.
-// In the first kernel (above, kept for A/B measurements behind IGemmParams::dbg bit 128) every ds_read_b128 address was
-// recomputed per step from run-time (tap, chunk, ring slot): ~80 VALU + ~90 SALU instructions per 32 MFMAs, executed by both
-// waves of a SIMD at the same time, i.e. with the matrix pipe idle (PMC: 2.6 VALU per MFMA, MFMA busy 38 %).  Here
+// One tile per workgroup (conv3x3_halo2_kernel): the fallback for shapes the persistent kernel below does not take (ragged channel
+// slots), and the A/B partner for measurements (IGemmParams::dbg bit 256).  The nine taps are unrolled at compile time:
 //   * the swizzle key of a halo row depends on its COLUMN hx only, so a lane needs six pixel-fragment base addresses
 //     (3 kx x 2 k-halves) and two weight-fragment bases; tap row, pixel row, halo buffer and ring slot (3-deep ring: slot =
-//     tap % 3) are ds_read immediates;
+//     tap % 3) are ds_read immediates.  (A first version recomputed every ds_read_b128 address per step from run-time tap / chunk
+//     / slot: ~80 VALU + ~90 SALU per 32 MFMAs, executed by both waves of a SIMD at once with the matrix pipe idle -- PMC: 2.6 VALU
+//     per MFMA, MFMA busy 38 %; removing them was worth 12-30 %.)
 //   * the weight-tile source pointers advance by a scalar stride per step (no per-step multiply), and
 //   * each MFMA batch is interleaved with the LDS reads of a register set that is dead during that batch.
-template <int V>
-struct IC { static constexpr int value = V; };
-
-typedef const __attribute__((address_space(3))) bf16x8_t* lds_frag_ptr;
-GP_DEV bf16x8_t lds_frag(unsigned base, int imm) { return *(lds_frag_ptr)(base + (unsigned)imm); }
-
 // swizzle key of halo column hx.  18-wide halo: hx & 7 (any 16 consecutive columns are conflict-free); 10-wide halo of the
 // x2-upsample case (lane pairs share a column): table found by exhaustive search, one nibble per column.
 template <bool UPS>
@@ -615,8 +342,9 @@ struct Halo3Geom {
     static constexpr int LDS = UPS ? EP_OFF + 32768 : EP_OFF;
 };
 
-// ABL: compile-time ablations for profiling (1 no epilogue, 2 no MFMA, 4 no output stores, 8 no halo DMA, 16 no weight DMA)
-template <bool UPS, int ABL = 0>
+// FUSED: 0 plain input, 1 input transform x * scale[b][c] + shift[b][c] (GroupNorm apply), 2 the same followed by SiLU.
+// ABL: compile-time ablations for profiling (2 no MFMA, 4 no output stores, 8 no halo DMA, 16 no weight DMA)
+template <bool UPS, int FUSED, int ABL = 0>
 __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p) {
     using G = HaloGeom<UPS>;
     using G3 = Halo3Geom<UPS>;
@@ -653,7 +381,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
 
     // ---- fetch state: the tile whose halo is being staged / normalised (one chunk ahead of the compute) ----------------------------
     constexpr int T_IT = (HROWS * 8 + 511) / 512;
-    const bool fused = p.in_scale != nullptr;
+    constexpr bool fused = FUSED != 0;
     int h_off[A_IT];
     unsigned h_ok = 0, t_ok = 0;
     auto setup_fetch = [&](int sp) __attribute__((always_inline)) {
@@ -697,32 +425,43 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     }
     const unsigned a_base = (unsigned)(unsigned long long)a_lds, b_base = (unsigned)(unsigned long long)b_lds;
     const unsigned gn_base = (unsigned)(unsigned long long)s_gn;
-    auto transform_part = [&](int buf, int cc, int k) __attribute__((always_inline)) {
-        if (!((t_ok >> k) & 1u)) return;
+    // Input transform of one 16-byte item (8 channels of one halo pixel) per thread and part: part k = item tid + 512 * k of halo buffer
+    // `buf`, channels of chunk cc.  Split in a load half and a finish half so that the K-step can put the LDS reads among the MFMAs of its
+    // first batch and the arithmetic (8 FMA + 8 SiLU with two quarter-rate transcendentals each + packing) among those of the second: run
+    // as a block after the MFMAs -- both waves of a SIMD at the same time -- it left the matrix pipe idle and cost ~20 % per conv.
+    // No branches: items beyond the halo go to the dump KiB, items outside the image (zero padding of the NORMALISED tensor) keep
+    // their zeros through a select.  LDS accesses by integer address (see common.h).
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u32x4_t* lds_u4_ptr;
+    struct TPart { u32x4_t raw; f32x4_t s0, s1, h0, h1; unsigned addr; bool ok; };
+    const unsigned dump_base = (unsigned)(unsigned long long)dump;
+    auto tp_load = [&](TPart& t, int buf, int cc, int k) __attribute__((always_inline)) {
         int tid_o = tid;
-        asm volatile("" : "+v"(tid_o));  // opaque: recompute the few address values here instead of carrying them through the loop
-        const int item = tid_o + 512 * k, r = item >> 3;
+        asm volatile("" : "+v"(tid_o));  // opaque: recompute the address values here instead of carrying them through the loop
+        const int item = tid_o + 512 * k;
+        const bool inr = item < HROWS * 8;
+        const int r = inr ? item >> 3 : 0;
         const int ls = ((item & 7) ^ halo_key<UPS>(r % HW_)) << 3;
-        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-        typedef float f4_t __attribute__((ext_vector_type(4)));
-        const unsigned a_item = a_base + buf * A_BUF + item * 16;
-        const unsigned a_sc = gn_base + ((cc << 6) + ls) * 4, a_sh = a_sc + GN_MAXC * 4;
-        u32x4_t raw;
-        f4_t s0, s1, h0, h1;
-        asm volatile(
-            "ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\tds_read_b128 %3, %7\n\t"
-            "ds_read_b128 %4, %7 offset:16\n\ts_waitcnt lgkmcnt(0)"
-            : "=&v"(raw), "=&v"(s0), "=&v"(s1), "=&v"(h0), "=&v"(h1)
-            : "v"(a_item), "v"(a_sc), "v"(a_sh)
-            : "memory");
-        float v[8] = {bflo(raw.x) * s0.x + h0.x, bfhi(raw.x) * s0.y + h0.y, bflo(raw.y) * s0.z + h0.z, bfhi(raw.y) * s0.w + h0.w,
-                      bflo(raw.z) * s1.x + h1.x, bfhi(raw.z) * s1.y + h1.y, bflo(raw.w) * s1.z + h1.z, bfhi(raw.w) * s1.w + h1.w};
-        if (p.in_silu) {
+        t.ok = (t_ok >> k) & 1u;
+        t.addr = inr ? a_base + buf * A_BUF + item * 16 : dump_base + (tid_o & 63) * 16;
+        const unsigned a_sc = gn_base + ((cc << 6) + ls) * 4;
+        t.raw = *(lds_u4_ptr)t.addr;
+        t.s0 = *(lds_f4_ptr)a_sc;
+        t.s1 = *(lds_f4_ptr)(a_sc + 16);
+        t.h0 = *(lds_f4_ptr)(a_sc + GN_MAXC * 4);
+        t.h1 = *(lds_f4_ptr)(a_sc + GN_MAXC * 4 + 16);
+    };
+    auto tp_finish = [&](const TPart& t) __attribute__((always_inline)) {
+        float v[8] = {bflo(t.raw.x) * t.s0.x + t.h0.x, bfhi(t.raw.x) * t.s0.y + t.h0.y, bflo(t.raw.y) * t.s0.z + t.h0.z,
+                      bfhi(t.raw.y) * t.s0.w + t.h0.w, bflo(t.raw.z) * t.s1.x + t.h1.x, bfhi(t.raw.z) * t.s1.y + t.h1.y,
+                      bflo(t.raw.w) * t.s1.z + t.h1.z, bfhi(t.raw.w) * t.s1.w + t.h1.w};
+        if (FUSED == 2) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
         }
-        const u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-        asm volatile("ds_write_b128 %0, %1" ::"v"(a_item), "v"(ov) : "memory");
+        u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        ov = t.ok ? ov : t.raw;
+        *(lds_u4_ptr)t.addr = ov;
     };
     auto stage_halo = [&](int buf, int cc) __attribute__((always_inline)) {
         char* dst = a_lds + buf * A_BUF;
@@ -805,8 +544,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     // trace back to `smem` make it wait for vmcnt(0) first (possible alias with an LDS-DMA in flight), i.e. for the residual
     // loads just issued and for the previous pass's stores -- four exposed HBM round trips per tile when measured.
     // Launch-time guarantees (launch_conv_halo): n_store, ldo (and ldres) multiples of 8, so every 8-channel slot is stored whole.
-    typedef __attribute__((address_space(3))) f32x4_t* lds_f4_ptr;
-    typedef __attribute__((address_space(3))) float* lds_f_ptr;
     const unsigned st_base = (unsigned)(unsigned long long)s_st, bias_base = (unsigned)(unsigned long long)s_bias;
     // Specialised at compile time on (activation present, residual present, statistics wanted): with run-time checks per element
     // the epilogue was ~2000 VALU + 130 scalar branches per wave and tile, as much SIMD time as the 18 K-steps of a K = 1152 layer.
@@ -942,9 +679,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     Half f0, f1a, f1b;
     halo_wait_vm<B_IT>();
     __builtin_amdgcn_s_barrier();
-    if (fused) {
+    if (fused) {  // chunk 0 of the first tile has nothing to hide under
 #pragma unroll
-        for (int k = 0; k < T_IT; ++k) transform_part(0, 0, k);
+        for (int k = 0; k < T_IT; ++k) {
+            TPart t;
+            tp_load(t, 0, 0, k);
+            tp_finish(t);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -971,14 +712,43 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
             if (issue_h) stage_halo(PAR ^ 1, fcc);
         }
         __builtin_amdgcn_sched_barrier(0);
+        // transform parts of this step (halo of chunk cc+1: complete for everybody from the barrier before tap 3, first read in tap 8)
+        constexpr int NP = !fused ? 0 : T_IT == 6 ? (TAP == 3 ? 2 : (TAP >= 4 && TAP <= 7) ? 1 : 0) : ((TAP == 3 || TAP == 4) ? 1 : 0);
+        constexpr int P0 = T_IT == 6 ? (TAP == 3 ? 0 : TAP - 2) : TAP - 3;
         if constexpr (TAP < 8) {
+            TPart tp[NP > 0 ? NP : 1];
+            if constexpr (NP > 0) {
+#pragma unroll
+                for (int u = 0; u < NP; ++u) tp_load(tp[u], PAR ^ 1, fcc, P0 + u);
+            }
             load_half(nxt1, IC<TAP1>{}, IC<PAR1>{}, IC<1>{});
             mfma16(f0);
-            interleave();
+            if constexpr (NP == 0) {
+                interleave();
+            } else {  // 16 MFMAs, 8 + 5 NP LDS reads
+                constexpr int NA = NP == 1 ? 5 : 2, RA = NP == 1 ? 2 : 3, RB = NP == 1 ? 1 : 2;  // NA groups of RA reads, then RB reads
+#pragma unroll
+                for (int q = 0; q < NA; ++q) { sgb<0x008, 2>(); sgb<0x100, RA>(); }
+#pragma unroll
+                for (int q = NA; q < 8; ++q) { sgb<0x008, 2>(); sgb<0x100, RB>(); }
+            }
             __builtin_amdgcn_sched_barrier(0);
             load_half(f0, IC<TAP1>{}, IC<PAR1>{}, IC<0>{});
+            if constexpr (NP > 0) {
+#pragma unroll
+                for (int u = 0; u < NP; ++u) tp_finish(tp[u]);
+            }
             mfma16(cur1);
-            interleave();
+            if constexpr (NP == 0) {
+                interleave();
+            } else {  // 16 MFMAs, 8 LDS reads, ~60 NP VALU + 16 NP transcendentals, NP LDS writes
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    sgb<0x008, 1>(); sgb<0x002, 4 * NP>(); sgb<0x400, NP>();
+                    sgb<0x008, 1>(); sgb<0x100, 1>(); sgb<0x002, 4 * NP>(); sgb<0x400, NP>();
+                }
+                sgb<0x200, NP>();
+            }
         } else {
             mfma16(f0);
             mfma16(cur1);
@@ -986,7 +756,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
             if (tile_end) {
                 halo_wait_vm<0>();  // everything this wave has in flight has landed: stores issued below cannot delay a certification
                 if (!(ABL & 1)) epilogue((UPS ? a_base + G3::EP_OFF : a_base + PAR * A_BUF) + wave * 4096);
-                else if (tid == 0 && acc[0][0][0] == 1.2345f) ((float*)p.out)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];
             }
             if (!final_) {
                 load_half(f0, IC<TAP1>{}, IC<PAR1>{}, IC<0>{});
@@ -994,15 +763,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (fused && !final_) {
-            if (T_IT == 6) {
-                if (TAP == 3) { transform_part(PAR ^ 1, fcc, 0); transform_part(PAR ^ 1, fcc, 1); }
-                else if (TAP >= 4 && TAP <= 7) transform_part(PAR ^ 1, fcc, TAP - 2);
-            } else {
-                if (TAP == 3) transform_part(PAR ^ 1, fcc, 0);
-                else if (TAP == 4) transform_part(PAR ^ 1, fcc, 1);
-            }
-        }
         if (!dma_first) {
             if (issue_w) stage_w(TAP % 3, adv);
             if (issue_h) stage_halo(PAR ^ 1, fcc);
@@ -1048,62 +808,60 @@ bool conv_halo_applicable(const IGemmParams& p) {
     if (p.ups) {
         if (p.Hu != 2 * p.Hi || p.Wu != 2 * p.Wi || p.Ho != p.Hu || p.Wo != p.Wu) return false;
     } else if (p.Ho != p.Hi || p.Wo != p.Wi) return false;
+    const int ncols = p.N > p.n_store ? p.N : p.n_store;
+    if (((ncols + 127) / 128) * 128 > p.n_rows) return false;  // the kernels read whole 128-row weight tiles
     return p.Ho >= 16 && p.Wo >= 16;
+}
+
+template <bool UPS, int FUSED, int ABL>
+static void launch_halo3_one(const IGemmParams& p, int grid, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<UPS, FUSED, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo3Geom<UPS>::LDS);
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv3x3_halo3_kernel<UPS, FUSED, ABL>), dim3(grid), dim3(512), Halo3Geom<UPS>::LDS, s, p);
+}
+
+static void launch_halo3(const IGemmParams& p, int grid, hipStream_t s) {
+    const int abl = (p.dbg >> 9) & 63;  // profiling ablations (GENPERCEPT_IGEMM_DBG = 512 * ABL), plain convs only
+    const int fused = !p.in_scale ? 0 : p.in_silu ? 2 : 1;
+    if (p.ups) {
+        if (fused == 2) launch_halo3_one<true, 2, 0>(p, grid, s);
+        else if (fused == 1) launch_halo3_one<true, 1, 0>(p, grid, s);
+        else launch_halo3_one<true, 0, 0>(p, grid, s);
+    } else if (fused == 2) launch_halo3_one<false, 2, 0>(p, grid, s);
+    else if (fused == 1) launch_halo3_one<false, 1, 0>(p, grid, s);
+    else if (abl == 2) launch_halo3_one<false, 0, 2>(p, grid, s);
+    else if (abl == 24) launch_halo3_one<false, 0, 24>(p, grid, s);
+    else launch_halo3_one<false, 0, 0>(p, grid, s);
 }
 
 void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
-    const int tiles = ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16) * p.B * ((ncols + 127) / 128);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<false>::LDS);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<true>::LDS);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<false>::LDS);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<true>::LDS);
-        attr = true;
-    }
-    static bool attr2 = false;
-    if (!attr2) {
+    const int tiles_n = (ncols + 127) / 128, tiles_sp = ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
         (void)hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<false>::LDS);
         (void)hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<true>::LDS);
-        attr2 = true;
     }
-    const bool rows_ok = ((ncols + 127) / 128) * 128 <= p.n_rows;  // the unrolled kernels read whole 128-row weight tiles
+    // (conv_halo_applicable guarantees whole 128-row weight tiles)
     const bool slots_ok = (p.n_store & 7) == 0 && (p.ldo & 7) == 0 && (!p.res || ((p.ldres & 7) == 0 && p.ldres >= p.n_store));
-    if (rows_ok && slots_ok && !(p.dbg & (128 | 256))) {
+    if (slots_ok && !(p.dbg & 256)) {
         // persistent kernel: B x J workgroups, J = workgroups per image (a multiple of tiles_n, about #CU / B)
-        static int ncu = 0;
-        if (!ncu) {
-            int dev = 0;
-            hipDeviceProp_t pr;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
-            if (ncu <= 0) ncu = 256;
-            (void)hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo3Geom<false>::LDS);
-            (void)hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo3Geom<true>::LDS);
-        }
-        const int tiles_n = (ncols + 127) / 128, tiles_sp = ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
         int per_img = ncu / p.B;
         if (per_img < 1) per_img = 1;
         int J = (per_img / tiles_n) * tiles_n;
         if (J < tiles_n) J = tiles_n;
         if (J > tiles_sp * tiles_n) J = tiles_sp * tiles_n;
-        if (p.ups) hipLaunchKernelGGL((conv3x3_halo3_kernel<true>), dim3(p.B * J), dim3(512), Halo3Geom<true>::LDS, s, p);
-        else {
-            switch ((p.dbg >> 9) & 63) {  // profiling ablations (GENPERCEPT_IGEMM_DBG = 512 * ABL)
-#define GP_H3_ABL(A) case A: { static bool at = false; if (!at) { (void)hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<false, A>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo3Geom<false>::LDS); at = true; } \
-                hipLaunchKernelGGL((conv3x3_halo3_kernel<false, A>), dim3(p.B * J), dim3(512), Halo3Geom<false>::LDS, s, p); break; }
-                GP_H3_ABL(2) GP_H3_ABL(3) GP_H3_ABL(4) GP_H3_ABL(24)
-#undef GP_H3_ABL
-                default: hipLaunchKernelGGL((conv3x3_halo3_kernel<false>), dim3(p.B * J), dim3(512), Halo3Geom<false>::LDS, s, p);
-            }
-        }
+        launch_halo3(p, p.B * J, s);
         return;
     }
-    if (rows_ok && !(p.dbg & 128)) {  // dbg bit 256: one tile per workgroup; bit 128: first-generation kernel (A/B measurements)
-        if (p.ups) hipLaunchKernelGGL((conv3x3_halo2_kernel<true>), dim3(tiles), dim3(512), HaloGeom<true>::LDS, s, p);
-        else hipLaunchKernelGGL((conv3x3_halo2_kernel<false>), dim3(tiles), dim3(512), HaloGeom<false>::LDS, s, p);
-        return;
-    }
-    if (p.ups) hipLaunchKernelGGL((conv3x3_halo_kernel<true, true>), dim3(tiles), dim3(512), HaloGeom<true>::LDS, s, p);
-    else hipLaunchKernelGGL((conv3x3_halo_kernel<false, true>), dim3(tiles), dim3(512), HaloGeom<false>::LDS, s, p);
+    const int tiles = tiles_sp * p.B * tiles_n;
+    if (p.ups) hipLaunchKernelGGL((conv3x3_halo2_kernel<true>), dim3(tiles), dim3(512), HaloGeom<true>::LDS, s, p);
+    else hipLaunchKernelGGL((conv3x3_halo2_kernel<false>), dim3(tiles), dim3(512), HaloGeom<false>::LDS, s, p);
 }

@@ -258,8 +258,14 @@ bool conv_uses_halo(const IGemmParams& p, int tile_hint) {
     return tile_hint == 5 || (tiles >= 160 && ncols > 32);
 }
 
+bool igemm_uses_pgemm(const IGemmParams& p, int tile_hint) {
+    static const bool no_pgemm = getenv("GENPERCEPT_NO_PGEMM") != nullptr;  // A/B switch
+    if (tile_hint == 7) return pgemm_applicable(p);
+    return tile_hint == 0 && !no_pgemm && pgemm_applicable(p);
+}
+
 static int select_cfg(const IGemmParams& p, int tile_hint) {
-    int cfg = tile_hint == 5 ? 0 : tile_hint;
+    int cfg = (tile_hint == 5 || tile_hint == 7) ? 0 : tile_hint;
     if (cfg == 0) {
         const int ncols = p.N > p.n_store ? p.N : p.n_store;
         const long long nb = p.batch > 0 ? p.batch : 1;
@@ -285,7 +291,7 @@ int igemm_tile_info(const IGemmParams& p, int tile_hint, int* mode, int* bm) {
     }
     const int cfg = select_cfg(p, tile_hint);
     *mode = 0;
-    *bm = (cfg == 1 || cfg == 6) ? 128 : cfg == 2 ? 64 : 256;
+    *bm = igemm_uses_pgemm(p, tile_hint) ? pgemm_bm(p) : (cfg == 1 || cfg == 6) ? 128 : cfg == 2 ? 64 : 256;
     const int hw = p.M / (p.B > 0 ? p.B : 1);
     if (p.B < 1 || hw * p.B != p.M || hw % *bm) return 0;  // a tile must not straddle two images
     return p.M / *bm;
@@ -294,6 +300,10 @@ int igemm_tile_info(const IGemmParams& p, int tile_hint, int* mode, int* bm) {
 void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s) {
     if (conv_uses_halo(p, tile_hint)) {
         launch_conv_halo(p, s);
+        return;
+    }
+    if (igemm_uses_pgemm(p, tile_hint)) {
+        launch_pgemm(p, s);
         return;
     }
     const int cfg = select_cfg(p, tile_hint);

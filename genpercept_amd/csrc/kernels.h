@@ -42,6 +42,11 @@ struct IGemmParams {
 };
 
 void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s);
+// pgemm.hip: persistent GEMM for plain-row problems (ks == 1, bf16 out, column bias); tile_hint 7 forces it, 0 prefers it
+bool pgemm_applicable(const IGemmParams& p);
+int pgemm_bm(const IGemmParams& p);                 // rows per tile (256 or 128) launch_pgemm will use
+void launch_pgemm(const IGemmParams& p, hipStream_t s);
+bool igemm_uses_pgemm(const IGemmParams& p, int tile_hint);
 // conv_halo.hip: 3x3 stride-1 convs on large maps (16x16-pixel tiles, input halo staged once per channel chunk); tile_hint 5
 bool conv_halo_applicable(const IGemmParams& p);   // includes the Cin <= 2048 limit when in_scale is set
 void launch_conv_halo(const IGemmParams& p, hipStream_t s);

@@ -112,6 +112,8 @@ def test_conv3x3_halo_kernel(case, metric_log):
     (2, 32, 32, 128, 128, 3, False, True, 5), (1, 40, 24, 64, 192, 3, False, False, 5), (4, 144, 160, 64, 128, 3, False, True, 5),
     (1, 24, 24, 128, 128, 3, True, True, 5), (3, 112, 112, 64, 256, 3, False, False, 5),
     (2, 32, 32, 128, 128, 3, False, True, 4), (2, 32, 32, 128, 256, 1, False, True, 1), (1, 16, 16, 320, 320, 3, False, False, 0),
+    # persistent GEMM (hint 7): 128-row and 256-row tiles
+    (4, 48, 48, 320, 640, 1, False, True, 7), (2, 96, 96, 320, 320, 1, False, False, 7), (4, 224, 224, 64, 128, 1, False, True, 7),
 ])
 def test_conv_epilogue_groupnorm_statistics(case, metric_log):
     """GroupNorm statistics accumulated in the conv epilogue (per-tile channel sums of the bf16 values as stored) and finalised to
@@ -225,7 +227,10 @@ def test_conv_fused_nearest_upsample(sizes, metric_log):
 
 
 GEMM_CASES = [(64, 64, 64, 0), (576, 1280, 320, 0), (100, 72, 128, 2), (1000, 320, 1280, 1), (36, 2560, 320, 0), (300, 24, 192, 3), (4800, 320, 320, 1),
-              (4800, 320, 320, 4), (1000, 130, 64, 4), (36864, 320, 320, 0), (70, 64, 2304, 4)]
+              (4800, 320, 320, 4), (1000, 130, 64, 4), (36864, 320, 320, 0), (70, 64, 2304, 4),
+              # tile hint 7: persistent GEMM (pgemm.hip); 128-row tiles, several tiles per workgroup, ragged last tile, K up to 40 steps,
+              # and (last case) the 256-row form with a ragged tail
+              (36864, 320, 320, 7), (4801, 320, 320, 7), (2304, 1280, 1280, 7), (9216, 640, 2560, 7), (300, 64, 64, 7), (200003, 128, 128, 7)]
 
 
 @pytest.mark.parametrize("case", GEMM_CASES)

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--tiles", default="0")
     ap.add_argument("--dbg", default="0", help="comma list of GENPERCEPT_IGEMM_DBG ablation values")
+    ap.add_argument("--gn", type=int, default=0, help="1: conv3x3(SiLU(GroupNorm(x))) with the apply fused into the halo conv (gp_conv2d_gn)")
     args = ap.parse_args()
     d = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(0)
@@ -46,6 +47,7 @@ def main():
         wt = torch.randn(cout, cin, ks, ks, generator=g) / math.sqrt(cin * ks * ks)
         wp = e.pack_weight(wt, device=d)
         bias = torch.randn(cout, generator=g).to(d)
+        gamma, beta = torch.ones(cin, device=d), torch.zeros(cin, device=d)
         flops = 2.0 * b * h * w * cout * cin * ks * ks
         variants = [(int(t), dv) for t in args.tiles.split(",") for dv in args.dbg.split(",")]
         times = {v: [] for v in variants}
@@ -55,7 +57,10 @@ def main():
                 st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 st.record()
                 for _ in range(args.iters):
-                    y = e.conv2d(x, wp, bias, cout, ks, tile=tile)
+                    if args.gn:
+                        y = e.conv2d_gn(x, wp, bias, cout, gamma, beta, 32, 1e-6, True)
+                    else:
+                        y = e.conv2d(x, wp, bias, cout, ks, tile=tile)
                 en.record()
                 torch.cuda.synchronize()
                 if rnd:
