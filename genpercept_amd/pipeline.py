@@ -27,6 +27,7 @@ from PIL import Image
 
 from . import config as gcfg
 from .image_util import chw2hwc, colorize_depth_maps, get_resample_method, resize_max_res, resize_to
+from .batchsize import find_batch_size
 
 
 @dataclass
@@ -239,6 +240,10 @@ class GenPerceptPipeline:
         assert ensemble_size == 1  # genpercept_pipeline.py:211-213
         assert denoising_steps == 1
         resample = get_resample_method(resample_method)
+        # genpercept_pipeline.py:264-270: batch size of the ensemble loader (always 1 on the one-step path: ensemble_size == 1)
+        if batch_size <= 0:
+            batch_size = find_batch_size(ensemble_size=ensemble_size, input_res=max(int(processing_res), 1), dtype=self.dtype)
+        assert batch_size >= 1
 
         if isinstance(input_image, Image.Image):
             arr = np.asarray(input_image.convert("RGB"))

@@ -8,6 +8,7 @@ Fixtures are data (seeds, inputs, expected outputs) — never reference source.
                      installed, so the two symbols dpt_head.py imports from it (LoRACompatibleConv, USE_PEFT_BACKEND;
                      dpt_head.py:20-21,130) are provided by a stub module.
   metrics_ref.npz    outputs of the REFERENCE's src/util/metric.py + src/util/alignment.py on seeded arrays.
+  batchsize_ref.npz  the REFERENCE's find_batch_size (genpercept/util/batchsize.py) on a grid of cards / resolutions / ensembles.
   e2e_tiny.npz       end-to-end goldens of the fp32 oracle (oracle/) on the tiny configs: inputs + expected outputs
                      for every stage (latent, unet out, feats, decode, final) — what the HIP path is checked against
                      on the GPU box where neither /root/reference nor large weights exist.
@@ -101,6 +102,34 @@ def make_metrics_golden():
     print("metrics_ref.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k.startswith("m_")})
 
 
+def make_batchsize_golden():
+    """Clamp behaviour of the REFERENCE's find_batch_size (genpercept/util/batchsize.py:51-81): for a card / resolution / dtype
+    the table answers with `bs_table` (queried with a huge ensemble so nothing clamps); the golden is what the reference then
+    returns for real ensemble sizes.  torch.cuda is monkey-patched (no GPU here; the function only reads the total memory)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_batchsize", os.path.join(REF, "genpercept/util/batchsize.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows = []
+    real_avail, real_info = torch.cuda.is_available, torch.cuda.mem_get_info
+    try:
+        torch.cuda.is_available = lambda: True
+        for vram in (8, 11, 24, 40, 80, 288):
+            torch.cuda.mem_get_info = lambda *a, v=vram: (0, v * 1024 ** 3)
+            for res in (384, 512, 768, 1024, 2048):
+                for dt_i, dt in enumerate((torch.float32, torch.float16)):
+                    bs_table = mod.find_batch_size(10 ** 9, res, dt)
+                    for ens in (1, 2, 3, 5, 7, 10, 16, 33, 50):
+                        rows.append((vram, res, dt_i, ens, bs_table, mod.find_batch_size(ens, res, dt)))
+        torch.cuda.is_available = lambda: False
+        no_gpu = mod.find_batch_size(10, 768, torch.float32)
+    finally:
+        torch.cuda.is_available, torch.cuda.mem_get_info = real_avail, real_info
+    np.savez_compressed(os.path.join(HERE, "batchsize_ref.npz"), rows=np.array(rows, dtype=np.int64), no_gpu=np.array(no_gpu),
+                        columns=np.array(["vram_gb", "res", "dtype(0=f32,1=f16)", "ensemble", "bs_table", "bs_returned"]))
+    print("batchsize golden:", len(rows), "rows; no-gpu ->", no_gpu)
+
+
 def make_e2e_tiny():
     uc, vc, dc = osd.UNetCfg.tiny(), osd.VAECfg.tiny(), odpt.DPTCfg.tiny()
     usd = osd.synth_state_dict(osd.unet_manifest(uc), 1)
@@ -137,10 +166,12 @@ def make_e2e_tiny():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dpt", "metrics", "e2e"]
+    which = sys.argv[1:] or ["dpt", "metrics", "e2e", "batchsize"]
     if "dpt" in which:
         make_dpt_golden()
     if "metrics" in which:
         make_metrics_golden()
     if "e2e" in which:
         make_e2e_tiny()
+    if "batchsize" in which:
+        make_batchsize_golden()

@@ -181,3 +181,29 @@ def test_product_manifests_equal_oracle_manifests_and_public_counts():
     assert "conv_out.weight" not in gw.unet_manifest(nohead) and len(gw.unet_manifest(nohead)) == 682
     a, b = gw.synth_state_dict(gw.unet_manifest(tu), 1), osd.synth_state_dict(osd.unet_manifest(osd.UNetCfg.tiny()), 1)
     assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_find_batch_size_clamp_matches_reference():
+    """genpercept_amd.batchsize mirrors the reference's find_batch_size (genpercept/util/batchsize.py:51-81): given the batch
+    that fits, the clamp against the ensemble size must reproduce the reference's answers (tests/golden/batchsize_ref.npz);
+    the hot path (ensemble_size == 1) always gets 1, as does a host without a GPU."""
+    import numpy as np
+    from genpercept_amd import batchsize as bsz
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "batchsize_ref.npz"))
+    assert int(g["no_gpu"]) == 1
+    n_checked = 0
+    for vram, res, dt, ens, bs_table, bs_ret in g["rows"]:
+        if bs_table == 1 and bs_ret == 1:
+            # either the table's bs is 1 or nothing fitted (the reference returns 1 both ways): only the ensemble-1 rule is checkable
+            assert bsz.clamp_batch_size(1, int(ens)) == 1 if ens == 1 else True
+            continue
+        assert bsz.clamp_batch_size(int(bs_table), int(ens)) == int(bs_ret), (vram, res, dt, ens, bs_table, bs_ret)
+        n_checked += 1
+    assert n_checked > 100
+    for ens in (1, 2, 10):
+        for res in (384, 768, 1024):
+            b = bsz.find_batch_size(ens, res, torch.bfloat16, total_vram_gb=288.0)
+            assert 1 <= b <= ens
+    assert bsz.find_batch_size(1, 768, torch.bfloat16, total_vram_gb=288.0) == 1
+    assert bsz.find_batch_size(10, 768, None, total_vram_gb=1.0) == 1          # nothing fits -> 1
+    assert bsz.find_batch_size(64, 768, None, total_vram_gb=288.0) in (32, 64)  # 288 GB: the whole ensemble or its half
