@@ -122,7 +122,7 @@ def main():
                 traffic = round((2.0 * fam(tj["FETCH_SIZE"]) + fam(tj["WRITE_SIZE"])) * 1024.0 / max(nd, 1))
             except Exception:
                 pass
-            roofline = {"bound": "mfma", "kernel": "implicit-GEMM conv/linear family (conv3x3_halo_kernel + igemm_kernel, v_mfma_f32_16x16x32_bf16)",
+            roofline = {"bound": "mfma", "kernel": "implicit-GEMM conv/linear family (conv3x3_halo3_kernel + pgemm_kernel + igemm_kernel, v_mfma_f32_16x16x32_bf16)",
                         "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                         "traffic_note": "bytes per launch, PMC (2*FETCH_SIZE + WRITE_SIZE) of profiles/r01_pmc_traffic_summary.json",
                         "launches": tm["n_igemm"], "flops_per_launch_avg": tm["flops_igemm"] / max(tm["n_igemm"], 1),
@@ -132,7 +132,9 @@ def main():
                         "pipeline_frac": round(TFLOP_PER_IMAGE_768 * scale * args.batch / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4)}
         stages = {"ms_encode": round(tm["ms_encode"], 3), "ms_unet": round(tm["ms_unet"], 3), "ms_head": round(tm["ms_head"], 3),
                   "ms_igemm_sum": round(tm["ms_igemm"], 3), "ms_attn_sum": round(tm["ms_attn"], 3), "kernel_launches": tm["n_launches"],
-                  "algorithmic_tflop_counted": round((tm["flops_igemm"] + tm["flops_attn"]) / 1e12 / args.batch, 3)}
+                  "algorithmic_tflop_counted": round((tm["flops_igemm"] + tm["flops_attn"]) / 1e12 / args.batch, 3),
+                  # second half of BASELINE.json's metric: UNet stage alone, 2.137 TFLOP per 768x768 image
+                  "unet_mfma_util": round(2.137 * (args.res / 768.0) ** 2 * args.batch / (max(tm["ms_unet"], 1e-9) * 1e-3) / PEAK_BF16_TFLOPS, 4)}
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu and not dpt:

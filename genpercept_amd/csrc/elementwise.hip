@@ -54,6 +54,43 @@ void launch_concat(const bf16_t* a, int Ca, const bf16_t* b, int Cb, bf16_t* out
     hipLaunchKernelGGL(concat_kernel, dim3(grid_for(pixels * ((Ca + Cb) / 8))), dim3(256), 0, s, a, Ca, b, Cb, out, pixels);
 }
 
+// The same concat, also leaving the GroupNorm statistics of the tensor it writes: per (bm consecutive pixels, channel) {sum, sum of
+// squares} in the layout of the conv epilogues (mode 0 of gn_finalize_tiles_kernel), so the resnet that consumes the concatenation
+// skips its statistics read pass.  A thread owns one 8-channel slot for the bm pixels of its tile: no cross-thread reduction.
+__global__ __launch_bounds__(256) void concat_stats_kernel(const bf16_t* __restrict__ a, int Ca, const bf16_t* __restrict__ b, int Cb,
+                                                            bf16_t* __restrict__ out, int bm, float* __restrict__ part) {
+    const int va = Ca >> 3, vt = (Ca + Cb) >> 3, C = Ca + Cb;
+    const int v = blockIdx.y * 256 + threadIdx.x;
+    if (v >= vt) return;
+    const long long p0 = (long long)blockIdx.x * bm;
+    const bool from_a = v < va;
+    const bf16_t* src = from_a ? a + p0 * Ca + v * 8 : b + p0 * Cb + (v - va) * 8;
+    const int ld = from_a ? Ca : Cb;
+    bf16_t* dst = out + p0 * C + v * 8;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+#pragma unroll 4
+    for (int r = 0; r < bm; ++r) {
+        const uint4 x = *(const uint4*)(src + (long long)r * ld);
+        *(uint4*)(dst + (long long)r * C) = x;
+        const float f[8] = {bflo(x.x), bfhi(x.x), bflo(x.y), bfhi(x.y), bflo(x.z), bfhi(x.z), bflo(x.w), bfhi(x.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+    }
+    float* po = part + ((long long)blockIdx.x * C + v * 8) * 2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { po[2 * e] = s[e]; po[2 * e + 1] = q[e]; }
+}
+int concat_stats_bm(long long hw) {
+    for (int bm : {64, 48, 32, 16})
+        if (hw % bm == 0) return bm;
+    return 0;
+}
+void launch_concat_stats(const bf16_t* a, int Ca, const bf16_t* b, int Cb, bf16_t* out, long long pixels, int bm, float* part, hipStream_t s) {
+    hipLaunchKernelGGL(concat_stats_kernel, dim3((unsigned)(pixels / bm), ((Ca + Cb) / 8 + 255) / 256), dim3(256), 0, s, a, Ca, b, Cb, out, bm, part);
+}
+
 // fp32 NCHW -> bf16 NHWC with zero-padded channels (stage-level entry points: latents / features handed in by the host)
 __global__ __launch_bounds__(256) void nchw_f32_to_nhwc_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int B, int C,
                                                                 long long HW, int Cpad) {

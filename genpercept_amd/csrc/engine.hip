@@ -835,7 +835,15 @@ struct gp_engine {
                 Act skip = skips.back();
                 skips.pop_back();
                 Act cat = new_act(h.B, h.H, h.W, h.C + skip.C);
-                launch_concat(h.p, h.C, skip.p, skip.C, cat.p, h.pixels(), st);
+                const int cbm = fuse_stats ? concat_stats_bm((long long)h.H * h.W) : 0;
+                if (cbm) {  // the copy also leaves the statistics the resnet's first GroupNorm needs
+                    cat.st = (float*)pool.alloc((size_t)(h.pixels() / cbm) * cat.C * 2 * sizeof(float));
+                    cat.st_mode = 0;
+                    cat.st_bm = cbm;
+                    launch_concat_stats(h.p, h.C, skip.p, skip.C, cat.p, h.pixels(), cbm, cat.st, st);
+                } else {
+                    launch_concat(h.p, h.C, skip.p, skip.C, cat.p, h.pixels(), st);
+                }
                 tm.n_launches++;
                 drop(h);
                 drop(skip);

@@ -85,6 +85,8 @@ void launch_softmax_rows(const float* in, bf16_t* out, int rows, int T, int ld, 
 // Elementwise / layout kernels
 void launch_rgb_prologue(const void* rgb, int is_u8, bf16_t* out, int B, int H, int W, int Cpad, hipStream_t s);  // NCHW -> NHWC, x/255*2-1
 void launch_concat(const bf16_t* a, int Ca, const bf16_t* b, int Cb, bf16_t* out, long long pixels, hipStream_t s);
+int concat_stats_bm(long long hw);  // pixels per statistics tile launch_concat_stats can use for an image of hw pixels (0: none)
+void launch_concat_stats(const bf16_t* a, int Ca, const bf16_t* b, int Cb, bf16_t* out, long long pixels, int bm, float* part, hipStream_t s);
 void launch_nchw_f32_to_nhwc(const float* in, bf16_t* out, int B, int C, int H, int W, int Cpad, hipStream_t s);
 void launch_nhwc_to_nchw_f32(const bf16_t* in, float* out, int B, int C, int H, int W, int ld, hipStream_t s);
 void launch_decode_epilogue(const bf16_t* in, float* out, int B, int H, int W, int ld, int mean3, int raw, hipStream_t s);  // mean, clip, (x+1)/2
