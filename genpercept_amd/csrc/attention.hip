@@ -17,7 +17,7 @@
 // the conv kernels' slot ^ (row & 7) is not for this pattern (checked exhaustively), so the attention tiles keep their own swizzle.
 GP_DEV int attn_off128(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-__global__ __launch_bounds__(256) void flash_attn64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                             const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
                                                             const bf16_t* __restrict__ zero, int T, int heads, int ldq, int ldk, int Tpad,
                                                             int ldo) {
@@ -65,63 +65,62 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(const bf16_t* __restr
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+    float m_run = -1e30f;   // running maximum in raw-score units
+    f32x16_t l_acc, zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) l_acc[r] = zero16[r] = 0.f;
+    bf16x8_t ones_row;      // A fragment of the ones block: MFMA row l31 == 0 holds 1.0 for every key, the other rows 0
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones_row[e] = l31 == 0 ? (short)0x3f80 : (short)0;
     const float sc = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
-
-    stage(0, 0);
-    wait_vm0();
-    __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < nt; ++kt) {
-        if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
+
+    // One KV tile.  The softmax is the bound of this kernel (head_dim 64: 16 MFMAs of 32 cycles against ~32 scores per lane), so it is
+    // kept to the minimum: raw v_exp_f32 (the libm exp2f wrapper added a compare, two selects and a v_ldexp per score), the 1/sqrt(d)
+    // * log2(e) scale folded into one FMA per score (the running maximum is tracked on the RAW scores; sc > 0 keeps the order), key
+    // masking only in the last tile (MASK), and the accumulator rescale skipped while no lane's maximum moves.
+    auto tile = [&](int kt, auto maskc) __attribute__((always_inline)) {
+        constexpr bool MASK = decltype(maskc)::value != 0;
         const char* sb = smem + cur * STAGE;
         // ---- S^T = K Q^T: two 32-key blocks, 4 k-steps of 16 over d
         f32x16_t s_acc[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.f;
             const int row = kb * 32 + l31;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8_t kf = *(const bf16x8_t*)(sb + attn_off128(row, ks * 2 + hh));
-                s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc[kb], 0, 0, 0);
+                s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : s_acc[kb], 0, 0, 0);  // C = 0: inline constant
             }
         }
         // ---- online softmax over this lane's 32 keys (+ the other half's 32 via lane ^ 32)
-        const int kbase = kt * 64 + 4 * hh;
-        const bool tail = (kt * 64 + 64) > T;
-        float mx = -1e30f;
+        if (MASK) {
+            const int kbase = kt * 64 + 4 * hh;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s = s_acc[kb][r] * sc;
-                if (tail) {
-                    const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2);
-                    if (key >= T) s = -1e30f;
-                }
-                s_acc[kb][r] = s;
-                mx = fmaxf(mx, s);
-            }
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + kb * 32 + (r & 3) + 8 * (r >> 2) >= T) s_acc[kb][r] = -1e30f;
+        }
+        float mx = fmaxf(s_acc[0][0], s_acc[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s_acc[0][r], s_acc[1][r]));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
+        const float m_new = fmaxf(m_run, mx);              // raw-score units
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+        const float nm = -m_new * sc;
         m_run = m_new;
-        float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(s_acc[kb][r] - m_new);
-                s_acc[kb][r] = pv;
-                rs += pv;
-            }
-        l_run = l_run * alpha + rs;
+            for (int r = 0; r < 16; ++r) s_acc[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][r], sc, nm));
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {  // (uniform) some query's maximum moved: rescale the accumulators
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+            for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+            l_acc[0] *= alpha;  // (only row 0 of the ones block is non-zero)
+        }
         // ---- O^T += V^T P^T: k-steps (kb, j) of 16 keys; this lane's P for its own query is the B operand
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -131,6 +130,9 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(s_acc[kb][8 * j + 2 * e], s_acc[kb][8 * j + 2 * e + 1]);
                 const int ko = kb * 32 + 16 * j + 4 * hh;  // key offset inside the tile (multiple of 4)
+                // row sums on the matrix pipe (it has slack, the VALU does not): a third "V^T" block whose row 0 is all ones gives
+                // sum_k P[k][q] of the bf16-rounded probabilities, over BOTH key halves, in register 0 of the lanes with hh == 0
+                l_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_row, pf.v, l_acc, 0, 0, 0);
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
                     const int row = d * 32 + l31;
@@ -142,12 +144,20 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(const bf16_t* __restr
                     o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o_acc[d], 0, 0, 0);
                 }
             }
+    };
+
+    stage(0, 0);
+    wait_vm0();
+    __syncthreads();
+    for (int kt = 0; kt < nt; ++kt) {
+        if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
+        if (kt * 64 + 64 > T) tile(kt, IC<1>{}); else tile(kt, IC<0>{});
         if (kt + 1 < nt) wait_vm0();
         __syncthreads();
         cur ^= 1;
     }
     // ---- normalise and store O[q][d] (this lane: q = l31, d = 32*blk + 8*(r>>2) + 4*hh + (r&3))
-    l_run += __shfl_xor(l_run, 32);
+    const float l_run = __shfl(l_acc[0], l31);  // row 0 of the ones block lives in the hh == 0 lanes (D row = 8 * (r >> 2) + 4 * hh + (r & 3))
     const float inv = 1.f / l_run;
     const int q = q0 + l31;
     if (q < T) {
