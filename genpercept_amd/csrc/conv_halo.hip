@@ -1,21 +1,22 @@
-// conv3x3 (stride 1, pad 1; optionally on a nearest-x2-upsampled input) with halo reuse — the kernel for the large VAE /
-// UNet feature maps, where the generic implicit GEMM (igemm.hip) is bound by operand loads: it re-fetches every input
-// pixel once per tap.  Here a workgroup owns a 16x16 OUTPUT-PIXEL tile x 128 output channels and, per 64-channel chunk,
-// stages the 18x18 input halo (10x10 source pixels in the x2-upsample case) in LDS ONCE; the nine taps then read shifted
-// rows of that halo.  Only the weight tiles ([128 cout][64 cin] per tap) stream per K-step, through a 4-deep LDS-DMA ring.
+// conv3x3 (stride 1, pad 1; optionally on a nearest-x2-upsampled input) with halo reuse — the kernels for the large VAE /
+// UNet feature maps (57 % of the 768x768 pass), where the generic implicit GEMM (igemm.hip) is bound by operand loads: it
+// re-fetches every input pixel once per tap.  Here a workgroup owns a 16x16 OUTPUT-PIXEL tile x 128 output channels and, per
+// 64-channel chunk, stages the 18x18 input halo (10x10 source pixels in the x2-upsample case) in LDS ONCE; the nine taps then
+// read shifted rows of that halo.  Only the weight tiles ([128 cout][64 cin] per tap) stream per K-step through an LDS-DMA ring.
 //
-//   LDS: 2 x 41 KiB halo (double-buffered across channel chunks) + 4 x 16 KiB weight ring + 1 KiB dump + 12 KiB GroupNorm
-//        scale/shift = 158 KiB, 1 workgroup/CU, 8 waves (4 groups of 4 pixel rows x 2 channel halves), each wave 64 pixels x
-//        64 channels = 16 accumulator tiles of v_mfma_f32_16x16x32_bf16.
+//   Waves: 8 = 4 groups of 4 pixel rows x 2 channel halves, each 64 pixels x 64 channels = 16 accumulator tiles of
+//        v_mfma_f32_16x16x32_bf16; 1 workgroup per CU.
 //   K-step = (chunk, tap): 2 weight DMAs per wave (+ 6 halo DMAs once per chunk), 16 ds_read_b128, 32 MFMAs.
-//   Software pipeline: the barrier at the top of step s certifies the operands of step s+1, so all 16 fragments of step s+1
-//        are read from LDS while step s's 32 MFMAs issue from registers (ping-pong register sets, loop unrolled by two);
-//        LDS latency never sits between a barrier and an MFMA.
+//   Software pipeline: the barrier at the end of step s-1 certifies the operands of step s+1, so the fragments of step s+1 are
+//        read from LDS between step s's MFMAs (2 MFMA : 1 ds_read, pinned with sched_group_barrier); LDS latency never sits
+//        between a barrier and an MFMA.
 //   Sync: counted s_waitcnt vmcnt + ONE raw s_barrier per K-step; waves 4-7 issue their DMA before their MFMAs, waves 0-3
-//        after (role split), so each SIMD overlaps one wave's matrix work with its partner's memory work.
+//        after (role split).
 //   Optional fused input transform x -> act(x * scale[b][c] + shift[b][c]) (GroupNorm apply + SiLU) on the staged halo of the
-//        NEXT chunk, one 16-byte item per thread per K-step, hidden under the MFMA steps; padding stays exactly zero.
-//   Epilogue: epilogue.h (LDS-staged coalesced stores, fused bias / residual / activation).
+//        NEXT chunk; padding stays exactly zero.
+//   Two kernels share this tiling: conv3x3_halo3_kernel (persistent: a workgroup walks many tiles, per-wave epilogue; the product
+//        path) and conv3x3_halo2_kernel (one tile per workgroup, shared epilogue.h; fallback for ragged channel slots and the
+//        A/B partner for measurements).
 #include "common.h"
 #include "epilogue.h"
 #include "kernels.h"
