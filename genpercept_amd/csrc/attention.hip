@@ -258,6 +258,63 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int i = tid; i < ld; i += 256) y[i] = i < T ? f2bf(exp2f(x[i] * sc - mx) * inv) : (bf16_t)0;
 }
 
+// The same with the row held in registers (ld <= 1024 * NV floats, ld % 4 == 0): ONE 16-byte-per-lane read pass instead of three
+// 4-byte ones, raw v_exp_f32 computed once per element, 8-byte stores.  HBM-bound: 6 B per score.
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int T, int ld, float scale) {
+    __shared__ float red[8];
+    const long long row = blockIdx.x;
+    const float4* x = (const float4*)(in + row * ld);
+    uint2* y = (uint2*)(out + row * ld);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float sc = scale * 1.44269504088896340736f;
+    const int nvec = ld >> 2;
+    float4 v[NV];
+    float mx = -1e30f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = k * 256 + tid;
+        v[k] = i < nvec ? x[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int e0 = i * 4;
+        v[k].x = e0 + 0 < T ? v[k].x : -1e30f;
+        v[k].y = e0 + 1 < T ? v[k].y : -1e30f;
+        v[k].z = e0 + 2 < T ? v[k].z : -1e30f;
+        v[k].w = e0 + 3 < T ? v[k].w : -1e30f;
+        mx = fmaxf(mx, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));  // raw-logit units (scale > 0)
+    const float nm = -mx * sc;
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        v[k].x = __builtin_amdgcn_exp2f(__builtin_fmaf(v[k].x, sc, nm));
+        v[k].y = __builtin_amdgcn_exp2f(__builtin_fmaf(v[k].y, sc, nm));
+        v[k].z = __builtin_amdgcn_exp2f(__builtin_fmaf(v[k].z, sc, nm));
+        v[k].w = __builtin_amdgcn_exp2f(__builtin_fmaf(v[k].w, sc, nm));
+        sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red[4 + wv] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = k * 256 + tid;
+        if (i < nvec) y[i] = pack_bf16x4(v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv);  // masked tail: exp2(-huge) = 0
+    }
+}
+
 void launch_softmax_rows(const float* in, bf16_t* out, int rows, int T, int ld, float scale, hipStream_t s) {
+    if ((ld & 3) == 0 && scale > 0.f && ld <= 16384) {
+        if (ld <= 4096) hipLaunchKernelGGL(softmax_rows_reg_kernel<4>, dim3(rows), dim3(256), 0, s, in, out, T, ld, scale);
+        else if (ld <= 9216) hipLaunchKernelGGL(softmax_rows_reg_kernel<9>, dim3(rows), dim3(256), 0, s, in, out, T, ld, scale);
+        else hipLaunchKernelGGL(softmax_rows_reg_kernel<16>, dim3(rows), dim3(256), 0, s, in, out, T, ld, scale);
+        return;
+    }
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, in, out, T, ld, scale);
 }
