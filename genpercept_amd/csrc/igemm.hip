@@ -56,7 +56,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
     const bf16_t* wt = p.wt + (long long)z * p.wt_bs;
     const int Cin = p.Cin;
     const int cpt = Cin >> 6;                       // 64-channel chunks per tap
-    const int nk = (CONV ? 9 : 1) * cpt;
+    const int nk_all = (CONV ? 9 : 1) * cpt;
+    // split-K: slice blockIdx.z of p.ksplit handles K-steps [k_begin, k_begin + nk)
+    const int zs = p.ksplit > 1 ? (int)blockIdx.z : 0;
+    const int k_begin = p.ksplit > 1 ? (int)((long long)nk_all * zs / p.ksplit) : 0;
+    const int nk = p.ksplit > 1 ? (int)((long long)nk_all * (zs + 1) / p.ksplit) - k_begin : nk_all;
 
     // this lane's 16-byte source chunk inside a 128-byte row (swizzled; identical for every DMA group of the wave)
     //   pixel tile:  slot ^ (row & 7)                              rows read 16-consecutive (conflict-free for any start row)
@@ -111,7 +115,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
     const float ups_sy = UPS ? (float)p.Hi / (float)p.Hu : 1.f;
     const float ups_sx = UPS ? (float)p.Wi / (float)p.Wu : 1.f;
 
-    int st_tap = 0, st_cc = 0, st_ky = 0, st_kx = 0;
+    int st_tap = CONV ? k_begin / cpt : 0, st_cc = CONV ? k_begin - st_tap * cpt : k_begin;
+    int st_ky = st_tap / 3, st_kx = st_tap - 3 * st_ky;
     auto stage = [&](int buf) {
         char* sb = smem + buf * STAGE;
         if constexpr (UPS) {
@@ -219,11 +224,69 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
 
     // ---- epilogue (epilogue.h): LDS-staged, fully coalesced bf16 stores ---------------------------------------------------
     if ((p.dbg & 16) && m0 >= 0) return;  // ablation: no epilogue
+    if (p.ksplit > 1) {  // fp32 partial sums of this K slice (launch_igemm set out_fp32, no bias / residual / activation)
+        IGemmParams pe = p;
+        pe.out = (float*)p.out + (long long)zs * p.split_bs;
+        conv_epilogue<BM, BN, WM, WN, 64 * NW>(pe, acc, bcol, n0, z, wave, lane, smem, [&](int pr) {
+            const int m = m0 + pr;
+            return m < p.M ? m : -1;
+        }, sid / tiles_n);
+        return;
+    }
     conv_epilogue<BM, BN, WM, WN, 64 * NW>(p, acc, bcol, n0, z, wave, lane, smem, [&](int pr) {
         const int m = m0 + pr;
         return m < p.M ? m : -1;
     }, sid / tiles_n);
 }
+
+// ---- split-K: out[m][n] = act( sum_z part[z][m][n] + bias[n] ) (+ res[m][n]); columns in [n_out, n_store) are written as 0 ----------
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, long long slice, int M, int N, int n_store,
+                                                             const float* __restrict__ bias, const bf16_t* __restrict__ res, int ldres, int act,
+                                                             bf16_t* __restrict__ out, int ldo) {
+    const int nv = n_store >> 2;  // 4 columns per thread (n_store % 4 == 0)
+    const long long total = (long long)M * nv;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = i / nv;
+        const int c = (int)(i - m * nv) * 4;
+        float4 a = *(const float4*)(part + m * n_store + c);
+        for (int z = 1; z < S; ++z) {
+            const float4 b = *(const float4*)(part + z * slice + m * n_store + c);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (c + e < N) {
+                if (bias) v[e] += bias[c + e];
+                if (res) v[e] += bf2f(res[m * ldres + c + e]);
+                if (act == GP_ACT_SILU) v[e] = silu_f(v[e]);
+                else if (act == GP_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+            } else {
+                v[e] = 0.f;
+            }
+        }
+        *(uint2*)(out + m * ldo + c) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// number of K slices launch_igemm will use (1 = none): 3x3 convs on tiny maps (M = 576 for 12x12 x 4 images, K = 11520 .. 23040) leave
+// 180 workgroups of 4 waves on 256 CUs with 180+ dependent K-steps each -- 200 TFLOP/s; slicing K fills the machine.
+int igemm_ksplit(const IGemmParams& p, int tile_hint) {
+    static const bool no_split = getenv("GENPERCEPT_NO_SPLITK") != nullptr;
+    if (tile_hint != 0 && tile_hint != 2) return 1;
+    if (no_split || p.ks != 3 || p.ups || p.batch > 1 || p.out_fp32 || p.act == GP_ACT_GEGLU || p.bias_mode == GP_BIAS_ROW || p.in_scale) return 1;
+    if ((p.n_store & 3) || (p.ldo & 3) || p.n_store != p.ldo) return 1;
+    if (conv_uses_halo(p, tile_hint)) return 1;
+    const int ncols = p.N > p.n_store ? p.N : p.n_store;
+    const long long t64 = (long long)((p.M + 63) / 64) * ((ncols + 63) / 64);
+    const int nk = 9 * (p.Cin >> 6);
+    if (t64 >= 384 || nk < 32) return 1;
+    int S = (int)(768 / t64);           // three 64x64 workgroups fit a CU
+    if (S > 8) S = 8;
+    while (S > 1 && nk / S < 12) --S;
+    return S < 2 ? 1 : S;
+}
+
 
 template <int BM, int BN, int WM, int WN, int KS, int NSTAGE>
 static void launch_one(const IGemmParams& p, dim3 grid, hipStream_t s) {
@@ -240,7 +303,7 @@ template <int BM, int BN, int WM, int WN, int NSTAGE>
 static void launch_cfg(const IGemmParams& p, hipStream_t s) {
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
     const int tiles = ((p.M + BM - 1) / BM) * ((ncols + BN - 1) / BN);
-    dim3 grid(tiles, p.batch > 0 ? p.batch : 1);
+    dim3 grid(tiles, p.batch > 0 ? p.batch : 1, p.ksplit > 1 ? p.ksplit : 1);
     if (p.ks == 3 && p.ups) launch_one<BM, BN, WM, WN, 4, NSTAGE>(p, grid, s);
     else if (p.ks == 3) launch_one<BM, BN, WM, WN, 3, NSTAGE>(p, grid, s);
     else launch_one<BM, BN, WM, WN, 1, NSTAGE>(p, grid, s);
@@ -284,6 +347,7 @@ static int select_cfg(const IGemmParams& p, int tile_hint) {
 int igemm_tile_info(const IGemmParams& p, int tile_hint, int* mode, int* bm) {
     // the staged epilogue is the only one that accumulates statistics (epilogue.h)
     if (p.out_fp32 || p.act == GP_ACT_GEGLU || (p.ldo & 7) || p.batch > 1 || p.N != p.n_store) return 0;
+    if (igemm_ksplit(p, tile_hint) > 1) return 0;  // partial sums: no epilogue statistics
     if (conv_uses_halo(p, tile_hint)) {
         *mode = 1;
         *bm = 256;
@@ -305,6 +369,29 @@ void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s) {
     if (igemm_uses_pgemm(p, tile_hint)) {
         launch_pgemm(p, s);
         return;
+    }
+    const int S = igemm_ksplit(p, tile_hint);
+    if (S > 1) {
+        static float* ws = nullptr;
+        static size_t ws_floats = 0;
+        const size_t slice = (size_t)p.M * p.n_store, need = slice * S;
+        if (need > ws_floats) {
+            if (ws) { (void)hipDeviceSynchronize(); (void)hipFree(ws); }
+            if (hipMalloc((void**)&ws, need * sizeof(float)) != hipSuccess) { ws = nullptr; ws_floats = 0; }
+            else ws_floats = need;
+        }
+        if (ws) {
+            IGemmParams q = p;
+            q.out = ws; q.out_fp32 = 1; q.ldo = p.n_store; q.bias = nullptr; q.bias_mode = GP_BIAS_NONE; q.res = nullptr; q.act = GP_ACT_NONE;
+            q.stats_out = nullptr; q.ksplit = S; q.split_bs = (long long)slice;
+            launch_cfg<64, 64, 2, 2, 3>(q, s);
+            const long long total = (long long)p.M * (p.n_store >> 2);
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, S, (long long)slice, p.M, p.N, p.n_store,
+                               p.bias_mode == GP_BIAS_COL ? p.bias : nullptr, p.res, p.ldres, p.act, (bf16_t*)p.out, p.ldo);
+            return;
+        }
     }
     const int cfg = select_cfg(p, tile_hint);
     if (cfg == 1) launch_cfg<128, 128, 2, 2, 2>(p, s);

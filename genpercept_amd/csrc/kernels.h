@@ -38,6 +38,8 @@ struct IGemmParams {
     int act, bias_mode;
     int dbg;              // ablation bits for profiling only (1: no DMA in the loop, 2: no MFMA work, 4: no waits/barriers)
     int batch;            // grid.y batches with the strides below (elements)
+    int ksplit;           // > 1: grid.z = ksplit slices of the K loop, slice z writes fp32 partials at out + z * split_bs (set by launch_igemm)
+    long long split_bs;
     long long in_bs, wt_bs, out_bs, res_bs, bias_bs;
 };
 

@@ -58,6 +58,8 @@ CONV_CASES = [
     (2, 16, 16, 64, 64, 1), (2, 16, 16, 64, 64, 2), (2, 16, 16, 64, 64, 3),
     (1, 24, 20, 128, 320, 0), (1, 13, 15, 192, 100, 1), (3, 9, 7, 64, 3, 0), (1, 12, 12, 1280, 1280, 0), (1, 40, 36, 256, 128, 1),
     (2, 16, 16, 64, 64, 4), (1, 40, 36, 256, 128, 4), (2, 33, 31, 128, 320, 4), (1, 96, 96, 128, 128, 0), (1, 17, 19, 64, 200, 2),
+    # split-K path (tiny maps, long K): 4 / 8 / 2 slices, ragged rows and columns
+    (4, 12, 12, 1280, 1280, 0), (1, 12, 12, 2560, 1280, 0), (2, 12, 12, 640, 320, 0), (1, 9, 11, 1280, 200, 2),
 ]
 
 
@@ -111,7 +113,7 @@ def test_conv3x3_halo_kernel(case, metric_log):
     # the generic implicit GEMM (0 -> heuristic tile, 1 = 128x128, 4 = 256x128)
     (2, 32, 32, 128, 128, 3, False, True, 5), (1, 40, 24, 64, 192, 3, False, False, 5), (4, 144, 160, 64, 128, 3, False, True, 5),
     (1, 24, 24, 128, 128, 3, True, True, 5), (3, 112, 112, 64, 256, 3, False, False, 5),
-    (2, 32, 32, 128, 128, 3, False, True, 4), (2, 32, 32, 128, 256, 1, False, True, 1), (1, 16, 16, 320, 320, 3, False, False, 0),
+    (2, 32, 32, 128, 128, 3, False, True, 4), (2, 32, 32, 128, 256, 1, False, True, 1), (1, 16, 16, 320, 320, 3, False, False, 1),
     # persistent GEMM (hint 7): 128-row and 256-row tiles
     (4, 48, 48, 320, 640, 1, False, True, 7), (2, 96, 96, 320, 320, 1, False, False, 7), (4, 224, 224, 64, 128, 1, False, True, 7),
 ])
