@@ -24,8 +24,8 @@
 template <int N>
 GP_DEV void halo_wait_vm() { wait_vm<N>(); }
 
-constexpr int GN_MAXC = 1536;      // fused input transform: per-channel scale/shift of one image live in 12 KiB of LDS
-constexpr int HALO_NB = 4;         // weight ring depth
+constexpr int GN_MAXC = 2560;      // fused input transform: per-channel scale/shift of one image live in 20 KiB of LDS (widest UNet up-block input)
+constexpr int HALO_NB = 3;         // weight ring depth
 
 template <bool UPS>
 struct HaloGeom {

@@ -152,7 +152,8 @@ def test_conv_epilogue_groupnorm_statistics(case, metric_log):
 
 
 @pytest.mark.parametrize("case", [(2, 32, 32, 128, 128, False, True), (1, 40, 24, 320, 192, False, True), (2, 16, 16, 64, 128, False, False),
-                                  (1, 12, 16, 256, 128, True, True), (1, 17, 21, 960, 64, False, True)])
+                                  (1, 12, 16, 256, 128, True, True), (1, 17, 21, 960, 64, False, True), (1, 24, 24, 2560, 128, False, True),
+                                  (4, 48, 48, 1920, 128, False, True)])
 def test_conv3x3_fused_groupnorm_input(case, metric_log):
     """GroupNorm apply (+SiLU) fused into the halo conv's input staging; zero padding applies to the NORMALISED tensor."""
     e = _eng()
