@@ -10,6 +10,8 @@
 //   ([C][Tpad], zero-padded beyond T) by the projection GEMM.
 // cross_attn_small: cross-attention against the constant, tiny text context (L = 2 for GenPercept's empty prompt).
 // softmax_rows: row softmax for the GEMM-based single-head VAE attention (head_dim 512).
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -17,11 +19,15 @@
 // the conv kernels' slot ^ (row & 7) is not for this pattern (checked exhaustively), so the attention tiles keep their own swizzle.
 GP_DEV int attn_off128(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
+// NKB: 32-key blocks per KV tile (2: 64 keys, 4: 128 keys -- one online-softmax update, one barrier and one DMA wait per 128 keys,
+// longer independent MFMA runs)
+template <int NKB>
 __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                             const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
                                                             const bf16_t* __restrict__ zero, int T, int heads, int ldq, int ldk, int Tpad,
                                                             int ldo) {
-    constexpr int STAGE = 16384;  // K tile 8 KiB + V^T tile 8 KiB
+    constexpr int KEYS = 32 * NKB, KBYTES = KEYS * 128, NH = NKB / 2;  // NH 64-key halves, each with its own [64 d][64 keys] V^T tile
+    constexpr int STAGE = 2 * KBYTES;  // K tile + V^T tiles
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -46,18 +52,25 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t* __re
     }
 
     const int chunk = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
-    const int nt = (T + 63) >> 6;
+    const int nt = (T + KEYS - 1) / KEYS;
     auto stage = [&](int buf, int kt) {
         char* sb = smem + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = (wave + 4 * i) * 8 + (lane >> 3);
-            const int key = kt * 64 + r;
+        for (int i = 0; i < NKB; ++i) {  // K rows: 8 * (wave + 4 i) + lane / 8
+            const int g = wave + 4 * i;
+            const int key = kt * KEYS + g * 8 + (lane >> 3);
             const bf16_t* src = key < T ? Kb + (long long)key * ldk + chunk * 8 : zero + chunk * 8;
-            glds16(src, sb + (wave + 4 * i) * 1024);
-            const bf16_t* vsrc = Vb + (long long)r * Tpad + kt * 64 + chunk * 8;  // row r = head channel d
-            glds16(vsrc, sb + 8192 + (wave + 4 * i) * 1024);
+            glds16(src, sb + g * 1024);
         }
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {  // V^T rows = head channels d
+                const int r = (wave + 4 * i) * 8 + (lane >> 3);
+                const int k0 = kt * KEYS + hf * 64;
+                const bf16_t* vsrc = k0 < Tpad ? Vb + (long long)r * Tpad + k0 + chunk * 8 : zero + chunk * 8;  // (Tpad % 64 == 0)
+                glds16(vsrc, sb + KBYTES + hf * 8192 + (wave + 4 * i) * 1024);
+            }
     };
 
     f32x16_t o_acc[2];
@@ -66,26 +79,25 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
     float m_run = -1e30f;   // running maximum in raw-score units
-    f32x16_t l_acc, zero16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) l_acc[r] = zero16[r] = 0.f;
-    bf16x8_t ones_row;      // A fragment of the ones block: MFMA row l31 == 0 holds 1.0 for every key, the other rows 0
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones_row[e] = l31 == 0 ? (short)0x3f80 : (short)0;
+    float l_run = 0.f;
     const float sc = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
+    f32x16_t zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
     int cur = 0;
 
     // One KV tile.  The softmax is the bound of this kernel (head_dim 64: 16 MFMAs of 32 cycles against ~32 scores per lane), so it is
     // kept to the minimum: raw v_exp_f32 (the libm exp2f wrapper added a compare, two selects and a v_ldexp per score), the 1/sqrt(d)
     // * log2(e) scale folded into one FMA per score (the running maximum is tracked on the RAW scores; sc > 0 keeps the order), key
     // masking only in the last tile (MASK), and the accumulator rescale skipped while no lane's maximum moves.
+    // (Row sums through an extra all-ones MFMA block were tried: no gain, 16 more VGPRs.)
     auto tile = [&](int kt, auto maskc) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(maskc)::value != 0;
         const char* sb = smem + cur * STAGE;
         // ---- S^T = K Q^T: two 32-key blocks, 4 k-steps of 16 over d
-        f32x16_t s_acc[2];
+        f32x16_t s_acc[NKB];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
             const int row = kb * 32 + l31;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -95,48 +107,51 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t* __re
         }
         // ---- online softmax over this lane's 32 keys (+ the other half's 32 via lane ^ 32)
         if (MASK) {
-            const int kbase = kt * 64 + 4 * hh;
+            const int kbase = kt * KEYS + 4 * hh;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (kbase + kb * 32 + (r & 3) + 8 * (r >> 2) >= T) s_acc[kb][r] = -1e30f;
         }
-        float mx = fmaxf(s_acc[0][0], s_acc[1][0]);
+        float mx = s_acc[0][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s_acc[0][r], s_acc[1][r]));
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);              // raw-score units
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
         const float nm = -m_new * sc;
         m_run = m_new;
+        float rs = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s_acc[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][r], sc, nm));
+            for (int r = 0; r < 16; ++r) {
+                s_acc[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][r], sc, nm));
+                rs += s_acc[kb][r];
+            }
+        l_run = l_run * alpha + rs;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {  // (uniform) some query's maximum moved: rescale the accumulators
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
-            l_acc[0] *= alpha;  // (only row 0 of the ones block is non-zero)
         }
         // ---- O^T += V^T P^T: k-steps (kb, j) of 16 keys; this lane's P for its own query is the B operand
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 union { bf16x8_t v; unsigned u[4]; } pf;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(s_acc[kb][8 * j + 2 * e], s_acc[kb][8 * j + 2 * e + 1]);
-                const int ko = kb * 32 + 16 * j + 4 * hh;  // key offset inside the tile (multiple of 4)
-                // row sums on the matrix pipe (it has slack, the VALU does not): a third "V^T" block whose row 0 is all ones gives
-                // sum_k P[k][q] of the bf16-rounded probabilities, over BOTH key halves, in register 0 of the lanes with hh == 0
-                l_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_row, pf.v, l_acc, 0, 0, 0);
+                const int ko = (kb & 1) * 32 + 16 * j + 4 * hh;  // key offset inside the 64-key half (multiple of 4)
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
                     const int row = d * 32 + l31;
-                    const char* vr = sb + 8192 + row * 128;
+                    const char* vr = sb + KBYTES + (kb >> 1) * 8192 + row * 128;
                     const int sw = (row >> 1) & 7;
                     union { bf16x8_t v; uint2 h2[2]; } vf;
                     vf.h2[0] = *(const uint2*)(vr + ((((ko >> 3)) ^ sw) << 4) + (ko & 7) * 2);
@@ -151,13 +166,13 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t* __re
     __syncthreads();
     for (int kt = 0; kt < nt; ++kt) {
         if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
-        if (kt * 64 + 64 > T) tile(kt, IC<1>{}); else tile(kt, IC<0>{});
+        if (kt * KEYS + KEYS > T) tile(kt, IC<1>{}); else tile(kt, IC<0>{});
         if (kt + 1 < nt) wait_vm0();
         __syncthreads();
         cur ^= 1;
     }
     // ---- normalise and store O[q][d] (this lane: q = l31, d = 32*blk + 8*(r>>2) + 4*hh + (r&3))
-    const float l_run = __shfl(l_acc[0], l31);  // row 0 of the ones block lives in the hh == 0 lanes (D row = 8 * (r >> 2) + 4 * hh + (r & 3))
+    l_run += __shfl_xor(l_run, 32);
     const float inv = 1.f / l_run;
     const int q = q0 + l31;
     if (q < T) {
@@ -175,7 +190,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t* __re
 void launch_flash_attn64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, const bf16_t* zero, int B, int T, int heads,
                          int ldq, int ldk, int Tpad, int ldo, hipStream_t s) {
     dim3 grid((T + 127) / 128, heads, B);
-    hipLaunchKernelGGL(flash_attn64_kernel, grid, dim3(256), 32768, s, q, k, vt, out, zero, T, heads, ldq, ldk, Tpad, ldo);
+    // 64-key tiles: 156 VGPRs, three waves per SIMD.  (128-key tiles -- one softmax update, barrier and DMA wait per 128 keys -- need 256
+    // VGPRs, two waves per SIMD, and measured 8 % slower: this kernel lives on latency hiding across waves.)
+    hipLaunchKernelGGL(flash_attn64_kernel<2>, grid, dim3(256), 32768, s, q, k, vt, out, zero, T, heads, ldq, ldk, Tpad, ldo);
 }
 
 // ---- cross-attention with a tiny constant context -------------------------------------------------------------------
