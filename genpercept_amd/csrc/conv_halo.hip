@@ -434,7 +434,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     // their zeros through a select.  LDS accesses by integer address (see common.h).
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) u32x4_t* lds_u4_ptr;
-    struct TPart { u32x4_t raw; f32x4_t s0, s1, h0, h1; unsigned addr; bool ok; };
+    struct TPart { u32x4_t raw; f32x4_t s0, s1, h0, h1; float v[8]; unsigned addr; bool ok; };
     const unsigned dump_base = (unsigned)(unsigned long long)dump;
     auto tp_load = [&](TPart& t, int buf, int cc, int k) __attribute__((always_inline)) {
         int tid_o = tid;
@@ -452,15 +452,24 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         t.h0 = *(lds_f4_ptr)(a_sc + GN_MAXC * 4);
         t.h1 = *(lds_f4_ptr)(a_sc + GN_MAXC * 4 + 16);
     };
-    auto tp_finish = [&](const TPart& t) __attribute__((always_inline)) {
-        float v[8] = {bflo(t.raw.x) * t.s0.x + t.h0.x, bfhi(t.raw.x) * t.s0.y + t.h0.y, bflo(t.raw.y) * t.s0.z + t.h0.z,
-                      bfhi(t.raw.y) * t.s0.w + t.h0.w, bflo(t.raw.z) * t.s1.x + t.h1.x, bfhi(t.raw.z) * t.s1.y + t.h1.y,
-                      bflo(t.raw.w) * t.s1.z + t.h1.z, bfhi(t.raw.w) * t.s1.w + t.h1.w};
+    // arithmetic in two halves so that it can sit under BOTH MFMA batches of the step (one VALU pipe per SIMD, two waves on it: with
+    // all of it under the second batch that batch was VALU-bound while the first one had idle VALU slots)
+    auto tp_mid = [&](TPart& t) __attribute__((always_inline)) {
+        t.v[0] = bflo(t.raw.x) * t.s0.x + t.h0.x; t.v[1] = bfhi(t.raw.x) * t.s0.y + t.h0.y;
+        t.v[2] = bflo(t.raw.y) * t.s0.z + t.h0.z; t.v[3] = bfhi(t.raw.y) * t.s0.w + t.h0.w;
+        t.v[4] = bflo(t.raw.z) * t.s1.x + t.h1.x; t.v[5] = bfhi(t.raw.z) * t.s1.y + t.h1.y;
+        t.v[6] = bflo(t.raw.w) * t.s1.z + t.h1.z; t.v[7] = bfhi(t.raw.w) * t.s1.w + t.h1.w;
         if (FUSED == 2) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+            for (int e = 0; e < 4; ++e) t.v[e] = silu_f(t.v[e]);
         }
-        u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    };
+    auto tp_finish = [&](TPart& t) __attribute__((always_inline)) {
+        if (FUSED == 2) {
+#pragma unroll
+            for (int e = 4; e < 8; ++e) t.v[e] = silu_f(t.v[e]);
+        }
+        u32x4_t ov = {pack_bf16x2(t.v[0], t.v[1]), pack_bf16x2(t.v[2], t.v[3]), pack_bf16x2(t.v[4], t.v[5]), pack_bf16x2(t.v[6], t.v[7])};
         ov = t.ok ? ov : t.raw;
         *(lds_u4_ptr)t.addr = ov;
     };
@@ -685,6 +694,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         for (int k = 0; k < T_IT; ++k) {
             TPart t;
             tp_load(t, 0, 0, k);
+            tp_mid(t);
             tp_finish(t);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -723,15 +733,20 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
                 for (int u = 0; u < NP; ++u) tp_load(tp[u], PAR ^ 1, fcc, P0 + u);
             }
             load_half(nxt1, IC<TAP1>{}, IC<PAR1>{}, IC<1>{});
+            if constexpr (NP > 0) {
+#pragma unroll
+                for (int u = 0; u < NP; ++u) tp_mid(tp[u]);
+            }
             mfma16(f0);
             if constexpr (NP == 0) {
                 interleave();
-            } else {  // 16 MFMAs, 8 + 5 NP LDS reads
-                constexpr int NA = NP == 1 ? 5 : 2, RA = NP == 1 ? 2 : 3, RB = NP == 1 ? 1 : 2;  // NA groups of RA reads, then RB reads
+            } else {  // 16 MFMAs; 8 + 5 NP LDS reads under the first ones, then ~38 NP VALU + 8 NP transcendentals under the rest
+                constexpr int NR = NP == 1 ? 7 : 6;  // MFMAs that carry the reads
 #pragma unroll
-                for (int q = 0; q < NA; ++q) { sgb<0x008, 2>(); sgb<0x100, RA>(); }
+                for (int q = 0; q < 6; ++q) { sgb<0x008, 1>(); sgb<0x100, NP == 1 ? 2 : 3>(); }
+                if constexpr (NP == 1) { sgb<0x008, 1>(); sgb<0x100, 1>(); }
 #pragma unroll
-                for (int q = NA; q < 8; ++q) { sgb<0x008, 2>(); sgb<0x100, RB>(); }
+                for (int q = NR; q < 16; ++q) { sgb<0x008, 1>(); sgb<0x002, 4 * NP>(); sgb<0x400, NP>(); }
             }
             __builtin_amdgcn_sched_barrier(0);
             load_half(f0, IC<TAP1>{}, IC<PAR1>{}, IC<0>{});
@@ -742,12 +757,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
             mfma16(cur1);
             if constexpr (NP == 0) {
                 interleave();
-            } else {  // 16 MFMAs, 8 LDS reads, ~60 NP VALU + 16 NP transcendentals, NP LDS writes
+            } else {  // 16 MFMAs, 8 LDS reads, ~24 NP VALU + 8 NP transcendentals, NP LDS writes
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    sgb<0x008, 1>(); sgb<0x002, 4 * NP>(); sgb<0x400, NP>();
-                    sgb<0x008, 1>(); sgb<0x100, 1>(); sgb<0x002, 4 * NP>(); sgb<0x400, NP>();
-                }
+                for (int q = 0; q < 8; ++q) { sgb<0x008, 2>(); sgb<0x100, 1>(); sgb<0x002, 3 * NP>(); sgb<0x400, NP>(); }
                 sgb<0x200, NP>();
             }
         } else {
