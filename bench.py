@@ -116,15 +116,15 @@ def main():
             ach = tm["flops_igemm"] / (tm["ms_igemm"] * 1e-3) / 1e12
             traffic = None  # HBM bytes per launch from the committed PMC passes (tools/gpu_pmc_traffic.sh; FETCH_SIZE doubled on gfx950)
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_summary.json")))
-                fam = lambda d: sum(v["sum_kb"] for k, v in d.items() if "igemm_kernel" in k or "conv3x3_halo" in k)  # noqa: E731
-                nd = sum(v["dispatches"] for k, v in tj["FETCH_SIZE"].items() if "igemm_kernel" in k or "conv3x3_halo" in k)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_summary_v2.json")))
+                fam = lambda d: sum(v["sum_kb"] for k, v in d.items() if "gemm_kernel" in k or "conv3x3_halo" in k)  # noqa: E731
+                nd = sum(v["dispatches"] for k, v in tj["FETCH_SIZE"].items() if "gemm_kernel" in k or "conv3x3_halo" in k)
                 traffic = round((2.0 * fam(tj["FETCH_SIZE"]) + fam(tj["WRITE_SIZE"])) * 1024.0 / max(nd, 1))
             except Exception:
                 pass
             roofline = {"bound": "mfma", "kernel": "implicit-GEMM conv/linear family (conv3x3_halo3_kernel + pgemm_kernel + igemm_kernel, v_mfma_f32_16x16x32_bf16)",
                         "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                        "traffic_note": "bytes per launch, PMC (2*FETCH_SIZE + WRITE_SIZE) of profiles/r01_pmc_traffic_summary.json",
+                        "traffic_note": "bytes per launch, PMC (2*FETCH_SIZE + WRITE_SIZE) of profiles/r01_pmc_traffic_summary_v2.json",
                         "launches": tm["n_igemm"], "flops_per_launch_avg": tm["flops_igemm"] / max(tm["n_igemm"], 1),
                         "avg_launch_ms": tm["ms_igemm"] / max(tm["n_igemm"], 1),
                         "attn_achieved": round(tm["flops_attn"] / max(tm["ms_attn"], 1e-9) / 1e9, 2), "attn_launches": tm["n_attn"],
