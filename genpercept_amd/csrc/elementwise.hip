@@ -307,3 +307,126 @@ void launch_minmax_norm(float* x, int B, long long n, float* ws, hipStream_t s) 
     hipLaunchKernelGGL(minmax_partial_kernel, dim3(nparts, B), dim3(256), 0, s, (const float*)x, n, ws);
     hipLaunchKernelGGL(minmax_apply_kernel, dim3(grid_for(n), B), dim3(256), 0, s, x, n, (const float*)ws, nparts);
 }
+
+// ---- VAE encoder conv_in fused with the RGB prologue ------------------------------------------------------------------------------------
+// rgb [B][3][H][W] (uint8, or float already in [-1,1]) -> conv3x3(pad 1, 3 -> Cout) -> NHWC bf16, plus GroupNorm partial statistics of the
+// output (16x16 tiles, the layout of the halo conv).  Through the generic path this layer cost a 64-channel zero-padded copy of the image
+// (302 MB written and read back) and a K = 576 conv of which 27/576 was real work; here K = 27 (padded to 32) is ONE
+// v_mfma_f32_16x16x32_bf16 per 16 pixels x 16 channels, the image is read as uint8 and the layer is bound by its 2 B/element output.
+//   workgroup: 4 waves, 16x16 output pixels x 128 channels; halo 18x18x3 normalised to bf16 in LDS ([pixel][4]); k = 3 * tap + c.
+__global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict__ rgb, int is_u8, const bf16_t* __restrict__ wt, int ldw,
+                                                           const float* __restrict__ bias, bf16_t* __restrict__ out, float* __restrict__ stats,
+                                                           int B, int H, int W, int Cout) {
+    __shared__ bf16_t s_h[18 * 18 * 4];
+    __shared__ float s_red[4 * 128 * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int a = lane & 15, q = lane >> 4;
+    const int tiles_x = (W + 15) >> 4, tiles_y = (H + 15) >> 4;
+    int sp = blockIdx.x;
+    const int tx = sp % tiles_x;
+    sp /= tiles_x;
+    const int ty = sp % tiles_y, b = sp / tiles_y;
+    const int n0 = blockIdx.y * 128;
+    const int npair = min(4, (Cout - n0) >> 5);  // 32-channel pairs of fragments handled here
+    const long long HW = (long long)H * W;
+
+    // halo: (pixel, channel) items, zero outside the image (the reference pads the NORMALISED image)
+    for (int i = tid; i < 18 * 18 * 4; i += 256) {
+        const int c = i & 3, pix = i >> 2;
+        const int hy = pix / 18, hx = pix - hy * 18;
+        const int iy = ty * 16 - 1 + hy, ix = tx * 16 - 1 + hx;
+        float v = 0.f;
+        if (c < 3 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+            const long long src = ((long long)b * 3 + c) * HW + (long long)iy * W + ix;
+            v = is_u8 ? ((float)((const unsigned char*)rgb)[src] / 255.0f * 2.0f - 1.0f) : ((const float*)rgb)[src];
+        }
+        s_h[i] = f2bf(v);
+    }
+    // weight fragments: MFMA row a of fragment i (pair ip = i / 2) is output channel 32 ip + 8 (a / 4) + 4 (i & 1) + (a & 3), so that a
+    // lane ends up with 8 consecutive channels of its pixel; this lane's k = 8 q + e -> (tap, c) = (k / 3, k % 3), zero for k >= 27
+    bf16x8_t wf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ch = n0 + 32 * (i >> 1) + 8 * (a >> 2) + 4 * (i & 1) + (a & 3);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * q + e;
+            wf[i][e] = (k < 27 && (i >> 1) < npair) ? (short)wt[(long long)ch * ldw + (k / 3) * 64 + (k % 3)] : (short)0;
+        }
+    }
+    float bv[4][8];
+#pragma unroll
+    for (int ip = 0; ip < 4; ++ip)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[ip][e] = (bias && ip < npair) ? bias[n0 + 32 * ip + 8 * q + e] : 0.f;
+    __syncthreads();
+
+    float st_s[4][8], st_q[4][8];
+#pragma unroll
+    for (int ip = 0; ip < 4; ++ip)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) st_s[ip][e] = st_q[ip][e] = 0.f;
+    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int py = 4 * wave + j;
+        bf16x8_t xf;  // B operand: pixel a of row py, k = 8 q + e
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * q + e;
+            const int tap = k / 3, c = k - 3 * tap, ky = tap / 3, kx = tap - 3 * ky;
+            xf[e] = k < 27 ? (short)s_h[((py + ky) * 18 + a + kx) * 4 + c] : (short)0;
+        }
+        const int oy = ty * 16 + py, ox = tx * 16 + a;
+        const bool ok = oy < H && ox < W;
+        bf16_t* o = out + (((long long)b * H + oy) * W + ox) * Cout + n0 + 8 * q;
+#pragma unroll
+        for (int ip = 0; ip < 4; ++ip) {
+            if (ip >= npair) break;
+            const f32x4_t lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * ip], xf, zero4, 0, 0, 0);
+            const f32x4_t hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * ip + 1], xf, zero4, 0, 0, 0);
+            const float v[8] = {lo.x + bv[ip][0], lo.y + bv[ip][1], lo.z + bv[ip][2], lo.w + bv[ip][3],
+                                hi.x + bv[ip][4], hi.y + bv[ip][5], hi.z + bv[ip][6], hi.w + bv[ip][7]};
+            uint4 pk;
+            pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+            if (ok) {
+                *(uint4*)(o + 32 * ip) = pk;
+                const float r[8] = {bflo(pk.x), bfhi(pk.x), bflo(pk.y), bfhi(pk.y), bflo(pk.z), bfhi(pk.z), bflo(pk.w), bfhi(pk.w)};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { st_s[ip][e] += r[e]; st_q[ip][e] += r[e] * r[e]; }
+            }
+        }
+    }
+    if (stats) {  // per (tile, channel) sums of the stored values: 16 pixel lanes -> lane a == 0, 4 waves -> LDS -> one thread per channel
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1)
+#pragma unroll
+            for (int ip = 0; ip < 4; ++ip)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { st_s[ip][e] += __shfl_xor(st_s[ip][e], off); st_q[ip][e] += __shfl_xor(st_q[ip][e], off); }
+        if (a == 0) {
+#pragma unroll
+            for (int ip = 0; ip < 4; ++ip)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s_red[(wave * 128 + 32 * ip + 8 * q + e) * 2] = st_s[ip][e];
+                    s_red[(wave * 128 + 32 * ip + 8 * q + e) * 2 + 1] = st_q[ip][e];
+                }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < Cout) {
+            float ss = 0.f, qq = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { ss += s_red[(w * 128 + tid) * 2]; qq += s_red[(w * 128 + tid) * 2 + 1]; }
+            float* so = stats + ((long long)blockIdx.x * Cout + n0 + tid) * 2;
+            so[0] = ss;
+            so[1] = qq;
+        }
+    }
+}
+// Cout % 32 == 0; wt = packed conv weight [rows][9][64] (ldw = 576); stats (optional): [B * tiles][Cout][2], 16x16 tiles (mode 1)
+void launch_rgb_conv_in(const void* rgb, int is_u8, const bf16_t* wt, int ldw, const float* bias, bf16_t* out, float* stats, int B, int H, int W,
+                        int Cout, hipStream_t s) {
+    const int tiles = ((W + 15) / 16) * ((H + 15) / 16) * B;
+    hipLaunchKernelGGL(rgb_conv_in_kernel, dim3(tiles, (Cout + 127) / 128), dim3(256), 0, s, rgb, is_u8, wt, ldw, bias, out, stats, B, H, W, Cout);
+}

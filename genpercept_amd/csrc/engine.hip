@@ -755,13 +755,31 @@ struct gp_engine {
     // ---- stages ---------------------------------------------------------------------------------------------------
     // rgb (device NCHW) -> latent NHWC, 64 allocated channels (cfg.vae_latent_channels real, scaled by scaling_factor)
     Act vae_encode(const void* rgb, int is_u8, int B, int Hh, int Ww) {
-        Act x = new_act(B, Hh, Ww, 64);
-        launch_rgb_prologue(rgb, is_u8, x.p, B, Hh, Ww, 64, st);
-        tm.n_launches++;
-        ConvOpt oin;
-        oin.want_stats = true;
-        Act h = conv(x, convs.at("vae.encoder.conv_in"), oin);
-        drop(x);
+        const PackedW& win = convs.at("vae.encoder.conv_in");
+        Act h;
+        if (win.cout % 32 == 0 && win.cin_pad == 64 && !getenv("GENPERCEPT_NO_RGB_CONV")) {
+            // u8 image -> conv_in output in one kernel (K = 27), statistics for the first resnet's norm1 included
+            h = new_act(B, Hh, Ww, win.cout);
+            if (fuse_stats) {
+                const int nt = ((Ww + 15) / 16) * ((Hh + 15) / 16) * B;
+                h.st = (float*)pool.alloc((size_t)nt * win.cout * 2 * sizeof(float));
+                h.st_mode = 1;
+                h.st_bm = 256;
+            }
+            tm.flops_igemm += 2.0 * (double)h.pixels() * win.cout * 27.0;
+            tm.n_launches++;
+            prof_begin(0);
+            launch_rgb_conv_in(rgb, is_u8, win.w, 9 * win.cin_pad, win.bias, h.p, h.st, B, Hh, Ww, win.cout, st);
+            prof_end();
+        } else {
+            Act x = new_act(B, Hh, Ww, 64);
+            launch_rgb_prologue(rgb, is_u8, x.p, B, Hh, Ww, 64, st);
+            tm.n_launches++;
+            ConvOpt oin;
+            oin.want_stats = true;
+            h = conv(x, win, oin);
+            drop(x);
+        }
         for (int i = 0; i < 4; ++i) {
             for (int j = 0; j < cfg.vae_layers_per_block; ++j) {
                 Act y = resnet(h, "vae.encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), cfg.vae_norm_eps);
@@ -1338,6 +1356,12 @@ gp_status gp_conv2d_gn(const void* in, const void* w_packed, const float* bias, 
         HIPCHK(hipGetLastError());
         return GP_OK;
     } catch (...) { return GP_ERR_HIP; }
+}
+
+gp_status gp_rgb_conv_in(const void* rgb, int is_u8, const void* w_packed, const float* bias, void* out, int B, int H, int W, int Cout, void* stream) {
+    if (!rgb || !w_packed || !out || B < 1 || H < 1 || W < 1 || (Cout % 32)) return GP_ERR_INVALID;
+    launch_rgb_conv_in(rgb, is_u8, (const bf16_t*)w_packed, 9 * 64, bias, (bf16_t*)out, nullptr, B, H, W, Cout, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
 }
 
 gp_status gp_conv2d_stats(const void* in, const void* w_packed, const float* bias, const void* residual, void* out, int B, int H, int W, int Cin,

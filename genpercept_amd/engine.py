@@ -70,6 +70,7 @@ SYMBOLS = {
     "gp_pack_weight": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "gp_conv2d": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 17 + [_vp]),
     "gp_conv2d_gn": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 7 + [_vp, _vp, _i, _f, _i, _vp]),
+    "gp_rgb_conv_in": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "gp_conv2d_stats": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp, _vp, _i, _f, _vp, _vp, _vp]),
     "gp_gemm": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
     "gp_groupnorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
@@ -327,6 +328,18 @@ def conv2d_gn(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, gam
                           gamma.data_ptr(), beta.data_ptr(), groups, eps, int(silu), _stream_ptr())
     if st != GP_OK:
         raise RuntimeError(f"gp_conv2d_gn failed ({st})")
+    return out
+
+
+def rgb_conv_in(rgb: torch.Tensor, w_packed: torch.Tensor, bias, cout: int) -> torch.Tensor:
+    """rgb: [B,3,H,W] uint8 (0..255) or float32 in [-1,1] on the device -> conv_in output NHWC bf16 (prologue fused)."""
+    lib = load_library()
+    b, _, h, w = rgb.shape
+    rgb = rgb.contiguous()
+    out = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=rgb.device)
+    st = lib.gp_rgb_conv_in(rgb.data_ptr(), int(rgb.dtype == torch.uint8), w_packed.data_ptr(), _ptr(bias), out.data_ptr(), b, h, w, cout, _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_rgb_conv_in failed ({st})")
     return out
 
 

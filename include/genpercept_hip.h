@@ -114,6 +114,10 @@ gp_status gp_conv2d(const void* in, const void* w_packed, const float* bias, con
  * stride 1, pad 1, optional nearest x2 upsample of the normalised input; H, W >= 16 (x2: >= 8). */
 gp_status gp_conv2d_gn(const void* in, const void* w_packed, const float* bias, const void* residual, void* out, int B, int H, int W, int Cin,
                        int Cout, int ups, int act, const float* gamma, const float* beta, int groups, float eps, int silu, void* stream);
+/* VAE-encoder conv_in fused with the RGB prologue of GenPerceptPipeline.__call__ (genpercept_pipeline.py:245, x / 255 * 2 - 1) :
+ * rgb [B][3][H][W] on the device (uint8 when is_u8, else float already in [-1,1]) -> conv3x3(pad 1, 3 -> Cout) + bias -> NHWC bf16.
+ * w_packed: gp_pack_weight(.., cout, 3, 3, 64, 0, ..).  Cout % 32 == 0. */
+gp_status gp_rgb_conv_in(const void* rgb, int is_u8, const void* w_packed, const float* bias, void* out, int B, int H, int W, int Cout, void* stream);
 /* conv (3x3 pad 1 or 1x1, stride 1, optional nearest x2 upsample) whose epilogue also leaves the GroupNorm statistics of the tensor it
  * writes (per-tile channel sums), finalised to the affine form the next GroupNorm applies: scale[b][c] = gamma[c] * rstd[b][g(c)],
  * shift[b][c] = beta[c] - mean[b][g(c)] * scale[b][c].  This is how the engine skips the statistics read pass of

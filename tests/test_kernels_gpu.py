@@ -79,6 +79,26 @@ def test_conv3x3_s1(case, metric_log):
     check(f"conv3x3_s1{case}", nhwc_to_nchw(y), ref, metric_log)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 128, True), (1, 37, 50, 64, True), (1, 16, 16, 160, False), (3, 33, 17, 128, False)])
+def test_rgb_conv_in_fused_prologue(case, metric_log):
+    """RGB prologue (uint8 -> x/255*2-1, genpercept_pipeline.py:245) fused with the VAE encoder's conv_in (K = 27 as one MFMA k-step)."""
+    e = _eng()
+    b, h, w, cout, u8 = case
+    g = torch.Generator().manual_seed(h * w + cout)
+    if u8:
+        rgb = torch.randint(0, 256, (b, 3, h, w), generator=g, dtype=torch.uint8)
+        x = rbf(rgb.float() / 255.0 * 2.0 - 1.0)
+    else:
+        rgb = torch.rand(b, 3, h, w, generator=g) * 2 - 1
+        x = rbf(rgb)
+    wt = rbf(torch.randn(cout, 3, 3, 3, generator=g) / math.sqrt(27))
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, bias, padding=1)
+    d = _dev()
+    y = e.rgb_conv_in(rgb.to(d), e.pack_weight(wt, device=d), bias.to(d), cout)
+    check(f"rgb_conv_in{case}", nhwc_to_nchw(y), ref, metric_log)
+
+
 HALO_CASES = [
     # B, H, W, Cin, Cout, ups, act, residual
     (1, 16, 16, 64, 128, False, "none", False), (2, 32, 48, 128, 128, False, "none", True), (1, 40, 36, 256, 320, False, "none", True),
