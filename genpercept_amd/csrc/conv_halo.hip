@@ -666,18 +666,33 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
 #pragma unroll
             for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     };
-    auto flush_stats = [&](int tile_row) __attribute__((always_inline)) {  // after a workgroup barrier that follows epilogue(): waves (wm, wn) -> channel sums
-        if (tid < BN && n0 + tid < n_out) {
-            // (inline asm: a compiler-visible LDS read here would make hipcc drain the DMA ring first, see transform_part)
+    // Statistics are accumulated per WORKGROUP (all its tiles belong to one image and one channel slice) and written once at the end:
+    // row (b, jw / tiles_n) of [B * R][N][2], R = J / tiles_n rows per image, followed by the pixel count of every row -- 36x fewer
+    // partial rows for the finalize kernel than one per tile (2304 tiles per 768x768 image).
+    float run_s = 0.f, run_q = 0.f;
+    int run_px = 0;
+    auto flush_stats = [&]() __attribute__((always_inline)) {  // after a workgroup barrier that follows epilogue(): waves (wm, wn) -> channel sums
+        const int ty = sp_cur / tiles_x, tx = sp_cur - ty * tiles_x;
+        run_px += min(16, Ho - 16 * ty) * min(16, Wo - 16 * tx);
+        if (tid < BN) {
+            // (inline asm: a compiler-visible LDS read here would make hipcc drain the DMA ring first, see tp_load)
             const unsigned a = st_base + (unsigned)tid * 8u;  // [(wm * 2 + wn) * 64 + ch][2] floats, tid = wn * 64 + ch
             f32x2_t v0, v1, v2, v3;
             asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:1024\n\tds_read_b64 %2, %4 offset:2048\n\t"
                          "ds_read_b64 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
                          : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
-            float* so = p.stats_out + ((long long)tile_row * p.N + n0 + tid) * 2;
-            so[0] = ((v0.x + v1.x) + v2.x) + v3.x;
-            so[1] = ((v0.y + v1.y) + v2.y) + v3.y;
+            run_s += ((v0.x + v1.x) + v2.x) + v3.x;
+            run_q += ((v0.y + v1.y) + v2.y) + v3.y;
         }
+    };
+    auto store_stats = [&]() __attribute__((always_inline)) {
+        const int R = J / tiles_n, row = b * R + jw / tiles_n;
+        if (tid < BN && n0 + tid < n_out) {
+            float* so = p.stats_out + ((long long)row * p.N + n0 + tid) * 2;
+            so[0] = run_s;
+            so[1] = run_q;
+        }
+        if (tid == 0 && nt == 0) p.stats_out[(long long)p.B * R * p.N * 2 + row] = (float)run_px;
     };
 
     // ---- prologue (first tile) ---------------------------------------------------------------------------------------------------------
@@ -796,7 +811,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         if (tile_end) {
             if (want_stats) {
                 if (final_) __syncthreads();  // (nothing in flight any more)
-                flush_stats(b * tiles_sp + sp_cur);
+                flush_stats();
+                if (final_) store_stats();
             }
             sp_cur += sp_stride;
             cc = 0;
@@ -850,28 +866,52 @@ static void launch_halo3(const IGemmParams& p, int grid, hipStream_t s) {
     else launch_halo3_one<false, 0, 0>(p, grid, s);
 }
 
-void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
-    const int ncols = p.N > p.n_store ? p.N : p.n_store;
-    const int tiles_n = (ncols + 127) / 128, tiles_sp = ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
+static int halo_ncu() {
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;
         hipDeviceProp_t pr;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
         if (ncu <= 0) ncu = 256;
+    }
+    return ncu;
+}
+// persistent kernel: B x J workgroups, J = workgroups per image (a multiple of tiles_n, about #CU / B)
+static int halo3_wgs_per_image(const IGemmParams& p, int ncu) {
+    const int ncols = p.N > p.n_store ? p.N : p.n_store;
+    const int tiles_n = (ncols + 127) / 128, tiles_sp = ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
+    int per_img = ncu / p.B;
+    if (per_img < 1) per_img = 1;
+    int J = (per_img / tiles_n) * tiles_n;
+    if (J < tiles_n) J = tiles_n;
+    if (J > tiles_sp * tiles_n) J = tiles_sp * tiles_n;
+    return J;
+}
+static bool halo_persistent(const IGemmParams& p) {
+    const bool slots_ok = (p.n_store & 7) == 0 && (p.ldo & 7) == 0 && (!p.res || ((p.ldres & 7) == 0 && p.ldres >= p.n_store));
+    return slots_ok && !(p.dbg & 256);
+}
+// statistics rows per image the halo kernel will write for this problem (per-workgroup partials + counts, "mode 2"); 0 = one row per
+// 16x16 tile ("mode 1", conv3x3_halo2_kernel)
+int conv_halo_stat_rows(const IGemmParams& p) {
+    if (!halo_persistent(p)) return 0;
+    const int ncols = p.N > p.n_store ? p.N : p.n_store;
+    return halo3_wgs_per_image(p, halo_ncu()) / ((ncols + 127) / 128);
+}
+
+void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
+    const int ncols = p.N > p.n_store ? p.N : p.n_store;
+    const int tiles_n = (ncols + 127) / 128, tiles_sp = ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
+    const int ncu = halo_ncu();
+    static bool attr = false;
+    if (!attr) {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<false>::LDS);
         (void)hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<true>::LDS);
+        attr = true;
     }
     // (conv_halo_applicable guarantees whole 128-row weight tiles)
-    const bool slots_ok = (p.n_store & 7) == 0 && (p.ldo & 7) == 0 && (!p.res || ((p.ldres & 7) == 0 && p.ldres >= p.n_store));
-    if (slots_ok && !(p.dbg & 256)) {
-        // persistent kernel: B x J workgroups, J = workgroups per image (a multiple of tiles_n, about #CU / B)
-        int per_img = ncu / p.B;
-        if (per_img < 1) per_img = 1;
-        int J = (per_img / tiles_n) * tiles_n;
-        if (J < tiles_n) J = tiles_n;
-        if (J > tiles_sp * tiles_n) J = tiles_sp * tiles_n;
-        launch_halo3(p, p.B * J, s);
+    if (halo_persistent(p)) {
+        launch_halo3(p, p.B * halo3_wgs_per_image(p, ncu), s);
         return;
     }
     const int tiles = tiles_sp * p.B * tiles_n;

@@ -504,7 +504,7 @@ struct gp_engine {
         int mode = 0, bm = 0;
         const int nt = igemm_tile_info(p, 0, &mode, &bm);
         if (nt <= 0) return;
-        y.st = (float*)pool.alloc((size_t)nt * p.N * 2 * sizeof(float));
+        y.st = (float*)pool.alloc((size_t)nt * (p.N * 2 + 1) * sizeof(float));
         y.st_mode = mode;
         y.st_bm = bm;
         p.stats_out = y.st;
@@ -1382,7 +1382,7 @@ gp_status gp_conv2d_stats(const void* in, const void* w_packed, const float* bia
         int mode = 0, bm = 0;
         const int nt = igemm_tile_info(p, tile_hint, &mode, &bm);
         if (nt <= 0) return GP_ERR_INVALID;
-        const size_t need = (size_t)nt * Cout * 2;
+        const size_t need = (size_t)nt * (Cout * 2 + 1);
         static float* part = nullptr;
         static size_t part_floats = 0;
         if (need > part_floats) {

@@ -349,6 +349,12 @@ int igemm_tile_info(const IGemmParams& p, int tile_hint, int* mode, int* bm) {
     if (p.out_fp32 || p.act == GP_ACT_GEGLU || (p.ldo & 7) || p.batch > 1 || p.N != p.n_store) return 0;
     if (igemm_ksplit(p, tile_hint) > 1) return 0;  // partial sums: no epilogue statistics
     if (conv_uses_halo(p, tile_hint)) {
+        const int R = conv_halo_stat_rows(p);
+        if (R > 0) {  // persistent kernel: one partial row per workgroup
+            *mode = 2;
+            *bm = R;
+            return R * p.B;
+        }
         *mode = 1;
         *bm = 256;
         return ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16) * p.B;

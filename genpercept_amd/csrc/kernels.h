@@ -53,8 +53,10 @@ bool igemm_uses_pgemm(const IGemmParams& p, int tile_hint);
 bool conv_halo_applicable(const IGemmParams& p);   // includes the Cin <= 2048 limit when in_scale is set
 void launch_conv_halo(const IGemmParams& p, hipStream_t s);
 bool conv_uses_halo(const IGemmParams& p, int tile_hint);
-// Pixel tiling launch_igemm(p, tile_hint) will use: mode 1 = 16x16 halo tiles per image, mode 0 = BM consecutive rows; returns the number
-// of pixel tiles, or 0 when that kernel path cannot produce stats_out (direct epilogue, GEGLU, fp32 output, ...).
+int conv_halo_stat_rows(const IGemmParams& p);     // > 0: statistics rows per image (per-workgroup partials + pixel counts, mode 2)
+// Statistics layout launch_igemm(p, tile_hint) will write: mode 0 = rows of BM consecutive pixels, mode 1 = 16x16 halo tiles per image,
+// mode 2 = *bm rows per image, each with its own pixel count appended after the [rows][N][2] sums; returns the number of rows (callers
+// allocate rows * (2 N + 1) floats), or 0 when that kernel path cannot produce stats_out (direct epilogue, GEGLU, fp32 output, ...).
 int igemm_tile_info(const IGemmParams& p, int tile_hint, int* mode, int* bm);
 // scale/shift from per-tile channel partials written by a conv epilogue (instead of launch_groupnorm_stats)
 void launch_groupnorm_from_partials(const float* partials, int mode, int bm, int B, int H, int W, int C, int G, float eps, const float* gamma,

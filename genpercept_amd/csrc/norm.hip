@@ -192,10 +192,12 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __r
     const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int cpg = C / G;
     const int tiles_x = (W + 15) >> 4, tiles_y = (H + 15) >> 4;
-    const int ntile = mode ? tiles_x * tiles_y : (H * W) / bm;
+    const int ntile = mode == 2 ? bm : mode ? tiles_x * tiles_y : (H * W) / bm;
     const float* pb = part + (long long)b * ntile * C * 2;
+    const float* cnt = part + (long long)gridDim.y * ntile * C * 2 + (long long)b * ntile;  // mode 2: pixel count of every row
     const int items = ntile * cpg;
     auto tile_px = [&](int t) -> float {
+        if (mode == 2) return cnt[t];
         if (!mode) return (float)bm;
         const int ty = t / tiles_x, tx = t - ty * tiles_x;
         return (float)(min(16, H - ty * 16) * min(16, W - tx * 16));
