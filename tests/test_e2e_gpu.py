@@ -207,8 +207,11 @@ def test_batch_equals_single(eng_vae, golden, metric_log):
     assert diff <= 1e-6
 
 
-def test_full_sd21_architecture_small_image(metric_log):
-    """Full-width SD2.1 UNet (865.9 M params) + VAE at 64x64 px against the fp32 oracle run on the host CPU."""
+@pytest.mark.parametrize("hw", [(64, 64), (232, 312)])
+def test_full_sd21_architecture_small_image(hw, metric_log):
+    """Full-width SD2.1 UNet (865.9 M params) + VAE against the fp32 oracle run on the host CPU: 64x64 px (every map below the
+    16x16-tile kernels' minimum: generic implicit GEMM, split-K, persistent GEMM) and 232x312 px (latent 29x39: the persistent halo
+    kernels with ragged tile edges, several tiles per workgroup, fused GroupNorm inputs and epilogue statistics, at real widths)."""
     from genpercept_amd.engine import Engine
     from oracle import pipeline as opipe
     from oracle import sd21 as osd
@@ -216,8 +219,8 @@ def test_full_sd21_architecture_small_image(metric_log):
     usd = osd.synth_state_dict(osd.unet_manifest(uc), 11)
     vsd = osd.synth_state_dict(osd.vae_manifest(vc), 12)
     g = torch.Generator().manual_seed(77)
-    rgb_u8 = torch.randint(0, 256, (1, 3, 64, 64), generator=g, dtype=torch.uint8)
-    rgb_u8[:, :, :32] //= 2
+    rgb_u8 = torch.randint(0, 256, (1, 3, hw[0], hw[1]), generator=g, dtype=torch.uint8)
+    rgb_u8[:, :, : hw[0] // 2] //= 2
     ctx = torch.randn(2, 1024, generator=g)
     with torch.no_grad():
         rgb = opipe.normalize_rgb(rgb_u8)
@@ -231,11 +234,11 @@ def test_full_sd21_architecture_small_image(metric_log):
     eng.finalize()
     d = torch.device("cuda", 0)
     try:
-        stage_check("full_vae_encode", eng.vae_encode(rgb_u8.to(d)), lat, metric_log)
-        stage_check("full_unet", eng.unet(lat.to(d))[0], v, metric_log)
+        stage_check(f"full_vae_encode{hw}", eng.vae_encode(rgb_u8.to(d)), lat, metric_log)
+        stage_check(f"full_unet{hw}", eng.unet(lat.to(d))[0], v, metric_log)
         out = eng.infer(rgb_u8.to(d), "depth").cpu().numpy()
         mean_abs = float(np.abs(out - ref.numpy()).mean())
-        metric_log("full_infer_depth", mean_abs=mean_abs, max_abs=float(np.abs(out - ref.numpy()).max()), absrel_ls=absrel_after_ls(out, ref.numpy()))
+        metric_log(f"full_infer_depth{hw}", mean_abs=mean_abs, max_abs=float(np.abs(out - ref.numpy()).max()), absrel_ls=absrel_after_ls(out, ref.numpy()))
         assert mean_abs <= TOL_MAP_MEAN
     finally:
         eng.close()
