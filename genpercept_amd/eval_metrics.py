@@ -12,11 +12,26 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 
 
-def align_depth_least_square(gt: np.ndarray, pred: np.ndarray, valid_mask: np.ndarray) -> Tuple[np.ndarray, float, float]:
-    """min_{s,t} || s * pred + t - gt ||^2 over valid pixels; returns (s * pred + t, s, t)."""
+def _nearest_downscale(x: np.ndarray, scale: float) -> np.ndarray:
+    """What alignment.py:45-55 does to a [H, W] array: torch.nn.Upsample(scale_factor, mode="nearest") applied to the [1, H, W] tensor,
+    which torch reads as (batch, channels, length) -- so only the LAST axis is resampled: width floor(W * scale), source column
+    floor(dst * (1 / scale)).  Kept as is: the evaluation protocol is defined by what the reference computes."""
+    w = x.shape[-1]
+    ow = int(np.floor(w * scale))
+    ix = np.minimum(np.floor(np.arange(ow) * np.float32(1.0 / scale)).astype(np.int64), w - 1)
+    return x[..., ix]
+
+
+def align_depth_least_square(gt: np.ndarray, pred: np.ndarray, valid_mask: np.ndarray, max_resolution: Optional[int] = None) -> Tuple[np.ndarray, float, float]:
+    """min_{s,t} || s * pred + t - gt ||^2 over valid pixels; returns (s * pred + t, s, t).  With max_resolution the fit runs on a
+    nearest-downscaled copy (alignment.py:43-55) and the result is applied to the full-resolution prediction."""
     g = np.asarray(gt).squeeze()
     p = np.asarray(pred).squeeze()
     m = np.asarray(valid_mask).squeeze().astype(bool)
+    if max_resolution is not None:
+        scale = float(np.min(max_resolution / np.array(np.asarray(pred).shape[-2:])))
+        if scale < 1:
+            g, p, m = _nearest_downscale(g, scale), _nearest_downscale(p, scale), _nearest_downscale(m, scale)
     a = np.stack([p[m], np.ones_like(p[m])], axis=1)
     x = np.linalg.lstsq(a, g[m], rcond=None)[0]
     scale, shift = float(x[0]), float(x[1])
@@ -28,6 +43,10 @@ def depth2disparity(depth: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     pos = depth > 0
     d[pos] = 1.0 / depth[pos]
     return d, pos
+
+
+def disparity2depth(disparity: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    return depth2disparity(disparity)  # alignment.py:93-94
 
 
 def _masked_mean(x: np.ndarray, mask: Optional[np.ndarray]) -> np.ndarray:
@@ -94,10 +113,25 @@ METRICS = {f.__name__: f for f in (abs_relative_difference, squared_relative_dif
                                     delta3_acc, i_rmse, silog_rmse)}
 
 
-def evaluate_depth(pred: np.ndarray, gt: np.ndarray, valid_mask: np.ndarray, min_depth: float = 1e-3, max_depth: float = 10.0) -> Dict[str, float]:
-    """eval.py:168-215 for one image: LS alignment in depth space, clip to the dataset range, ten metrics."""
-    aligned, _, _ = align_depth_least_square(gt, pred, valid_mask)
-    aligned = np.clip(aligned, min_depth, max_depth)
-    a, g, m = (np.asarray(x, dtype=np.float64)[None] for x in (aligned.squeeze(), np.asarray(gt).squeeze(), np.asarray(valid_mask).squeeze()))
+def evaluate_depth(pred: np.ndarray, gt: np.ndarray, valid_mask: np.ndarray, min_depth: float = 1e-3, max_depth: float = 10.0,
+                   alignment: str = "least_square", alignment_max_res: Optional[int] = None) -> Dict[str, float]:
+    """eval.py:168-215 for one image: LS alignment in depth space ("least_square") or in disparity space ("least_square_disparity"),
+    clip to the dataset range and to d > 0, ten metrics."""
+    pred = np.asarray(pred)
+    gt_a = np.asarray(gt)
+    vm = np.asarray(valid_mask).astype(bool)
+    if alignment == "least_square":
+        aligned, _, _ = align_depth_least_square(gt_a, pred, vm, alignment_max_res)
+    elif alignment == "least_square_disparity":
+        gt_disp, gt_pos = depth2disparity(gt_a)
+        m = vm & gt_pos & (pred > 0)
+        disp, _, _ = align_depth_least_square(gt_disp, pred, m, alignment_max_res)
+        aligned, _ = disparity2depth(np.clip(disp, 1e-3, None))
+    elif alignment in (None, "", "none"):
+        aligned = pred
+    else:
+        raise NotImplementedError(alignment)
+    aligned = np.clip(np.clip(aligned, min_depth, max_depth), 1e-6, None)
+    a, g, m = (np.asarray(x, dtype=np.float64)[None] for x in (aligned.squeeze(), gt_a.squeeze(), vm.squeeze()))
     m = m.astype(bool)
     return {k: f(a, g, m) for k, f in METRICS.items()}

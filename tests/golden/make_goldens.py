@@ -9,6 +9,7 @@ Fixtures are data (seeds, inputs, expected outputs) — never reference source.
                      dpt_head.py:20-21,130) are provided by a stub module.
   metrics_ref.npz    outputs of the REFERENCE's src/util/metric.py + src/util/alignment.py on seeded arrays.
   batchsize_ref.npz  the REFERENCE's find_batch_size (genpercept/util/batchsize.py) on a grid of cards / resolutions / ensembles.
+  infer_eval_ref.npz the REFERENCE's get_pred_name (all naming modes) and alignment variants (max_resolution, disparity-space protocol).
   e2e_tiny.npz       end-to-end goldens of the fp32 oracle (oracle/) on the tiny configs: inputs + expected outputs
                      for every stage (latent, unet out, feats, decode, final) — what the HIP path is checked against
                      on the GPU box where neither /root/reference nor large weights exist.
@@ -130,6 +131,52 @@ def make_batchsize_golden():
     print("batchsize golden:", len(rows), "rows; no-gpu ->", no_gpu)
 
 
+def make_infer_eval_golden():
+    """Naming modes of the REFERENCE's get_pred_name (src/dataset/base_dataset.py:531-545; cv2 / torchvision are stubbed, the function
+    needs neither) and its alignment variants (src/util/alignment.py: max_resolution fit, disparity-space protocol of eval.py:181-200)."""
+    import importlib.util
+    for name in ("cv2", "torchvision", "torchvision.transforms", "tarfile_stub"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision.transforms"].InterpolationMode = types.SimpleNamespace(NEAREST=0, BILINEAR=1, BICUBIC=2, NEAREST_EXACT=3)
+    sys.modules["torchvision.transforms"].Resize = object
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.path.insert(0, REF)
+    spec = importlib.util.spec_from_file_location("ref_base_dataset", os.path.join(REF, "src/dataset/base_dataset.py"))
+    bd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bd)
+    basenames = ["rgb_0001.png", "rgb_0250.jpg", "0000000005_rgb.png", "12_34_rgb.png", "frame.png", "rgb_1_2.png", "a_b_c_d.jpeg"]
+    names = {}
+    for mode in bd.PerceptionFileNameMode:
+        for bn in basenames:
+            for suf in (".npy", ".png"):
+                try:
+                    names[f"{mode.name}|{bn}|{suf}"] = bd.get_pred_name(bn, mode, suffix=suf)
+                except Exception as e:  # e.g. IndexError for names without '_'
+                    names[f"{mode.name}|{bn}|{suf}"] = "!" + type(e).__name__
+    spec = importlib.util.spec_from_file_location("ref_alignment2", os.path.join(REF, "src/util/alignment.py"))
+    al = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(al)
+    rng = np.random.RandomState(5)
+    gt = (rng.rand(97, 130) * 9 + 0.5).astype(np.float32)
+    pred = (0.1 * gt + 0.05 + 0.02 * rng.randn(97, 130)).astype(np.float32)
+    mask = rng.rand(97, 130) > 0.2
+    out = {"gt": gt, "pred": pred, "mask": mask}
+    for mr in (32, 64, 200):
+        a, s_, t_ = al.align_depth_least_square(gt, pred, mask, return_scale_shift=True, max_resolution=mr)
+        out[f"align_maxres{mr}"] = np.asarray(a, dtype=np.float64)
+        out[f"align_maxres{mr}_st"] = np.array([float(s_), float(t_)])
+    # disparity-space protocol (eval.py:181-200)
+    gdisp, gpos = al.depth2disparity(gt, return_mask=True)
+    pdisp = (1.0 / np.clip(gt, 1e-3, None) * 0.7 + 0.02 + 0.01 * rng.randn(97, 130)).astype(np.float32)
+    m = mask & gpos & (pdisp > 0)
+    d, s_, t_ = al.align_depth_least_square(gdisp, pdisp, m, return_scale_shift=True, max_resolution=None)
+    out["pred_disp"] = pdisp
+    out["disp_protocol_depth"] = np.asarray(al.disparity2depth(np.clip(d, 1e-3, None)), dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "infer_eval_ref.npz"), name_keys=np.array(list(names.keys())), name_vals=np.array(list(names.values())), **out)
+    print("infer/eval golden:", len(names), "names")
+
+
 def make_e2e_tiny():
     uc, vc, dc = osd.UNetCfg.tiny(), osd.VAECfg.tiny(), odpt.DPTCfg.tiny()
     usd = osd.synth_state_dict(osd.unet_manifest(uc), 1)
@@ -166,7 +213,7 @@ def make_e2e_tiny():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dpt", "metrics", "e2e", "batchsize"]
+    which = sys.argv[1:] or ["dpt", "metrics", "e2e", "batchsize", "infer_eval"]
     if "dpt" in which:
         make_dpt_golden()
     if "metrics" in which:
@@ -175,3 +222,5 @@ if __name__ == "__main__":
         make_e2e_tiny()
     if "batchsize" in which:
         make_batchsize_golden()
+    if "infer_eval" in which:
+        make_infer_eval_golden()

@@ -207,3 +207,67 @@ def test_find_batch_size_clamp_matches_reference():
     assert bsz.find_batch_size(1, 768, torch.bfloat16, total_vram_gb=288.0) == 1
     assert bsz.find_batch_size(10, 768, None, total_vram_gb=1.0) == 1          # nothing fits -> 1
     assert bsz.find_batch_size(64, 768, None, total_vram_gb=288.0) in (32, 64)  # 288 GB: the whole ensemble or its half
+
+
+def test_infer_eval_driver_matches_reference(tmp_path):
+    """genpercept_amd.infer_eval against outputs of the reference's own functions (tests/golden/infer_eval_ref.npz):
+    get_pred_name for every naming mode, least-squares alignment with max_resolution, the disparity-space protocol; then the
+    inference loop + evaluation on a synthetic NYU-style tree with a stand-in pipeline (file layout, masks, metric reduction)."""
+    import numpy as np
+    from PIL import Image
+    from genpercept_amd import eval_metrics as em
+    from genpercept_amd import infer_eval as ie
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "infer_eval_ref.npz"))
+    n = 0
+    for key, want in zip(g["name_keys"], g["name_vals"]):
+        mode, bn, suf = str(key).split("|")
+        try:
+            got = ie.get_pred_name(bn, ie.FileNameMode[mode], suffix=suf)
+        except Exception as e:
+            got = "!" + type(e).__name__
+        assert got == str(want), (key, got, want)
+        n += 1
+    assert n == 56
+    gt, pred, mask = g["gt"], g["pred"], g["mask"]
+    for mr in (32, 64, 200):
+        a, s, t = em.align_depth_least_square(gt, pred, mask, max_resolution=mr)
+        np.testing.assert_allclose([s, t], g[f"align_maxres{mr}_st"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(a, g[f"align_maxres{mr}"], rtol=1e-5, atol=1e-5)
+    # disparity-space protocol (eval.py:181-200) through evaluate_depth's internals
+    gdisp, gpos = em.depth2disparity(gt)
+    pd = g["pred_disp"]
+    m = mask & gpos & (pd > 0)
+    d, _, _ = em.align_depth_least_square(gdisp, pd, m)
+    depth, _ = em.disparity2depth(np.clip(d, 1e-3, None))
+    np.testing.assert_allclose(depth, g["disp_protocol_depth"], rtol=1e-4, atol=1e-5)
+
+    # end to end on a synthetic NYU-style tree
+    base, outd = tmp_path / "data", tmp_path / "pred"
+    rng = np.random.RandomState(0)
+    samples = []
+    for i in range(3):
+        scene = base / "test" / f"room_{i:04d}"
+        scene.mkdir(parents=True)
+        depth_m = (rng.rand(480, 640) * 8 + 0.7).astype(np.float32)
+        Image.fromarray((depth_m * 1000).astype(np.uint16)).save(scene / f"depth_{i:04d}.png")
+        Image.fromarray(rng.randint(0, 255, (480, 640, 3), dtype=np.uint8)).save(scene / f"rgb_{i:04d}.png")
+        samples.append([f"test/room_{i:04d}/rgb_{i:04d}.png", f"test/room_{i:04d}/depth_{i:04d}.png"])
+    (base / "list.txt").write_text("\n".join(" ".join(s) for s in samples) + "\n")
+    assert ie.read_filename_list(str(base / "list.txt")) == samples
+
+    class FakePipe:  # affine-invariant prediction: a scaled/shifted copy of the GT (what the LS alignment undoes)
+        def __call__(self, img, **kw):
+            assert kw["batch_size"] == 0 and kw["color_map"] is None and kw["mode"] == "depth"
+            idx = FakePipe.i
+            FakePipe.i += 1
+            d = np.asarray(Image.open(base / samples[idx][1])).astype(np.float32) / 1000.0
+            from types import SimpleNamespace
+            return SimpleNamespace(pred_np=(0.1 * d + 0.05).astype(np.float32), pred_colored=None)
+    FakePipe.i = 0
+    written = ie.run_inference(FakePipe(), str(base), samples, str(outd), ie.FileNameMode.rgb_id, mode="depth")
+    assert [os.path.relpath(w, outd) for w in written] == [f"test/room_{i:04d}/pred_{i:04d}.npy" for i in range(3)]
+    res = ie.evaluate_predictions(str(outd), str(base), samples, dataset="nyu", alignment="least_square", output_dir=str(tmp_path / "eval"))
+    assert res["abs_relative_difference"] < 1e-3 and res["delta1_acc"] > 0.999
+    assert os.path.exists(tmp_path / "eval" / "eval_metrics-least_square.txt")
+    vm = ie.valid_mask_of(np.full((480, 640), 5.0, np.float32), 1e-3, 10.0, ie.DATASETS["nyu"]["eval_crop"])
+    assert vm.sum() == (471 - 45) * (601 - 41) and not vm[44, 100] and vm[45, 41] and not vm[470, 601]
