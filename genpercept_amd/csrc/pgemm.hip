@@ -12,7 +12,7 @@
 //   * per-WAVE epilogue, no workgroup barrier: fp32 staging through the LDS pieces the wave itself will refill next (its own DMA
 //     destinations of the slot just consumed), coalesced 16-byte stores, residual rows prefetched; stores drain under the next tile;
 //   * optional GroupNorm partial statistics per (M tile, channel) as in epilogue.h.
-// Not handled here (launch_igemm keeps them on igemm_kernel): GEGLU, fp32 output, batched problems, row bias, odd strides.
+// Not handled here (launch_igemm keeps them on igemm_kernel): fp32 output, batched problems, row bias, odd strides.
 #include "common.h"
 #include "kernels.h"
 
@@ -269,13 +269,41 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
             }
         }
     };
-    const int ep_variant = (p.act != GP_ACT_NONE ? 4 : 0) | (p.res ? 2 : 0) | (want_stats ? 1 : 0);
+    // GEGLU (the transformer's first feed-forward GEMM): packed weight rows interleave value and gate so that a lane's 8 columns of a
+    // fragment pair are 4 values + their 4 gates (engine: geglu_row); out[m][c] = value * gelu(gate), 4 outputs = 8 bytes per lane,
+    // written straight from the accumulators (no staging: the 32-byte row pieces are what igemm_kernel's direct path wrote as well).
+    auto epilogue_geglu = [&]() __attribute__((always_inline)) {
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int q = lane_o >> 4, a = lane_o & 15;
+        const int n_half = p.N >> 1;
+        bf16_t* outp = (bf16_t*)p.out;
+#pragma unroll
+        for (int ip = 0; ip < FP; ++ip) {
+            const f32x4_t bl = *(lds_f4_ptr)(bias_base + (wn * TN + 32 * ip + 8 * q) * 4);
+            const f32x4_t bh = *(lds_f4_ptr)(bias_base + (wn * TN + 32 * ip + 8 * q) * 4 + 16);
+            const int col = ((n0 + wn * TN + 32 * ip) >> 1) + 4 * q;   // first of this lane's 4 output columns
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                const int m = cm0 + wm * 64 + 16 * j + a;
+                if (m >= p.M || col >= p.n_store) continue;
+                const f32x4_t val = acc[2 * ip][j] + bl, gate = acc[2 * ip + 1][j] + bh;
+                float v[4] = {val.x * gelu_erf_f(gate.x), val.y * gelu_erf_f(gate.y), val.z * gelu_erf_f(gate.z), val.w * gelu_erf_f(gate.w)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (col + r >= n_half) v[r] = 0.f;
+                if (!(ABL & 4)) *(uint2*)(outp + (long long)m * p.ldo + col) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    };
+    const int ep_variant = p.act == GP_ACT_GEGLU ? 8 : (p.act != GP_ACT_NONE ? 4 : 0) | (p.res ? 2 : 0) | (want_stats ? 1 : 0);
     auto epilogue = [&](auto slotc) __attribute__((always_inline)) {
         switch (ep_variant) {
             case 0: epilogue_body(slotc, IC<0>{}, IC<0>{}, IC<0>{}); break;
             case 1: epilogue_body(slotc, IC<0>{}, IC<0>{}, IC<1>{}); break;
             case 2: epilogue_body(slotc, IC<0>{}, IC<1>{}, IC<0>{}); break;
             case 3: epilogue_body(slotc, IC<0>{}, IC<1>{}, IC<1>{}); break;
+            case 8: epilogue_geglu(); break;
             default: epilogue_body(slotc, IC<1>{}, IC<1>{}, IC<1>{}); break;
         }
 #pragma unroll
@@ -368,7 +396,9 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
 }
 
 bool pgemm_applicable(const IGemmParams& p) {
-    if (p.ks != 1 || p.batch > 1 || p.out_fp32 || p.act == GP_ACT_GEGLU || p.bias_mode == GP_BIAS_ROW || p.in_scale) return false;
+    if (p.ks != 1 || p.batch > 1 || p.out_fp32 || p.bias_mode == GP_BIAS_ROW || p.in_scale) return false;
+    if (p.act == GP_ACT_GEGLU) return !p.res && !p.stats_out && (p.N & 63) == 0 && (p.Cin & 63) == 0 && (p.lda & 7) == 0 && (p.ldw & 7) == 0 &&
+                                      (p.ldo & 3) == 0 && (p.n_store & 3) == 0 && p.M >= 256;
     if ((p.Cin & 63) || (p.lda & 7) || (p.ldw & 7) || (p.ldo & 7) || (p.n_store & 7)) return false;
     if (p.res && ((p.ldres & 7) || p.ldres < p.n_store)) return false;
     return p.M >= 256;

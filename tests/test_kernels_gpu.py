@@ -297,10 +297,12 @@ def test_gemm_row_bias_batched_zero_fill(metric_log):
     assert float(out[:, :, t:].float().abs().max()) == 0.0, "padding columns must be written as zeros"
 
 
-def test_gemm_geglu(metric_log):
+@pytest.mark.parametrize("mc", [(200, 128), (4801, 128), (36864, 320), (2304, 64)])
+def test_gemm_geglu(mc, metric_log):
+    """GEGLU feed-forward GEMM: M = 200 stays on igemm_kernel's direct path, the larger ones run the persistent GEMM's GEGLU epilogue."""
     e = _eng()
     g = torch.Generator().manual_seed(4)
-    m, c = 200, 128
+    m, c = mc
     a = rbf(torch.randn(m, c, generator=g))
     w = rbf(torch.randn(8 * c, c, generator=g) / math.sqrt(c))
     bias = torch.randn(8 * c, generator=g)
@@ -317,7 +319,7 @@ def test_gemm_geglu(metric_log):
     pb = torch.empty_like(bias)
     pb[dst] = bias
     y = e.conv2d(a.to(d).to(torch.bfloat16).reshape(1, 1, m, c), wp, pb.to(d), 8 * c, 1, act="geglu")
-    check("gemm_geglu", y.reshape(m, 4 * c), ref, metric_log)
+    check(f"gemm_geglu{mc}", y.reshape(m, 4 * c), ref, metric_log)
 
 
 @pytest.mark.parametrize("case", [(2, 64, 64, True), (1, 128, 4096, True), (2, 320, 300, False), (1, 960, 144, True), (3, 2560, 36, True),
