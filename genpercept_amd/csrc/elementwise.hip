@@ -314,11 +314,12 @@ void launch_minmax_norm(float* x, int B, long long n, float* ws, hipStream_t s) 
 // (302 MB written and read back) and a K = 576 conv of which 27/576 was real work; here K = 27 (padded to 32) is ONE
 // v_mfma_f32_16x16x32_bf16 per 16 pixels x 16 channels, the image is read as uint8 and the layer is bound by its 2 B/element output.
 //   workgroup: 4 waves, 16x16 output pixels x 128 channels; halo 18x18x3 normalised to bf16 in LDS ([pixel][4]); k = 3 * tap + c.
-__global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict__ rgb, int is_u8, const bf16_t* __restrict__ wt, int ldw,
+__global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict__ rgb, int is_u8, const bf16_t* __restrict__ w27,
                                                            const float* __restrict__ bias, bf16_t* __restrict__ out, float* __restrict__ stats,
                                                            int B, int H, int W, int Cout) {
     __shared__ bf16_t s_h[18 * 18 * 4];
     __shared__ float s_red[4 * 128 * 2];
+    __shared__ __attribute__((aligned(16))) bf16_t s_w[128 * 32];  // this slice's weights, [channel][k = 3 tap + c, zero for k >= 27]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int a = lane & 15, q = lane >> 4;
     const int tiles_x = (W + 15) >> 4, tiles_y = (H + 15) >> 4;
@@ -342,17 +343,14 @@ __global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict
         }
         s_h[i] = f2bf(v);
     }
-    // weight fragments: MFMA row a of fragment i (pair ip = i / 2) is output channel 32 ip + 8 (a / 4) + 4 (i & 1) + (a & 3), so that a
-    // lane ends up with 8 consecutive channels of its pixel; this lane's k = 8 q + e -> (tap, c) = (k / 3, k % 3), zero for k >= 27
-    bf16x8_t wf[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int ch = n0 + 32 * (i >> 1) + 8 * (a >> 2) + 4 * (i & 1) + (a & 3);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = 8 * q + e;
-            wf[i][e] = (k < 27 && (i >> 1) < npair) ? (short)wt[(long long)ch * ldw + (k / 3) * 64 + (k % 3)] : (short)0;
-        }
+    // weights: compact [Cout][32] matrix (pack_k27_kernel) -> LDS (two 16-byte pieces per thread), then 16 bytes per fragment and lane.
+    // (Gathering the 27 taps per lane from the [rows][9][64] conv layout cost more than the whole rest of the kernel: ~32 cache lines
+    //  per load instruction, 64 instructions per lane and workgroup.)
+    for (int i = tid; i < 128 * 32 / 8; i += 256) {
+        const int ch = i >> 2;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (n0 + ch < Cout) v = *(const uint4*)(w27 + (long long)(n0 + ch) * 32 + (i & 3) * 8);
+        *(uint4*)(s_w + i * 8) = v;
     }
     float bv[4][8];
 #pragma unroll
@@ -360,6 +358,11 @@ __global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict
 #pragma unroll
         for (int e = 0; e < 8; ++e) bv[ip][e] = (bias && ip < npair) ? bias[n0 + 32 * ip + 8 * q + e] : 0.f;
     __syncthreads();
+    // weight fragments: MFMA row a of fragment i (pair ip = i / 2) is output channel 32 ip + 8 (a / 4) + 4 (i & 1) + (a & 3), so that a
+    // lane ends up with 8 consecutive channels of its pixel; this lane's k = 8 q .. 8 q + 7
+    bf16x8_t wf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wf[i] = *(const bf16x8_t*)(s_w + (32 * (i >> 1) + 8 * (a >> 2) + 4 * (i & 1) + (a & 3)) * 32 + 8 * q);
 
     float st_s[4][8], st_q[4][8];
 #pragma unroll
@@ -424,9 +427,19 @@ __global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict
         }
     }
 }
-// Cout % 32 == 0; wt = packed conv weight [rows][9][64] (ldw = 576); stats (optional): [B * tiles][Cout][2], 16x16 tiles (mode 1)
-void launch_rgb_conv_in(const void* rgb, int is_u8, const bf16_t* wt, int ldw, const float* bias, bf16_t* out, float* stats, int B, int H, int W,
-                        int Cout, hipStream_t s) {
+// compact conv_in weights: [Cout][32] bf16 with k = 3 * tap + c (c < 3), zero for k >= 27, from the packed conv layout [rows][9][64]
+__global__ __launch_bounds__(256) void pack_k27_kernel(const bf16_t* __restrict__ wt, int ldw, int Cout, bf16_t* __restrict__ w27) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cout * 32) return;
+    const int ch = i >> 5, k = i & 31;
+    w27[i] = k < 27 ? wt[(long long)ch * ldw + (k / 3) * 64 + (k % 3)] : (bf16_t)0;
+}
+void launch_pack_k27(const bf16_t* wt, int ldw, int Cout, bf16_t* w27, hipStream_t s) {
+    hipLaunchKernelGGL(pack_k27_kernel, dim3((Cout * 32 + 255) / 256), dim3(256), 0, s, wt, ldw, Cout, w27);
+}
+// Cout % 32 == 0; w27 = launch_pack_k27 output; stats (optional): [B * tiles][Cout][2], 16x16 tiles (mode 1)
+void launch_rgb_conv_in(const void* rgb, int is_u8, const bf16_t* w27, const float* bias, bf16_t* out, float* stats, int B, int H, int W, int Cout,
+                        hipStream_t s) {
     const int tiles = ((W + 15) / 16) * ((H + 15) / 16) * B;
-    hipLaunchKernelGGL(rgb_conv_in_kernel, dim3(tiles, (Cout + 127) / 128), dim3(256), 0, s, rgb, is_u8, wt, ldw, bias, out, stats, B, H, W, Cout);
+    hipLaunchKernelGGL(rgb_conv_in_kernel, dim3(tiles, (Cout + 127) / 128), dim3(256), 0, s, rgb, is_u8, w27, bias, out, stats, B, H, W, Cout);
 }

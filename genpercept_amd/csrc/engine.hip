@@ -146,6 +146,7 @@ struct gp_engine {
     float* gn_ws = nullptr;
     size_t gn_ws_floats = 0;
     float* mm_ws = nullptr;
+    bf16_t* conv_in_w27 = nullptr;  // VAE encoder conv_in as a [Cout][32] (K = 27) matrix for rgb_conv_in_kernel
     bool fuse_gn = true;   // GENPERCEPT_NO_GN_FUSION=1 keeps the separate apply pass (A/B measurements)
     bool fuse_stats = true;  // GENPERCEPT_NO_STATS_FUSION=1 keeps the separate statistics pass
 
@@ -769,7 +770,12 @@ struct gp_engine {
             tm.flops_igemm += 2.0 * (double)h.pixels() * win.cout * 27.0;
             tm.n_launches++;
             prof_begin(0);
-            launch_rgb_conv_in(rgb, is_u8, win.w, 9 * win.cin_pad, win.bias, h.p, h.st, B, Hh, Ww, win.cout, st);
+            if (!conv_in_w27) {  // compact K = 27 weight matrix, built once from the packed conv weight
+                HIPCHK(hipMalloc((void**)&conv_in_w27, (size_t)win.cout * 32 * sizeof(bf16_t)));
+                weights_dev.push_back(conv_in_w27);
+                launch_pack_k27(win.w, 9 * win.cin_pad, win.cout, conv_in_w27, st);
+            }
+            launch_rgb_conv_in(rgb, is_u8, conv_in_w27, win.bias, h.p, h.st, B, Hh, Ww, win.cout, st);
             prof_end();
         } else {
             Act x = new_act(B, Hh, Ww, 64);
@@ -1360,8 +1366,13 @@ gp_status gp_conv2d_gn(const void* in, const void* w_packed, const float* bias, 
 
 gp_status gp_rgb_conv_in(const void* rgb, int is_u8, const void* w_packed, const float* bias, void* out, int B, int H, int W, int Cout, void* stream) {
     if (!rgb || !w_packed || !out || B < 1 || H < 1 || W < 1 || (Cout % 32)) return GP_ERR_INVALID;
-    launch_rgb_conv_in(rgb, is_u8, (const bf16_t*)w_packed, 9 * 64, bias, (bf16_t*)out, nullptr, B, H, W, Cout, (hipStream_t)stream);
-    return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
+    bf16_t* w27 = nullptr;
+    if (hipMalloc((void**)&w27, (size_t)Cout * 32 * sizeof(bf16_t)) != hipSuccess) return GP_ERR_HIP;
+    launch_pack_k27((const bf16_t*)w_packed, 9 * 64, Cout, w27, (hipStream_t)stream);
+    launch_rgb_conv_in(rgb, is_u8, w27, bias, (bf16_t*)out, nullptr, B, H, W, Cout, (hipStream_t)stream);
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(w27);
+    return (e == hipSuccess && hipGetLastError() == hipSuccess) ? GP_OK : GP_ERR_HIP;
 }
 
 gp_status gp_conv2d_stats(const void* in, const void* w_packed, const float* bias, const void* residual, void* out, int B, int H, int W, int Cin,

@@ -89,8 +89,9 @@ void launch_softmax_rows(const float* in, bf16_t* out, int rows, int T, int ld, 
 // Elementwise / layout kernels
 void launch_rgb_prologue(const void* rgb, int is_u8, bf16_t* out, int B, int H, int W, int Cpad, hipStream_t s);  // NCHW -> NHWC, x/255*2-1
 // fused RGB prologue + VAE-encoder conv_in (3 -> Cout, Cout % 32 == 0) + GroupNorm partial statistics (16x16 tiles) of the output
-void launch_rgb_conv_in(const void* rgb, int is_u8, const bf16_t* wt, int ldw, const float* bias, bf16_t* out, float* stats, int B, int H, int W,
-                        int Cout, hipStream_t s);
+void launch_pack_k27(const bf16_t* wt, int ldw, int Cout, bf16_t* w27, hipStream_t s);  // [rows][9][64] conv layout -> compact [Cout][32]
+void launch_rgb_conv_in(const void* rgb, int is_u8, const bf16_t* w27, const float* bias, bf16_t* out, float* stats, int B, int H, int W, int Cout,
+                        hipStream_t s);
 void launch_concat(const bf16_t* a, int Ca, const bf16_t* b, int Cb, bf16_t* out, long long pixels, hipStream_t s);
 int concat_stats_bm(long long hw);  // pixels per statistics tile launch_concat_stats can use for an image of hw pixels (0: none)
 void launch_concat_stats(const bf16_t* a, int Ca, const bf16_t* b, int Cb, bf16_t* out, long long pixels, int bm, float* part, hipStream_t s);
