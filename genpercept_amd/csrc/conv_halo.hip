@@ -739,8 +739,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         }
         __builtin_amdgcn_sched_barrier(0);
         // transform parts of this step (halo of chunk cc+1: complete for everybody from the barrier before tap 3, first read in tap 8)
-        constexpr int NP = !fused ? 0 : T_IT == 6 ? (TAP == 3 ? 2 : (TAP >= 4 && TAP <= 7) ? 1 : 0) : ((TAP == 3 || TAP == 4) ? 1 : 0);
-        constexpr int P0 = T_IT == 6 ? (TAP == 3 ? 0 : TAP - 2) : TAP - 3;
+        // 18x18 halo: 2592 items = 5 full parts (taps 3..7, one each) + 32 items left over, which only wave 0 handles (in tap 3, after the
+        // MFMAs): as a sixth part for everybody they cost 1/6 of the transform's VALU time for 1 % of its work.  10x10 halo: two parts.
+        constexpr int T_FULL = (HROWS * 8) / 512, T_TAIL_WAVES = ((HROWS * 8) % 512 + 63) / 64;  // 5, 1  /  1, 5
+        constexpr int NP = !fused ? 0 : T_IT == 6 ? ((TAP >= 3 && TAP <= 7) ? 1 : 0) : ((TAP == 3 || TAP == 4) ? 1 : 0);
+        constexpr int P0 = TAP - 3;
         if constexpr (TAP < 8) {
             TPart tp[NP > 0 ? NP : 1];
             if constexpr (NP > 0) {
@@ -776,6 +779,15 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { sgb<0x008, 2>(); sgb<0x100, 1>(); sgb<0x002, 3 * NP>(); sgb<0x400, NP>(); }
                 sgb<0x200, NP>();
+            }
+            if constexpr (fused && T_IT == 6 && TAP == 3) {  // the 32 left-over items (uniform branch: wave 0 only)
+                __builtin_amdgcn_sched_barrier(0);
+                if (wave < T_TAIL_WAVES) {
+                    TPart t;
+                    tp_load(t, PAR ^ 1, fcc, T_FULL);
+                    tp_mid(t);
+                    tp_finish(t);
+                }
             }
         } else {
             mfma16(f0);
