@@ -64,6 +64,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    if world > 1:  # every rank synthesises the same weights on the host: share the cores instead of oversubscribing them N times
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     dpt = args.head == "dpt"
     if dpt:
         args.mode = "disparity"
