@@ -277,11 +277,17 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 // The same with the row held in registers (ld <= 1024 * NV floats, ld % 4 == 0): ONE 16-byte-per-lane read pass instead of three
 // 4-byte ones, raw v_exp_f32 computed once per element, 8-byte stores.  HBM-bound: 6 B per score.
-template <int NV>
-__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int T, int ld, float scale) {
+GP_DEV float4 load4(const float* p, int i) { return ((const float4*)p)[i]; }
+GP_DEV float4 load4(const _Float16* p, int i) {
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    const h4_t h = ((const h4_t*)p)[i];
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+template <int NV, typename TIN>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const TIN* __restrict__ in, bf16_t* __restrict__ out, int T, int ld, float scale) {
     __shared__ float red[8];
     const long long row = blockIdx.x;
-    const float4* x = (const float4*)(in + row * ld);
+    const TIN* x = in + row * ld;
     uint2* y = (uint2*)(out + row * ld);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float sc = scale * 1.44269504088896340736f;
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __re
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int i = k * 256 + tid;
-        v[k] = i < nvec ? x[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[k] = i < nvec ? load4(x, i) : make_float4(0.f, 0.f, 0.f, 0.f);
         const int e0 = i * 4;
         v[k].x = e0 + 0 < T ? v[k].x : -1e30f;
         v[k].y = e0 + 1 < T ? v[k].y : -1e30f;
@@ -328,10 +334,19 @@ __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __re
 
 void launch_softmax_rows(const float* in, bf16_t* out, int rows, int T, int ld, float scale, hipStream_t s) {
     if ((ld & 3) == 0 && scale > 0.f && ld <= 16384) {
-        if (ld <= 4096) hipLaunchKernelGGL(softmax_rows_reg_kernel<4>, dim3(rows), dim3(256), 0, s, in, out, T, ld, scale);
-        else if (ld <= 9216) hipLaunchKernelGGL(softmax_rows_reg_kernel<9>, dim3(rows), dim3(256), 0, s, in, out, T, ld, scale);
-        else hipLaunchKernelGGL(softmax_rows_reg_kernel<16>, dim3(rows), dim3(256), 0, s, in, out, T, ld, scale);
+        if (ld <= 4096) hipLaunchKernelGGL((softmax_rows_reg_kernel<4, float>), dim3(rows), dim3(256), 0, s, in, out, T, ld, scale);
+        else if (ld <= 9216) hipLaunchKernelGGL((softmax_rows_reg_kernel<9, float>), dim3(rows), dim3(256), 0, s, in, out, T, ld, scale);
+        else hipLaunchKernelGGL((softmax_rows_reg_kernel<16, float>), dim3(rows), dim3(256), 0, s, in, out, T, ld, scale);
         return;
     }
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, in, out, T, ld, scale);
+}
+
+// fp16 logits (written by the score GEMM with out_fp32 == 2): same kernel, half the read traffic; ld % 4 == 0, ld <= 16384
+bool softmax_rows_f16_supported(int ld) { return (ld & 3) == 0 && ld <= 16384; }
+void launch_softmax_rows_f16(const void* in, bf16_t* out, int rows, int T, int ld, float scale, hipStream_t s) {
+    const _Float16* x = (const _Float16*)in;
+    if (ld <= 4096) hipLaunchKernelGGL((softmax_rows_reg_kernel<4, _Float16>), dim3(rows), dim3(256), 0, s, x, out, T, ld, scale);
+    else if (ld <= 9216) hipLaunchKernelGGL((softmax_rows_reg_kernel<9, _Float16>), dim3(rows), dim3(256), 0, s, x, out, T, ld, scale);
+    else hipLaunchKernelGGL((softmax_rows_reg_kernel<16, _Float16>), dim3(rows), dim3(256), 0, s, x, out, T, ld, scale);
 }

@@ -679,18 +679,23 @@ struct gp_engine {
         Act qk = linear(n, a.qk);  // [B*T][2C]
         bf16_t* vt = v_transposed(n, a.v, T, Tpad);
         drop(n);
-        float* S = (float*)pool.alloc((size_t)B * T * Tpad * sizeof(float));
+        // logits as fp16 (11 significant bits: finer than the bf16 probabilities they turn into; raw q.k of GroupNorm-ed activations
+        // stays far below 65504) halve the score traffic, the largest HBM item of the VAE; GENPERCEPT_FP32_SCORES=1 keeps fp32 (A/B)
+        static const bool f32_scores = getenv("GENPERCEPT_FP32_SCORES") != nullptr;
+        const bool half_scores = !f32_scores && softmax_rows_f16_supported(Tpad);
+        float* S = (float*)pool.alloc((size_t)B * T * Tpad * (half_scores ? 2 : 4));
         {
             IGemmParams p{};
             p.in = qk.p; p.wt = qk.p + C; p.out = S; p.zero = zero;
             p.M = T; p.N = T; p.Cin = C; p.n_rows = T; p.ks = 1; p.stride = 1;
-            p.lda = 2 * C; p.ldw = 2 * C; p.ldo = Tpad; p.n_store = T; p.out_fp32 = 1;
+            p.lda = 2 * C; p.ldw = 2 * C; p.ldo = Tpad; p.n_store = T; p.out_fp32 = half_scores ? 2 : 1;
             p.batch = B; p.in_bs = (long long)T * 2 * C; p.wt_bs = (long long)T * 2 * C; p.out_bs = (long long)T * Tpad;
             run_igemm(p);
         }
         drop(qk);
         bf16_t* P = (bf16_t*)pool.alloc((size_t)B * T * Tpad * sizeof(bf16_t));
-        launch_softmax_rows(S, P, B * T, T, Tpad, 1.0f / std::sqrt((float)C), st);
+        if (half_scores) launch_softmax_rows_f16(S, P, B * T, T, Tpad, 1.0f / std::sqrt((float)C), st);
+        else launch_softmax_rows(S, P, B * T, T, Tpad, 1.0f / std::sqrt((float)C), st);
         tm.n_launches++;
         pool.release(S);
         Act o = new_act(x.B, x.H, x.W, C);
@@ -1466,6 +1471,12 @@ gp_status gp_cross_attention(const void* q, const float* kc, const float* vc, vo
 gp_status gp_softmax_rows(const float* in, void* out, int rows, int T, int ld, float scale, void* stream) {
     if (!in || !out || ld < T) return GP_ERR_INVALID;
     launch_softmax_rows(in, (bf16_t*)out, rows, T, ld, scale, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
+}
+
+gp_status gp_softmax_rows_f16(const void* in_f16, void* out, int rows, int T, int ld, float scale, void* stream) {
+    if (!in_f16 || !out || ld < T || !softmax_rows_f16_supported(ld) || scale <= 0.f) return GP_ERR_INVALID;
+    launch_softmax_rows_f16(in_f16, (bf16_t*)out, rows, T, ld, scale, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
 }
 

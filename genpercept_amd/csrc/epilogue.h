@@ -172,7 +172,20 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
                 else if (p.act == GP_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
                 if (col + e >= n_out) v[e] = 0.f;
             }
-            if (p.out_fp32) {
+            if (p.out_fp32 == 2) {  // fp16 output (attention logits: 11 significant bits, range 65504)
+                _Float16* o = (_Float16*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
+                if (col + 7 < p.n_store && (p.ldo & 7) == 0) {
+                    typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+                    h8_t hv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hv[e] = (_Float16)v[e];
+                    *(h8_t*)o = hv;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (col + e < p.n_store) o[e] = (_Float16)v[e];
+                }
+            } else if (p.out_fp32) {
                 float* o = (float*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
                 if (col + 7 < p.n_store && (p.ldo & 3) == 0) {
                     *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);

@@ -34,7 +34,7 @@ struct IGemmParams {
     int lda, ldo, ldres;  // element strides of in (ks==1), out, res
     int ldw;              // element stride between rows of `wt` (taps*Cin for packed weights)
     int n_store;          // columns written (>= N_out; columns in [N_out, n_store) are written as 0)
-    int out_fp32;         // 1: fp32 output
+    int out_fp32;         // 1: fp32 output, 2: fp16 output (direct epilogue path)
     int act, bias_mode;
     int dbg;              // ablation bits for profiling only (1: no DMA in the loop, 2: no MFMA work, 4: no waits/barriers)
     int batch;            // grid.y batches with the strides below (elements)
@@ -85,6 +85,8 @@ void launch_cross_attn_small(const bf16_t* q, const float* kc, const float* vc, 
 
 // Row softmax: in fp32 [rows][ld] (first T columns valid) -> bf16 [rows][ld], columns >= T written as 0.
 void launch_softmax_rows(const float* in, bf16_t* out, int rows, int T, int ld, float scale, hipStream_t s);
+bool softmax_rows_f16_supported(int ld);
+void launch_softmax_rows_f16(const void* in_f16, bf16_t* out, int rows, int T, int ld, float scale, hipStream_t s);  // fp16 logits
 
 // Elementwise / layout kernels
 void launch_rgb_prologue(const void* rgb, int is_u8, bf16_t* out, int B, int H, int W, int Cpad, hipStream_t s);  // NCHW -> NHWC, x/255*2-1

@@ -78,6 +78,7 @@ SYMBOLS = {
     "gp_flash_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "gp_cross_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "gp_softmax_rows": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
+    "gp_softmax_rows_f16": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "gp_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
 }
 
@@ -370,7 +371,7 @@ def gemm(a: torch.Tensor, bt: torch.Tensor, bias=None, bias_mode: int = 1, resid
     n = bt.shape[1]
     nout = n // 2 if act == "geglu" else n
     nst = n_store or nout
-    out = torch.empty((bsz, m, nst), dtype=torch.float32 if out_fp32 else torch.bfloat16, device=a.device)
+    out = torch.empty((bsz, m, nst), dtype=torch.float16 if int(out_fp32) == 2 else (torch.float32 if out_fp32 else torch.bfloat16), device=a.device)
     st = lib.gp_gemm(a.data_ptr(), a.stride(1), bt.data_ptr(), bt.stride(1), _ptr(bias), bias_mode, _ptr(residual), nst, out.data_ptr(), nst, m, n,
                      k, n, nst, ACT[act], int(out_fp32), bsz, a.stride(0), bt.stride(0), m * nst, tile, _stream_ptr())
     if st != GP_OK:
@@ -424,7 +425,10 @@ def softmax_rows(x: torch.Tensor, t: int, scale: float) -> torch.Tensor:
     lib = load_library()
     rows, ld = x.shape
     out = torch.empty((rows, ld), dtype=torch.bfloat16, device=x.device)
-    st = lib.gp_softmax_rows(x.data_ptr(), out.data_ptr(), rows, t, ld, scale, _stream_ptr())
+    if x.dtype == torch.float16:
+        st = lib.gp_softmax_rows_f16(x.data_ptr(), out.data_ptr(), rows, t, ld, scale, _stream_ptr())
+    else:
+        st = lib.gp_softmax_rows(x.data_ptr(), out.data_ptr(), rows, t, ld, scale, _stream_ptr())
     if st != GP_OK:
         raise RuntimeError(f"gp_softmax_rows failed ({st})")
     return out

@@ -128,7 +128,7 @@ gp_status gp_conv2d_stats(const void* in, const void* w_packed, const float* bia
                           float* scale_out, float* shift_out, void* stream);
 /* out[M][N] = A[M][K] * Bt[N][K]^T (+bias per column / per row), batched over `batch` with element strides. */
 gp_status gp_gemm(const void* a, int lda, const void* bt, int ldb, const float* bias, int bias_mode, const void* residual, int ldres, void* out,
-                  int ldo, int M, int N, int K, int n_rows_bt, int n_store, int act, int out_fp32, int batch, long long a_bs, long long bt_bs,
+                  int ldo, int M, int N, int K, int n_rows_bt, int n_store, int act, int out_fp32 /* 0 bf16, 1 fp32, 2 fp16 */, int batch, long long a_bs, long long bt_bs,
                   long long out_bs, int tile_hint, void* stream);
 gp_status gp_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int silu, void* stream);
 gp_status gp_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C, float eps, void* stream);
@@ -136,6 +136,8 @@ gp_status gp_flash_attention(const void* q, const void* k, const void* vt, void*
                              void* stream);
 gp_status gp_cross_attention(const void* q, const float* kc, const float* vc, void* out, int rows, int C, int L, void* stream);
 gp_status gp_softmax_rows(const float* in, void* out, int rows, int T, int ld, float scale, void* stream);
+/* the same for fp16 logits (gp_gemm with out_fp32 = 2 writes them): ld % 4 == 0, ld <= 16384 */
+gp_status gp_softmax_rows_f16(const void* in_f16, void* out, int rows, int T, int ld, float scale, void* stream);
 gp_status gp_bilinear(const void* in, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream);
 
 #ifdef __cplusplus

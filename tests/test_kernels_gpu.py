@@ -274,6 +274,10 @@ def test_gemm_bias_residual(case, metric_log):
     check(f"gemm{case}", y[:, :n], a @ bt.t() + bias + res, metric_log)
     y32 = e.gemm(ad, bd, out_fp32=True, n_store=nst, tile=tile)
     check(f"gemm_f32{case}", y32[:, :n], a @ bt.t(), metric_log, fp32=True)
+    if tile != 7:
+        y16 = e.gemm(ad, bd, out_fp32=2, n_store=nst, tile=tile)  # fp16 output (attention logits)
+        assert y16.dtype == torch.float16
+        check(f"gemm_f16{case}", y16[:, :n], a @ bt.t(), metric_log)
 
 
 def test_gemm_row_bias_batched_zero_fill(metric_log):
@@ -420,6 +424,10 @@ def test_softmax_rows(shape, metric_log):
     d = _dev()
     y = e.softmax_rows(x.to(d), t, 0.05)
     check(f"softmax_rows{shape}", y[:, :t], torch.softmax(x[:, :t] * 0.05, dim=-1), metric_log)
+    if ld <= 16384 and ld % 4 == 0:  # fp16 logits (what the VAE attention's score GEMM writes)
+        xh = x.to(torch.float16)
+        yh = e.softmax_rows(xh.to(d), t, 0.05)
+        check(f"softmax_rows_f16{shape}", yh[:, :t], torch.softmax(xh.float()[:, :t] * 0.05, dim=-1), metric_log)
     if ld > t:
         assert float(y[:, t:].float().abs().max()) == 0.0
 
