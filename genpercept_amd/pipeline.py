@@ -28,6 +28,7 @@ from PIL import Image
 from . import config as gcfg
 from .image_util import chw2hwc, colorize_depth_maps, get_resample_method, resize_max_res, resize_to
 from .batchsize import find_batch_size
+from .weights import merge_lora_state_dict
 
 
 @dataclass
@@ -56,14 +57,15 @@ def _load_checkpoint_dir(path: str) -> Dict[str, torch.Tensor]:
 
 
 def _state_dict_of(obj) -> Optional[Dict[str, torch.Tensor]]:
+    """Weights of a module-like object, with PEFT LoRA adapters (run.py:345-357) folded into their base layers."""
     if obj is None:
         return None
     if isinstance(obj, dict):
-        return obj
+        return merge_lora_state_dict(obj)
     if isinstance(obj, (str, os.PathLike)):
-        return _load_checkpoint_dir(str(obj))
+        return merge_lora_state_dict(_load_checkpoint_dir(str(obj)))
     if hasattr(obj, "state_dict"):
-        return obj.state_dict()
+        return merge_lora_state_dict(obj.state_dict())
     raise TypeError(f"cannot take weights from {type(obj)}: expected state_dict(), a dict of tensors or a checkpoint directory")
 
 

@@ -178,3 +178,38 @@ def synth_state_dict(manifest: Dict[str, Sequence[int]], seed: int = 0, gain: fl
             t = (torch.rand(shape, generator=g) * 2.0 - 1.0) * a
         sd[name] = t.float().contiguous()
     return sd
+
+
+def merge_lora_state_dict(sd: Dict[str, torch.Tensor], scale: Optional[float] = None) -> Dict[str, torch.Tensor]:
+    """Fold PEFT LoRA adapters into their base weights so the engine sees a plain diffusers state dict.
+
+    The reference adds rank-r adapters (alpha = r) to `to_q / to_k / to_v / to_out.0` before `load_state_dict` (run.py:345-357),
+    which makes the checkpoint's keys `<module>.base_layer.weight`, `<module>.lora_A.<adapter>.weight` ([r, in]) and
+    `<module>.lora_B.<adapter>.weight` ([out, r]); the module computes base(x) + (alpha / r) * B(A(x)), i.e. the effective weight is
+    W + (alpha / r) * B @ A.  `scale` defaults to alpha / r = 1 (the reference's configuration).  A dict without adapter keys is
+    returned unchanged (same object).
+    """
+    if not any(".lora_A." in k or ".base_layer." in k for k in sd):
+        return sd
+    s = 1.0 if scale is None else float(scale)
+    out: Dict[str, torch.Tensor] = OrderedDict()
+    for k, v in sd.items():
+        if ".lora_A." in k or ".lora_B." in k:
+            continue
+        if ".base_layer." in k:
+            mod, leaf = k.split(".base_layer.")
+            if leaf == "weight":
+                a = [t for kk, t in sd.items() if kk.startswith(mod + ".lora_A.") and kk.endswith(".weight")]
+                b = [t for kk, t in sd.items() if kk.startswith(mod + ".lora_B.") and kk.endswith(".weight")]
+                if len(a) != len(b) or len(a) > 1:
+                    raise ValueError(f"{mod}: expected one lora_A / lora_B pair, found {len(a)} / {len(b)}")
+                w = v.float()
+                if a:
+                    delta = b[0].float().reshape(b[0].shape[0], -1) @ a[0].float().reshape(a[0].shape[0], -1)
+                    w = w + s * delta.reshape(w.shape)
+                out[mod + ".weight"] = w.to(v.dtype)
+            else:
+                out[mod + "." + leaf] = v
+        else:
+            out[k] = v
+    return out

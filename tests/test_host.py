@@ -271,3 +271,24 @@ def test_infer_eval_driver_matches_reference(tmp_path):
     assert os.path.exists(tmp_path / "eval" / "eval_metrics-least_square.txt")
     vm = ie.valid_mask_of(np.full((480, 640), 5.0, np.float32), 1e-3, 10.0, ie.DATASETS["nyu"]["eval_crop"])
     assert vm.sum() == (471 - 45) * (601 - 41) and not vm[44, 100] and vm[45, 41] and not vm[470, 601]
+
+
+def test_lora_adapters_are_merged_into_base_weights():
+    """run.py:345-357: a PEFT-wrapped UNet checkpoint (base_layer / lora_A / lora_B keys, alpha = r) must load as W + B @ A."""
+    from genpercept_amd.weights import merge_lora_state_dict
+    g = torch.Generator().manual_seed(0)
+    r, cin, cout = 8, 64, 96
+    base = torch.randn(cout, cin, generator=g)
+    a = torch.randn(r, cin, generator=g) * 0.1
+    b = torch.randn(cout, r, generator=g) * 0.1
+    plain = {"blk.attn1.to_k.weight": torch.randn(cout, cin, generator=g), "blk.norm.weight": torch.ones(cin)}
+    assert merge_lora_state_dict(plain) is plain
+    sd = {"blk.attn1.to_q.base_layer.weight": base, "blk.attn1.to_q.lora_A.default.weight": a, "blk.attn1.to_q.lora_B.default.weight": b,
+          "blk.attn1.to_out.0.base_layer.weight": base.clone(), "blk.attn1.to_out.0.base_layer.bias": torch.zeros(cout),
+          "blk.attn1.to_out.0.lora_A.default.weight": a, "blk.attn1.to_out.0.lora_B.default.weight": b, **plain}
+    m = merge_lora_state_dict(sd)
+    assert set(m) == {"blk.attn1.to_q.weight", "blk.attn1.to_out.0.weight", "blk.attn1.to_out.0.bias", "blk.attn1.to_k.weight", "blk.norm.weight"}
+    x = torch.randn(5, cin, generator=g)
+    want = x @ base.t() + (x @ a.t()) @ b.t()          # what the PEFT module computes with alpha / r = 1
+    torch.testing.assert_close(x @ m["blk.attn1.to_q.weight"].t(), want, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(merge_lora_state_dict(sd, scale=0.5)["blk.attn1.to_q.weight"], base + 0.5 * b @ a)
