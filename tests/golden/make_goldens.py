@@ -10,6 +10,7 @@ Fixtures are data (seeds, inputs, expected outputs) — never reference source.
   metrics_ref.npz    outputs of the REFERENCE's src/util/metric.py + src/util/alignment.py on seeded arrays.
   batchsize_ref.npz  the REFERENCE's find_batch_size (genpercept/util/batchsize.py) on a grid of cards / resolutions / ensembles.
   infer_eval_ref.npz the REFERENCE's get_pred_name (all naming modes) and alignment variants (max_resolution, disparity-space protocol).
+  image_util_ref.npz the REFERENCE's colorize_depth_maps / chw2hwc outputs, resize_max_res size rule, resample-method names.
   e2e_tiny.npz       end-to-end goldens of the fp32 oracle (oracle/) on the tiny configs: inputs + expected outputs
                      for every stage (latent, unet out, feats, decode, final) — what the HIP path is checked against
                      on the GPU box where neither /root/reference nor large weights exist.
@@ -177,6 +178,62 @@ def make_infer_eval_golden():
     print("infer/eval golden:", len(names), "names")
 
 
+def make_image_util_golden():
+    """The REFERENCE's genpercept/util/image_util.py: colorize_depth_maps (matplotlib Spectral), chw2hwc, the output-size rule of
+    resize_max_res (int() truncation; torchvision's `resize` is replaced by a stub that records the requested size -- the resampling
+    itself is torchvision's, not the reference's) and get_tv_resample_method's name handling."""
+    import importlib.util
+    tv, tvt, tvf = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms"), types.ModuleType("torchvision.transforms.functional")
+
+    class IM:  # stand-in enum members
+        BILINEAR, BICUBIC, NEAREST, NEAREST_EXACT = "bilinear", "bicubic", "nearest", "nearest-exact"
+    requested = []
+
+    def fake_resize(img, size, interpolation=None, antialias=None):
+        requested.append((tuple(img.shape[-2:]), tuple(size), interpolation, antialias))
+        return img
+    tvt.InterpolationMode = IM
+    tvf.resize = fake_resize
+    tv.transforms, tvt.functional = tvt, tvf
+    saved = {k: sys.modules.get(k) for k in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional")}
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.transforms.functional": tvf})
+    try:
+        spec = importlib.util.spec_from_file_location("ref_image_util", os.path.join(REF, "genpercept/util/image_util.py"))
+        iu = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(iu)
+        rng = np.random.RandomState(3)
+        depth = rng.rand(2, 13, 17).astype(np.float32) * 1.4 - 0.2          # values outside [0,1] exercise the clip
+        out = {"depth": depth, "colored_spectral": iu.colorize_depth_maps(depth, 0, 1, cmap="Spectral"),
+               "colored_single": iu.colorize_depth_maps(depth[0], 0.1, 0.9, cmap="Spectral"),
+               "chw": rng.rand(3, 5, 7).astype(np.float32)}
+        out["hwc"] = iu.chw2hwc(out["chw"])
+        sizes = []
+        for (h, w) in [(480, 640), (768, 1024), (1000, 333), (375, 1242), (64, 64), (100, 768), (1080, 1920), (513, 511)]:
+            for mr in (768, 512, 384):
+                requested.clear()
+                iu.resize_max_res(torch.zeros(1, 3, h, w), mr)
+                (_, size, interp, aa) = requested[0]
+                assert aa is True and interp == "bilinear"
+                sizes.append((h, w, mr, size[0], size[1]))
+        out["resize_sizes"] = np.array(sizes, dtype=np.int64)
+        names = {}
+        for nm in ("bilinear", "bicubic", "nearest", "nearest-exact", "lanczos", ""):
+            try:
+                names[nm] = str(iu.get_tv_resample_method(nm))
+            except ValueError:
+                names[nm] = "!ValueError"
+        out["resample_keys"] = np.array(list(names.keys()))
+        out["resample_vals"] = np.array(list(names.values()))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    np.savez_compressed(os.path.join(HERE, "image_util_ref.npz"), **out)
+    print("image_util golden:", len(sizes), "size cases;", dict(names))
+
+
 def make_e2e_tiny():
     uc, vc, dc = osd.UNetCfg.tiny(), osd.VAECfg.tiny(), odpt.DPTCfg.tiny()
     usd = osd.synth_state_dict(osd.unet_manifest(uc), 1)
@@ -213,7 +270,7 @@ def make_e2e_tiny():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dpt", "metrics", "e2e", "batchsize", "infer_eval"]
+    which = sys.argv[1:] or ["dpt", "metrics", "e2e", "batchsize", "infer_eval", "image_util"]
     if "dpt" in which:
         make_dpt_golden()
     if "metrics" in which:
@@ -224,3 +281,5 @@ if __name__ == "__main__":
         make_batchsize_golden()
     if "infer_eval" in which:
         make_infer_eval_golden()
+    if "image_util" in which:
+        make_image_util_golden()

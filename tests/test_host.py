@@ -292,3 +292,23 @@ def test_lora_adapters_are_merged_into_base_weights():
     want = x @ base.t() + (x @ a.t()) @ b.t()          # what the PEFT module computes with alpha / r = 1
     torch.testing.assert_close(x @ m["blk.attn1.to_q.weight"].t(), want, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(merge_lora_state_dict(sd, scale=0.5)["blk.attn1.to_q.weight"], base + 0.5 * b @ a)
+
+
+def test_image_util_matches_reference():
+    """Host pre/post processing against outputs of the reference's genpercept/util/image_util.py
+    (tests/golden/image_util_ref.npz): Spectral colouring incl. clipping, CHW->HWC, resize_max_res's truncating size rule, method names."""
+    import numpy as np
+    from genpercept_amd import image_util as iu
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "image_util_ref.npz"))
+    np.testing.assert_allclose(iu.colorize_depth_maps(g["depth"], 0, 1, cmap="Spectral"), g["colored_spectral"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(iu.colorize_depth_maps(g["depth"][0], 0.1, 0.9, cmap="Spectral"), g["colored_single"], rtol=0, atol=1e-7)
+    np.testing.assert_array_equal(iu.chw2hwc(g["chw"]), g["hwc"])
+    for h, w, mr, nh, nw in g["resize_sizes"]:
+        out = iu.resize_max_res(torch.zeros(1, 3, int(h), int(w), dtype=torch.uint8), int(mr))
+        assert tuple(out.shape[-2:]) == (int(nh), int(nw)), (h, w, mr, out.shape, nh, nw)
+    for name, want in zip(g["resample_keys"], g["resample_vals"]):
+        try:
+            got = iu.get_resample_method(str(name))
+        except ValueError:
+            got = "!ValueError"
+        assert got == str(want), (name, got, want)
