@@ -3,8 +3,10 @@
 #include "common.h"
 #include "kernels.h"
 
+// pixel chunks per image = workgroups per image of the statistics / apply passes: at least 16 pixels each, at most 256 chunks.
+// (HW / 256 left the UNet's 12x12 and 24x24 maps with ONE or two workgroups per image -- 4..8 on the whole GPU, 50 us for 1.5 MB.)
 static inline int gn_nchunk(int HW) {
-    int n = HW / 256;
+    int n = HW / 16;
     if (n < 1) n = 1;
     if (n > 256) n = 256;
     return n;
