@@ -20,7 +20,7 @@ struct IGemmParams {
     void* out;            // bf16 or fp32 [M][ldo]
     const bf16_t* zero;   // >= 256 bytes of zeros (source for padding / out-of-range rows)
     const float* in_scale;  // optional fused input transform x -> act(x * in_scale[b][c] + in_shift[b][c]) (GroupNorm apply);
-    const float* in_shift;  //   only honoured by conv_halo.hip (conv_halo_fuses_input())
+    const float* in_shift;  //   only honoured by conv_halo.hip (callers check conv_uses_halo())
     int in_silu;
     float* stats_out;     // optional: per-(tile, output channel) {sum, sum of squares} of the STORED bf16 values, [tile_rows][N][2] fp32,
                           //   tile_rows = pixel tiles in launch order (igemm_tile_info); feeds the next GroupNorm without a read pass
@@ -43,6 +43,8 @@ struct IGemmParams {
     long long in_bs, wt_bs, out_bs, res_bs, bias_bs;
 };
 
+// tile_hint: 0 auto (halo conv / persistent GEMM / split-K / generic tile by heuristic), 1 = 128x128, 2 = 64x64, 3 = 256x32, 4 = 256x128,
+//            5 = conv_halo.hip, 6 = 128x64, 7 = pgemm.hip
 void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s);
 // pgemm.hip: persistent GEMM for plain-row problems (ks == 1, bf16 out, column bias); tile_hint 7 forces it, 0 prefers it
 bool pgemm_applicable(const IGemmParams& p);
@@ -50,7 +52,7 @@ int pgemm_bm(const IGemmParams& p);                 // rows per tile (256 or 128
 void launch_pgemm(const IGemmParams& p, hipStream_t s);
 bool igemm_uses_pgemm(const IGemmParams& p, int tile_hint);
 // conv_halo.hip: 3x3 stride-1 convs on large maps (16x16-pixel tiles, input halo staged once per channel chunk); tile_hint 5
-bool conv_halo_applicable(const IGemmParams& p);   // includes the Cin <= 2048 limit when in_scale is set
+bool conv_halo_applicable(const IGemmParams& p);   // includes the Cin <= 2560 limit when in_scale is set
 void launch_conv_halo(const IGemmParams& p, hipStream_t s);
 bool conv_uses_halo(const IGemmParams& p, int tile_hint);
 int conv_halo_stat_rows(const IGemmParams& p);     // > 0: statistics rows per image (per-workgroup partials + pixel counts, mode 2)
@@ -60,7 +62,7 @@ int conv_halo_stat_rows(const IGemmParams& p);     // > 0: statistics rows per i
 int igemm_tile_info(const IGemmParams& p, int tile_hint, int* mode, int* bm);
 // scale/shift from per-tile channel partials written by a conv epilogue (instead of launch_groupnorm_stats)
 void launch_groupnorm_from_partials(const float* partials, int mode, int bm, int B, int H, int W, int C, int G, float eps, const float* gamma,
-                                    const float* beta, float* scale, float* shift, hipStream_t s);  // what launch_igemm will do; callers that set in_scale must check it  // tile_hint: 0 auto, 1 = 128x128, 2 = 64x64, 3 = 256x32
+                                    const float* beta, float* scale, float* shift, hipStream_t s);
 
 // GroupNorm over NHWC bf16 (fp32 statistics), optional fused SiLU.  Three passes: partial statistics, per-(image, channel)
 // scale/shift, apply; the apply pass is skipped when the consuming conv fuses it (IGemmParams::in_scale).
