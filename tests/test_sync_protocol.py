@@ -1,0 +1,223 @@
+"""Model check (CPU) of the LDS-DMA ring protocol of conv3x3_halo3_kernel (genpercept_amd/csrc/conv_halo.hip).
+
+The kernel never drains its DMA ring: every K-step ends with a COUNTED `s_waitcnt vmcnt(N)` and one raw `s_barrier`, and which
+operations may stay in flight depends on the tap, on tile / workgroup ends and on the role split (half of the waves issue their DMA
+before the MFMAs, half after).  A wrong count does not fail a test run reliably -- the DMA usually lands in time anyway -- so the
+table is checked here against an adversarial model instead:
+
+  * a wave's loads complete in issue order, as late as its waits allow: after `vmcnt(N)` only the loads older than its N youngest are
+    guaranteed to have landed (stores also occupy the counter but complete in any order, so they can only make a wait stronger);
+  * data is visible to OTHER waves only through a barrier that follows the issuing wave's covering wait;
+  * every LDS read (fragment prefetch of step s+1 during step s, the in-place input transform, the prologue) must find its operands
+    certified that way, and every DMA into a ring slot / halo buffer must be issued after a barrier that follows the last read of the
+    previous content (and, for the halo buffer the epilogue uses as its staging window, after the epilogue).
+
+The schedule below is a transcription of kstep() / the prologue; test_model_matches_source pins the transcribed lines.
+"""
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NW = 8
+
+
+def simulate(cpt, ntiles, a_it=6, b_it=2, fused=True):
+    """Returns nothing; raises AssertionError with a description on the first protocol violation."""
+    nchunks = cpt * ntiles
+    nsteps = 9 * nchunks
+    fifo = [[] for _ in range(NW)]          # per wave: issued load ops, oldest first: ("W", step) or ("H", chunk), one entry per DMA instruction
+    done = [set() for _ in range(NW)]       # per wave: resources guaranteed landed (all its parts)
+    certified = set()                       # resources every wave has had certified before a barrier that was passed
+    last_read_step = {}                     # resource -> last step in which somebody reads it from LDS
+    issue_step = {}
+
+    def issue(w, res, n, step):
+        fifo[w].extend([res] * n)
+        issue_step.setdefault(res, step)
+        # WAR: the slot / buffer being overwritten
+        prev = ("W", res[1] - 3) if res[0] == "W" else ("H", res[1] - 2)
+        if prev in last_read_step:
+            assert last_read_step[prev] < step, f"{res} issued in step {step} while {prev} is still read in step {last_read_step[prev]}"
+
+    def wait(w, n):
+        keep = fifo[w][len(fifo[w]) - n:] if n else []
+        for r in fifo[w][:len(fifo[w]) - n] if n else fifo[w]:
+            if r not in keep:       # a resource is complete when none of its instructions is among the n youngest
+                done[w].add(r)
+        fifo[w] = list(keep)
+
+    def barrier():
+        for r in set.intersection(*done):
+            certified.add(r)
+
+    def read(res, step, what):
+        assert res in certified, f"step {step}: {what} reads {res} before it is certified (cpt {cpt}, tiles {ntiles})"
+        last_read_step[res] = max(last_read_step.get(res, -1), step)
+
+    # ---- prologue ----
+    for w in range(NW):
+        issue(w, ("H", 0), a_it, -1)
+        for t in range(3):
+            issue(w, ("W", t), b_it, -1)
+        wait(w, b_it)
+    barrier()
+    if fused:
+        read(("H", 0), -1, "prologue transform")
+    read(("W", 0), -1, "prologue fragments")
+    read(("H", 0), -1, "prologue fragments")
+    barrier()
+
+    # ---- main loop ----
+    for s in range(nsteps):
+        c, tap = divmod(s, 9)
+        cc = c % cpt
+        tile_end = cc == cpt - 1
+        final = tile_end and c == nchunks - 1
+        issue_w = not (final and tap >= 6)
+        issue_h = tap == 0 and not final
+
+        def dma(w):
+            if issue_w:
+                issue(w, ("W", s + 3), b_it, s)
+            if issue_h:
+                issue(w, ("H", c + 1), a_it, s)
+        dma_first = [w >= NW // 2 and not (tap == 8 and tile_end) for w in range(NW)]
+        for w in range(NW):
+            if dma_first[w]:
+                dma(w)
+        # fragment prefetch of step s+1 (tap 8: after the epilogue, unless this is the workgroup's last step)
+        if not (tap == 8 and final):
+            read(("W", s + 1), s, "fragment prefetch")
+            read(("H", (s + 1) // 9), s, "fragment prefetch")
+        if fused and not final and 3 <= tap <= 7:
+            read(("H", c + 1), s, "input transform")
+        if tap == 8 and tile_end:
+            for w in range(NW):
+                wait(w, 0)                                  # vmcnt(0) ahead of the epilogue
+            last_read_step[("H", c)] = max(last_read_step.get(("H", c), -1), s)   # epilogue staging window = this chunk's halo buffer
+        for w in range(NW):
+            if not dma_first[w]:
+                dma(w)
+        if tap == 8 and final:
+            break
+        for w in range(NW):
+            if tap <= 1:
+                wait(w, a_it + b_it if not final else b_it)
+            elif tap < 6:
+                wait(w, b_it)
+            elif tap < 8:
+                wait(w, 0 if final else b_it)
+            elif not tile_end:
+                wait(w, b_it)
+        barrier()
+    return nsteps
+
+
+@pytest.mark.parametrize("cpt", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("ntiles", [1, 2, 3])
+@pytest.mark.parametrize("geom", [(6, 2), (2, 2)])  # (halo DMA instructions per wave, weight DMA instructions per wave): 18x18 / 10x10 halo
+def test_ring_protocol_is_safe(cpt, ntiles, geom):
+    simulate(cpt, ntiles, a_it=geom[0], b_it=geom[1], fused=True)
+    simulate(cpt, ntiles, a_it=geom[0], b_it=geom[1], fused=False)
+
+
+def test_model_detects_a_weaker_wait():
+    """The model is not vacuous: allowing one more weight tile in flight at taps 2..5 must be flagged."""
+    import types
+    src = simulate.__code__
+    ns = {}
+    code = open(__file__).read().split("def simulate(")[1].split("\n@pytest")[0]
+    code = "def simulate(" + code.replace("            elif tap < 6:\n                wait(w, b_it)", "            elif tap < 6:\n                wait(w, 2 * b_it)")
+    exec("NW = 8\n" + code, ns)
+    with pytest.raises(AssertionError):
+        ns["simulate"](2, 2)
+
+
+def test_model_matches_source():
+    s = open(os.path.join(ROOT, "genpercept_amd", "csrc", "conv_halo.hip")).read()
+    for line in ["const bool issue_w = !(final_ && TAP >= 6), issue_h = TAP == 0 && !final_;",
+                 "const bool dma_first = second_half && !(TAP == 8 && tile_end);",
+                 "if (TAP <= 1) { if (!final_) halo_wait_vm<A_IT + B_IT>(); else halo_wait_vm<B_IT>(); }",
+                 "else if (TAP < 6) halo_wait_vm<B_IT>();",
+                 "else if (TAP < 8) { if (final_) halo_wait_vm<0>(); else halo_wait_vm<B_IT>(); }",
+                 "else if (!tile_end) halo_wait_vm<B_IT>();",
+                 "halo_wait_vm<0>();  // everything this wave has in flight has landed",
+                 "halo_wait_vm<B_IT>();\n    __builtin_amdgcn_s_barrier();"]:
+        assert line in s, line
+
+
+# ---- persistent GEMM (pgemm.hip): 3-deep ring over the (tile, k) step stream ----------------------------------------------------------
+def simulate_pgemm(nk, ntiles, lps=6):
+    total = nk * ntiles
+    fifo = [[] for _ in range(NW)]
+    done = [set() for _ in range(NW)]
+    certified = set()
+    last_read = {}
+
+    def issue(w, stage, step, after_own_epilogue):
+        prev = stage - 3
+        if prev in last_read:
+            assert last_read[prev] < step, f"stage {stage} issued in step {step} while stage {prev} is still read in step {last_read[prev]}"
+        fifo[w].extend([stage] * lps)
+
+    def wait(w, n):
+        keep = fifo[w][len(fifo[w]) - n:] if n else []
+        for r in (fifo[w][:len(fifo[w]) - n] if n else fifo[w]):
+            if r not in keep:
+                done[w].add(r)
+        fifo[w] = list(keep)
+
+    def barrier():
+        certified.update(set.intersection(*done))
+
+    def read(stage, step):
+        assert stage in certified, f"step {step}: fragments of stage {stage} read before certification (nk {nk}, tiles {ntiles})"
+        last_read[stage] = max(last_read.get(stage, -1), step)
+
+    for w in range(NW):
+        for st in range(min(3, total)):
+            issue(w, st, -1, False)
+        wait(w, lps if total > 2 else 0)
+    barrier()
+    read(0, -1)
+    barrier()
+    for gs in range(total):
+        kt = gs % nk
+        tile_end = kt == nk - 1
+        issue_ok, more = gs + 3 < total, gs + 1 < total
+        dma_first = [w >= 4 and not tile_end for w in range(NW)]
+        for w in range(NW):
+            if dma_first[w] and issue_ok:
+                issue(w, gs + 3, gs, False)
+        if more:
+            read(gs + 1, gs)          # (past the end the kernel reads stale bytes nobody uses)
+        if tile_end:
+            for w in range(NW):
+                wait(w, 0)
+        for w in range(NW):
+            if not dma_first[w] and issue_ok:
+                issue(w, gs + 3, gs, tile_end)   # at a tile end: after this wave's own epilogue (its window = its own DMA pieces of the slot)
+        if not more:
+            break
+        for w in range(NW):
+            if not tile_end:
+                wait(w, lps if issue_ok else 0)
+        barrier()
+
+
+@pytest.mark.parametrize("nk", [1, 2, 3, 5, 10, 40])
+@pytest.mark.parametrize("ntiles", [1, 2, 4])
+@pytest.mark.parametrize("lps", [6, 4])
+def test_pgemm_ring_protocol_is_safe(nk, ntiles, lps):
+    simulate_pgemm(nk, ntiles, lps)
+
+
+def test_pgemm_model_matches_source():
+    s = open(os.path.join(ROOT, "genpercept_amd", "csrc", "pgemm.hip")).read()
+    for line in ["const bool issue = gs + 3 < total, more = gs + 1 < total;",
+                 "const bool dma_first = second_half && !tile_end;",
+                 "if (!tile_end) { if (issue) wait_vm<LPS>(); else wait_vm<0>(); }",
+                 "if (total > 2) wait_vm<LPS>(); else wait_vm<0>();",
+                 'asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");']:
+        assert line in s, line
