@@ -221,3 +221,57 @@ def test_pgemm_model_matches_source():
                  "if (total > 2) wait_vm<LPS>(); else wait_vm<0>();",
                  'asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");']:
         assert line in s, line
+
+
+# ---- generic implicit GEMM (igemm.hip): NSTAGE-deep ring, wait + barrier at the TOP of a step, operands read in the step itself ----------
+def simulate_igemm(nk, nstage, lps=6):
+    fifo = [[] for _ in range(NW)]
+    done = [set() for _ in range(NW)]
+    certified = set()
+    last_read = {}
+
+    def issue(w, stage, step):
+        prev = stage - nstage
+        if prev in last_read:
+            assert last_read[prev] < step, f"stage {stage} overwrites stage {prev} in step {step}, still read in step {last_read[prev]}"
+        fifo[w].extend([stage] * lps)
+
+    def wait(w, n):
+        keep = fifo[w][len(fifo[w]) - n:] if n else []
+        for r in (fifo[w][:len(fifo[w]) - n] if n else fifo[w]):
+            if r not in keep:
+                done[w].add(r)
+        fifo[w] = list(keep)
+
+    for w in range(NW):
+        for s0 in range(min(nstage - 1, nk)):
+            issue(w, s0, -1)
+    for kt in range(nk):
+        ahead = min(nstage - 2, nk - 1 - kt)
+        for w in range(NW):
+            wait(w, 2 * lps if ahead >= 2 else lps if ahead == 1 else 0)
+        certified.update(set.intersection(*done))          # s_barrier
+        do_stage = kt + nstage - 1 < nk
+        for w in range(NW // 2, NW):                        # second half: DMA before the MFMAs
+            if do_stage:
+                issue(w, kt + nstage - 1, kt)
+        assert kt in certified, f"step {kt} reads its operands before they are certified (nk {nk}, nstage {nstage})"
+        last_read[kt] = kt
+        for w in range(NW // 2):
+            if do_stage:
+                issue(w, kt + nstage - 1, kt)
+
+
+@pytest.mark.parametrize("nstage", [2, 3, 4])
+@pytest.mark.parametrize("nk", [1, 2, 3, 5, 9, 45, 180])
+def test_igemm_ring_protocol_is_safe(nk, nstage):
+    simulate_igemm(nk, nstage)
+
+
+def test_igemm_model_matches_source():
+    s = open(os.path.join(ROOT, "genpercept_amd", "csrc", "igemm.hip")).read()
+    for line in ["const int ahead = min(NSTAGE - 2, nk - 1 - kt);  // stages issued after step kt's",
+                 "if (ahead >= 2) wait_vm_n<2 * LPS>();", "else if (ahead == 1) wait_vm_n<LPS>();", "else wait_vm_n<0>();",
+                 "const bool do_stage = kt + NSTAGE - 1 < nk && !(p.dbg & 1);",
+                 "if (second_half && do_stage) stage(nxt);", "if (!second_half && do_stage) stage(nxt);"]:
+        assert line in s, line
