@@ -8,6 +8,7 @@
 // follow the public SD2.1 architecture.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -238,7 +239,8 @@ struct gp_engine {
         return pack(w.v.data(), b, cout, cin, ks, cin_pad, geglu);
     }
     // two linear layers stacked along the output dimension ([Wa; Wb]), optional biases
-    PackedW pack_stacked(const std::string& a, const std::string& b) {
+    // (scale_a multiplies the first layer's weight and bias: the softmax scale of an attention folded into its query projection)
+    PackedW pack_stacked(const std::string& a, const std::string& b, float scale_a = 1.f) {
         const HostTensor& wa = H(a + ".weight");
         const HostTensor& wb = H(b + ".weight");
         const int ca = (int)wa.shape[0], cb = (int)wb.shape[0], cin = (int)(wa.numel() / ca);
@@ -250,6 +252,10 @@ struct gp_engine {
             bias.resize(ca + cb);
             memcpy(bias.data(), H(a + ".bias").v.data(), ca * 4);
             memcpy(bias.data() + ca, H(b + ".bias").v.data(), cb * 4);
+        }
+        if (scale_a != 1.f) {
+            for (size_t i = 0; i < (size_t)ca * cin; ++i) w[i] *= scale_a;
+            for (int i = 0; i < ca && !bias.empty(); ++i) bias[i] *= scale_a;
         }
         return pack(w.data(), bias.empty() ? nullptr : bias.data(), ca + cb, cin, 1, round_up(cin, 64));
     }
@@ -308,7 +314,9 @@ struct gp_engine {
                           o = p + (newn ? ".to_out.0" : ".proj_attn");
         a.gn = norm_named(p + ".group_norm");
         a.C = a.gn.C;
-        a.qk = pack_stacked(q, k);
+        // softmax(q k^T / sqrt(C)): the scale goes into the query projection, so the logits the score GEMM writes are the SCALED ones
+        // (what diffusers keeps in fp16 too); raw 512-term dot products of a real checkpoint can pass fp16's 65504
+        a.qk = pack_stacked(q, k, 1.0f / std::sqrt((float)a.C));
         a.v = pack_named(v, 1);
         a.o = pack_named(o, 1);
         vattn[p] = std::move(a);
@@ -513,6 +521,24 @@ struct gp_engine {
         y.st_bm = bm;
         p.stats_out = y.st;
     }
+    // profiling level 3: one event before every launch; a launch's cost is the time to the next mark (kernel + the gap behind it)
+    struct Mark { hipEvent_t ev; std::string name; double flops; };
+    std::vector<Mark> marks;
+    size_t marks_used = 0;
+    void mark(const std::string& name, double flops = 0.0, int n = 1) {
+        tm.n_launches += n;
+        if (prof < 3) return;
+        if (marks_used == marks.size()) {
+            Mark m;
+            HIPCHK(hipEventCreate(&m.ev));
+            marks.push_back(m);
+        }
+        marks[marks_used].name = name;
+        marks[marks_used].flops = flops;
+        HIPCHK(hipEventRecord(marks[marks_used].ev, st));
+        ++marks_used;
+    }
+    static std::string dims(const Act& a) { return std::to_string(a.B) + "x" + std::to_string(a.H) + "x" + std::to_string(a.W) + "x" + std::to_string(a.C); }
     void prof_begin(int kind) {
         if (prof < 2) return;
         if (ev_used == ev_pool.size()) {
@@ -534,7 +560,15 @@ struct gp_engine {
         const int taps = p.ks == 3 ? 9 : 1;
         tm.flops_igemm += 2.0 * (double)p.M * (double)p.N * (double)p.Cin * taps * (p.batch > 0 ? p.batch : 1);
         tm.n_igemm++;
-        tm.n_launches++;
+        if (prof >= 3) {
+            const char* path = conv_uses_halo(p, hint) ? (p.in_scale ? (p.in_silu ? "halo+gn+silu" : "halo+gn") : "halo") : igemm_uses_pgemm(p, hint) ? "pgemm" : "igemm";
+            mark(std::string(p.ks == 3 ? (p.ups ? "conv3x3up " : (p.stride == 2 ? "conv3x3s2 " : "conv3x3 ")) : (p.batch > 1 ? "bgemm " : "gemm ")) + path + " M=" + std::to_string(p.M) +
+                     " N=" + std::to_string(p.N) + " K=" + std::to_string(p.Cin * taps) + (p.batch > 1 ? " batch=" + std::to_string(p.batch) : "") + (p.res ? " +res" : "") +
+                     (p.act == GP_ACT_GEGLU ? " geglu" : "") + (p.stats_out ? " +stats" : ""),
+                 2.0 * (double)p.M * (double)p.N * (double)p.Cin * taps * (p.batch > 0 ? p.batch : 1));
+        } else {
+            tm.n_launches++;
+        }
         prof_begin(0);
         launch_igemm(p, hint, st);
         prof_end();
@@ -613,19 +647,19 @@ struct gp_engine {
         scale = ws + groupnorm_ws_floats(x.B, x.H * x.W, x.C, cfg.norm_groups);
         shift = scale + (size_t)x.B * x.C;
         if (x.st) {
+            mark("gn_finalize_tiles " + dims(x));
             launch_groupnorm_from_partials(x.st, x.st_mode, x.st_bm, x.B, x.H, x.W, x.C, cfg.norm_groups, eps, n.g, n.b, scale, shift, st);
-            tm.n_launches++;
         } else {
+            mark("gn_stats+finalize " + dims(x), 0.0, 2);
             launch_groupnorm_stats(x.p, n.g, n.b, x.B, x.H * x.W, x.C, cfg.norm_groups, eps, ws, scale, shift, st);
-            tm.n_launches += 2;
         }
     }
     Act groupnorm(const Act& x, const NormW& n, float eps, bool silu) {
         float *scale, *shift;
         gn_scale_shift(x, n, eps, scale, shift);
         Act y = new_act(x.B, x.H, x.W, x.C);
+        mark("gn_apply " + dims(x));
         launch_groupnorm_apply(x.p, y.p, scale, shift, x.B, x.H * x.W, x.C, silu ? 1 : 0, st);
-        tm.n_launches++;
         return y;
     }
     float* gn_workspace(const Act& x) {  // partial statistics + per-(image, channel) scale / shift
@@ -652,16 +686,16 @@ struct gp_engine {
         const bool fuse_here = slices <= gn_fuse_max_slices || x.H * x.W < gn_fuse_always_below_px;
         if (fuse_gn && fuse_here && conv_uses_halo(p, 0)) return conv(x, w, o, scale, shift, silu);
         Act y = new_act(x.B, x.H, x.W, x.C);
+        mark("gn_apply " + dims(x));
         launch_groupnorm_apply(x.p, y.p, scale, shift, x.B, x.H * x.W, x.C, silu ? 1 : 0, st);
-        tm.n_launches++;
         Act out = conv(y, w, o);
         drop(y);
         return out;
     }
     Act layernorm(const Act& x, const NormW& n) {
         Act y = new_act(x.B, x.H, x.W, x.C);
+        mark("layernorm " + dims(x));
         launch_layernorm(x.p, y.p, n.g, n.b, (int)x.pixels(), x.C, 1e-5f, st);
-        tm.n_launches++;
         return y;
     }
 
@@ -688,8 +722,10 @@ struct gp_engine {
         Act qk = linear(n, a.qk);  // [B*T][2C]
         bf16_t* vt = v_transposed(n, a.v, T, Tpad);
         drop(n);
-        // logits as fp16 (11 significant bits: finer than the bf16 probabilities they turn into; raw q.k of GroupNorm-ed activations
-        // stays far below 65504) halve the score traffic, the largest HBM item of the VAE; GENPERCEPT_FP32_SCORES=1 keeps fp32 (A/B)
+        // logits as fp16 (11 significant bits: finer than the bf16 probabilities they turn into) halve the score traffic, the largest HBM
+        // item of the VAE.  They are the SCALED logits (1/sqrt(C) is folded into the query projection, build_vae_attn) and the fp16
+        // conversion saturates at +-65504 (epilogue.h), so an outlier row degrades to a one-hot softmax instead of inf - inf = NaN.
+        // GENPERCEPT_FP32_SCORES=1 keeps fp32 (A/B)
         static const bool f32_scores = getenv("GENPERCEPT_FP32_SCORES") != nullptr;
         const bool half_scores = !f32_scores && softmax_rows_f16_supported(Tpad);
         float* S = (float*)pool.alloc((size_t)B * T * Tpad * (half_scores ? 2 : 4));
@@ -703,9 +739,9 @@ struct gp_engine {
         }
         drop(qk);
         bf16_t* P = (bf16_t*)pool.alloc((size_t)B * T * Tpad * sizeof(bf16_t));
-        if (half_scores) launch_softmax_rows_f16(S, P, B * T, T, Tpad, 1.0f / std::sqrt((float)C), st);
-        else launch_softmax_rows(S, P, B * T, T, Tpad, 1.0f / std::sqrt((float)C), st);
-        tm.n_launches++;
+        mark("softmax_rows T=" + std::to_string(T));
+        if (half_scores) launch_softmax_rows_f16(S, P, B * T, T, Tpad, 1.0f, st);
+        else launch_softmax_rows(S, P, B * T, T, Tpad, 1.0f, st);
         pool.release(S);
         Act o = new_act(x.B, x.H, x.W, C);
         {
@@ -738,7 +774,7 @@ struct gp_engine {
         Act a = new_act(x.B, x.H, x.W, C);
         tm.flops_attn += 4.0 * x.B * t.heads * (double)T * T * 64;
         tm.n_attn++;
-        tm.n_launches++;
+        mark("flash_attn64 T=" + std::to_string(T) + " heads=" + std::to_string(t.heads), 4.0 * x.B * t.heads * (double)T * T * 64);
         prof_begin(1);
         launch_flash_attn64(qk.p, qk.p + C, vt, a.p, zero, x.B, T, t.heads, 2 * C, 2 * C, Tpad, C, st);
         prof_end();
@@ -751,8 +787,8 @@ struct gp_engine {
         Act q2 = linear(l2, t.q2);
         drop(l2);
         Act a2 = new_act(x.B, x.H, x.W, C);
+        mark("cross_attn_small " + dims(q2));
         launch_cross_attn_small(q2.p, t.kc, t.vc, a2.p, (int)x.pixels(), C, ctx_L, st);
-        tm.n_launches++;
         drop(q2);
         linear(a2, t.o2, y.p, GP_ACT_NONE, y.p);
         drop(a2);
@@ -782,7 +818,7 @@ struct gp_engine {
                 h.st_bm = 256;
             }
             tm.flops_igemm += 2.0 * (double)h.pixels() * win.cout * 27.0;
-            tm.n_launches++;
+            mark("rgb_conv_in " + dims(h), 2.0 * (double)h.pixels() * win.cout * 27.0);
             prof_begin(0);
             if (!conv_in_w27) {  // compact K = 27 weight matrix, built once from the packed conv weight
                 HIPCHK(hipMalloc((void**)&conv_in_w27, (size_t)win.cout * 32 * sizeof(bf16_t)));
@@ -793,8 +829,8 @@ struct gp_engine {
             prof_end();
         } else {
             Act x = new_act(B, Hh, Ww, 64);
+            mark("rgb_prologue");
             launch_rgb_prologue(rgb, is_u8, x.p, B, Hh, Ww, 64, st);
-            tm.n_launches++;
             ConvOpt oin;
             oin.want_stats = true;
             h = conv(x, win, oin);
@@ -874,6 +910,7 @@ struct gp_engine {
                 skips.pop_back();
                 Act cat = new_act(h.B, h.H, h.W, h.C + skip.C);
                 const int cbm = fuse_stats ? concat_stats_bm((long long)h.H * h.W) : 0;
+                mark("concat " + dims(cat));
                 if (cbm) {  // the copy also leaves the statistics the resnet's first GroupNorm needs
                     cat.st = (float*)pool.alloc((size_t)(h.pixels() / cbm) * cat.C * 2 * sizeof(float));
                     cat.st_mode = 0;
@@ -882,7 +919,6 @@ struct gp_engine {
                 } else {
                     launch_concat(h.p, h.C, skip.p, skip.C, cat.p, h.pixels(), st);
                 }
-                tm.n_launches++;
                 drop(h);
                 drop(skip);
                 Act y = resnet(cat, bp + ".resnets." + std::to_string(j), cfg.unet_norm_eps);
@@ -904,6 +940,7 @@ struct gp_engine {
             }
             if (feats) {
                 feats[i] = new_act(h.B, h.H, h.W, h.C);
+                mark("feat_copy " + dims(h));
                 HIPCHK(hipMemcpyAsync(feats[i].p, h.p, (size_t)h.pixels() * h.C * 2, hipMemcpyDeviceToDevice, st));
             }
         }
@@ -923,8 +960,8 @@ struct gp_engine {
     Act vae_decode(const Act& z_in, float in_scale) {
         const int L = cfg.vae_latent_channels;
         Act z = new_act(z_in.B, z_in.H, z_in.W, 64);
+        mark("post_quant_conv");
         launch_pointwise_small(z_in.p, z.p, pq_w_dev, pq_b_dev, z_in.pixels(), L, L, z_in.C, 64, in_scale, st);
-        tm.n_launches++;
         ConvOpt oin;
         oin.want_stats = true;
         Act h = conv(z, convs.at("vae.decoder.conv_in"), oin);
@@ -957,8 +994,8 @@ struct gp_engine {
 
     Act rcu(const Act& x, const std::string& p) {  // pre-activation residual unit (dpt_head.py:256-271)
         Act r = new_act(x.B, x.H, x.W, x.C);
+        mark("relu " + dims(x));
         launch_relu(x.p, r.p, x.pixels() * x.C, st);
-        tm.n_launches++;
         ConvOpt o1;
         o1.act = GP_ACT_RELU;
         Act h = conv(r, convs.at(p + ".convolution1"), o1);
@@ -990,8 +1027,8 @@ struct gp_engine {
                 bool resized = false;
                 if (r.H != fused.H || r.W != fused.W) {
                     Act rr = new_act(r.B, fused.H, fused.W, r.C);
+                    mark("bilinear " + dims(rr));
                     launch_bilinear(r.p, rr.p, r.B, r.H, r.W, fused.H, fused.W, r.C, 0, st);
-                    tm.n_launches++;
                     drop(r);
                     r = rr;
                     resized = true;
@@ -1000,16 +1037,16 @@ struct gp_engine {
                 Act rc = rcu(r, lp + ".residual_layer1");
                 drop(r);
                 x = new_act(fused.B, fused.H, fused.W, fused.C);
+                mark("add " + dims(fused));
                 launch_add(fused.p, rc.p, x.p, fused.pixels() * fused.C, st);
-                tm.n_launches++;
                 drop(rc);
                 drop(fused);
             }
             Act x2 = rcu(x, lp + ".residual_layer2");
             drop(x);
             Act up = new_act(x2.B, x2.H * 2, x2.W * 2, x2.C);
+            mark("bilinear " + dims(up));
             launch_bilinear(x2.p, up.p, x2.B, x2.H, x2.W, x2.H * 2, x2.W * 2, x2.C, 1, st);
-            tm.n_launches++;
             drop(x2);
             fused = linear(up, convs.at(lp + ".projection"));
             drop(up);
@@ -1021,27 +1058,27 @@ struct gp_engine {
         Act y = conv(x, convs.at("dpt.head.head.0"), ConvOpt{});
         drop(x);
         Act up = new_act(y.B, y.H * 2, y.W * 2, y.C);
+        mark("bilinear " + dims(up));
         launch_bilinear(y.p, up.p, y.B, y.H, y.W, y.H * 2, y.W * 2, y.C, 1, st);
-        tm.n_launches++;
         drop(y);
         ConvOpt o32;
         o32.act = GP_ACT_RELU;
         Act z = conv(up, convs.at("dpt.head.head.2"), o32);
         drop(up);
+        mark("dpt_final " + dims(z));
         launch_dpt_final(z.p, dpt_w_dev, dpt_b, out_dev, z.B, z.H * z.W, z.C, st);
-        tm.n_launches++;
         drop(z);
     }
 
     Act from_nchw_f32(const float* src, int B, int C, int Hh, int Ww, int Cpad) {
         Act a = new_act(B, Hh, Ww, Cpad);
+        mark("nchw_f32_to_nhwc");
         launch_nchw_f32_to_nhwc(src, a.p, B, C, Hh, Ww, Cpad, st);
-        tm.n_launches++;
         return a;
     }
     void to_nchw_f32(const Act& a, int C, float* dst) {
+        mark("nhwc_to_nchw_f32");
         launch_nhwc_to_nchw_f32(a.p, dst, a.B, C, a.H, a.W, a.C, st);
-        tm.n_launches++;
     }
 
     void collect_profile() {
@@ -1132,6 +1169,7 @@ void gp_destroy(gp_engine* e) {
     for (void* p : e->weights_dev) hipFree(p);
     e->pool.destroy();
     for (auto& pr : e->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto& m : e->marks) hipEventDestroy(m.ev);
     for (int i = 0; i < 4; ++i) if (e->ev[i]) hipEventDestroy(e->ev[i]);
     delete e;
 }
@@ -1196,6 +1234,36 @@ gp_status gp_get_timings(gp_engine* e, gp_timings* out) {
     });
 }
 
+/* Per-launch log of the last gp_infer at profiling level 3: one line "ms<TAB>flops<TAB>name" per launch (ms = time to the next launch's
+ * start: kernel + gap).  Returns the number of bytes the full log needs (incl. NUL); writes at most cap bytes. */
+int gp_get_launch_log(gp_engine* e, char* buf, int cap) {
+    if (!e) return -1;
+    std::string out;
+    try {
+        if (e->marks_used > 1) {
+            HIPCHK(hipEventSynchronize(e->marks[e->marks_used - 1].ev));
+            for (size_t i = 0; i + 1 < e->marks_used; ++i) {
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, e->marks[i].ev, e->marks[i + 1].ev));
+                char line[64];
+                snprintf(line, sizeof line, "%.4f\t%.0f\t", ms, e->marks[i].flops);
+                out += line;
+                out += e->marks[i].name;
+                out += "\n";
+            }
+        }
+    } catch (const std::exception& ex) {
+        e->err = ex.what();
+        return -1;
+    }
+    if (buf && cap > 0) {
+        const size_t n = std::min(out.size(), (size_t)cap - 1);
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return (int)out.size() + 1;
+}
+
 static void check_ready(gp_engine* e, void* stream) {
     if (!e->finalized) throw std::logic_error("engine not finalized");
     HIPCHK(hipSetDevice(e->cfg.device));
@@ -1212,6 +1280,7 @@ gp_status gp_infer(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, i
             for (int i = 0; i < 4; ++i) if (!e->ev[i]) HIPCHK(hipEventCreate(&e->ev[i]));
             HIPCHK(hipEventRecord(e->ev[0], e->st));
         }
+        e->marks_used = 0;
         Act lat = e->vae_encode(rgb_dev, is_u8, B, H, W);
         if (stage_ev) HIPCHK(hipEventRecord(e->ev[1], e->st));
         if (!e->cfg.dpt_enabled) {
@@ -1222,8 +1291,8 @@ gp_status gp_infer(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, i
             Act dec = e->vae_decode(v, -1.0f / e->cfg.vae_scaling_factor);
             e->drop(v);
             const int mean3 = !(mode == GP_MODE_NORMAL || mode == GP_MODE_SEG);
+            e->mark("decode_epilogue");
             launch_decode_epilogue(dec.p, out_dev, B, dec.H, dec.W, dec.C, mean3, 0, e->st);
-            e->tm.n_launches++;
             e->drop(dec);
         } else {
             Act feats[4];
@@ -1234,9 +1303,10 @@ gp_status gp_infer(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, i
             const long long out_px = (long long)gp_dpt_out_size(rev[0].H) * gp_dpt_out_size(rev[0].W);
             e->dpt_head(rev, out_dev);
             for (int i = 0; i < 4; ++i) e->drop(feats[i]);
+            e->mark("minmax_norm", 0.0, 2);
             launch_minmax_norm(out_dev, B, out_px, e->mm_ws, e->st);
-            e->tm.n_launches += 2;
         }
+        e->mark("END", 0.0, 0);
         if (stage_ev) {
             HIPCHK(hipEventRecord(e->ev[3], e->st));
             HIPCHK(hipEventSynchronize(e->ev[3]));
@@ -1290,9 +1360,24 @@ gp_status gp_vae_decode(gp_engine* e, const float* pred_latent, int B, int h, in
         Act dec = e->vae_decode(z, 1.0f / e->cfg.vae_scaling_factor);
         e->drop(z);
         // decode_pred (genpercept_pipeline.py:507-526): channel mean for 1-channel modes, no clip / shift
+        e->mark("decode_epilogue");
         launch_decode_epilogue(dec.p, out, B, h * 8, w * 8, dec.C, mean3, 1, e->st);
-        e->tm.n_launches++;
         e->drop(dec);
+        HIPCHK(hipGetLastError());
+    });
+}
+
+gp_status gp_vae_mid_attention(gp_engine* e, int decoder, const float* x, int B, int h, int w, float* out, void* stream) {
+    if (!e || !x || !out) return GP_ERR_INVALID;
+    return guard(e, [&] {
+        check_ready(e, stream);
+        const std::string name = decoder ? "vae.decoder.mid_block.attentions.0" : "vae.encoder.mid_block.attentions.0";
+        const int C = e->vattn.at(name).C;
+        Act a = e->from_nchw_f32(x, B, C, h, w, C);
+        Act y = e->vae_attention(a, name);
+        e->drop(a);
+        e->to_nchw_f32(y, C, out);
+        e->drop(y);
         HIPCHK(hipGetLastError());
     });
 }

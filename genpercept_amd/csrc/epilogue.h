@@ -172,7 +172,9 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
                 else if (p.act == GP_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
                 if (col + e >= n_out) v[e] = 0.f;
             }
-            if (p.out_fp32 == 2) {  // fp16 output (attention logits: 11 significant bits, range 65504)
+            if (p.out_fp32 == 2) {  // fp16 output (attention logits: 11 significant bits), saturating at the fp16 range
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e], -65504.f), 65504.f);
                 _Float16* o = (_Float16*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
                 if (col + 7 < p.n_store && (p.ldo & 7) == 0) {
                     typedef _Float16 h8_t __attribute__((ext_vector_type(8)));

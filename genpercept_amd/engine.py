@@ -61,9 +61,11 @@ SYMBOLS = {
     "gp_unet": (_i, [_vp, _vp, _i, _i, _i, _vp, C.POINTER(_vp), _vp]),
     "gp_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gp_dpt_head": (_i, [_vp, C.POINTER(_vp), _i, _i, _i, _vp, _vp]),
+    "gp_vae_mid_attention": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "gp_set_profile": (_i, [_vp, _i]),
     "gp_get_timings": (_i, [_vp, C.POINTER(GpTimings)]),
     "gp_reset_timings": (_i, [_vp]),
+    "gp_get_launch_log": (_i, [_vp, C.c_char_p, _i]),
     "gp_packed_rows": (_i, [_i]),
     "gp_latent_size": (_i, [_i]),
     "gp_dpt_out_size": (_i, [_i]),
@@ -246,6 +248,13 @@ class Engine:
         self._check(self.lib.gp_vae_decode(self._h, z.data_ptr(), b, h, w, int(mean3), out.data_ptr(), _stream_ptr()))
         return out
 
+    def vae_mid_attention(self, x: torch.Tensor, decoder: bool) -> torch.Tensor:
+        x = x.float().contiguous()
+        b, _, h, w = x.shape
+        out = torch.empty_like(x)
+        self._check(self.lib.gp_vae_mid_attention(self._h, int(decoder), x.data_ptr(), b, h, w, out.data_ptr(), _stream_ptr()))
+        return out
+
     def dpt_head(self, feats: Sequence[torch.Tensor]) -> torch.Tensor:
         feats = [f.float().contiguous() for f in feats]
         b, _, h, w = feats[0].shape
@@ -260,6 +269,19 @@ class Engine:
 
     def reset_timings(self):
         self._check(self.lib.gp_reset_timings(self._h))
+
+    def launch_log(self):
+        """[(ms, flops, description)] of the last infer() at profiling level 3 (kernel time + the gap to the next launch)."""
+        n = self.lib.gp_get_launch_log(self._h, None, 0)
+        if n <= 1:
+            return []
+        buf = C.create_string_buffer(n)
+        self.lib.gp_get_launch_log(self._h, buf, n)
+        rows = []
+        for line in buf.value.decode().splitlines():
+            ms, fl, name = line.split("\t", 2)
+            rows.append((float(ms), float(fl), name))
+        return rows
 
     def timings(self) -> dict:
         t = GpTimings()

@@ -95,6 +95,9 @@ gp_status gp_vae_encode(gp_engine* e, const void* rgb_dev, int is_u8, int B, int
 gp_status gp_unet(gp_engine* e, const float* latent_in, int B, int h, int w, float* sample_out /* may be NULL */,
                   float* const* feats_out /* 4 pointers or NULL; multi_level_feats order */, void* stream);
 gp_status gp_vae_decode(gp_engine* e, const float* pred_latent, int B, int h, int w, int mean3, float* out, void* stream);
+/* The VAE mid-block attention alone (AutoencoderKL mid_block.attentions[0]: GroupNorm, 1 head x C, +residual; call sites
+ * genpercept_pipeline.py:500-501 / :521-522); decoder = 0: the encoder's, 1: the decoder's.  x, out: DEVICE fp32 [B][C][h][w]. */
+gp_status gp_vae_mid_attention(gp_engine* e, int decoder, const float* x, int B, int h, int w, float* out, void* stream);
 gp_status gp_dpt_head(gp_engine* e, const float* const* feats /* reversed multi_level_feats: [c0@h, c1@h, c2@h/2, c3@h/4] */,
                       int B, int h, int w, float* out /* [B][gp_dpt_out_size(h)][gp_dpt_out_size(w)], not normalised */, void* stream);
 
@@ -102,6 +105,9 @@ gp_status gp_dpt_head(gp_engine* e, const float* const* feats /* reversed multi_
 gp_status gp_set_profile(gp_engine* e, int level);
 gp_status gp_get_timings(gp_engine* e, gp_timings* out);
 gp_status gp_reset_timings(gp_engine* e);
+/* Profiling level 3: text log of the last gp_infer, one line "ms<TAB>algorithmic flops<TAB>description" per kernel launch
+ * (ms = start-to-next-start on the stream: kernel time plus the gap behind it).  Returns the bytes needed (incl. NUL). */
+int gp_get_launch_log(gp_engine* e, char* buf, int cap);
 
 /* ---- per-kernel entry points (DEVICE pointers, bf16 NHWC activations) -------------------------------------------- */
 /* Pack an OIHW fp32 HOST weight into the device layout [n_rows][taps][cin_pad] bf16 (n_rows = gp_packed_rows(cout)). */

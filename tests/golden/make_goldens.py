@@ -7,6 +7,7 @@ Fixtures are data (seeds, inputs, expected outputs) — never reference source.
                      (/root/reference/genpercept/models/dpt_head.py) on seeded weights/inputs.  `diffusers` is not
                      installed, so the two symbols dpt_head.py imports from it (LoRACompatibleConv, USE_PEFT_BACKEND;
                      dpt_head.py:20-21,130) are provided by a stub module.
+  dpt_head_ref_odd.npz  the same class on odd feature shapes (9x11, 13x10, 29x39 latents): the bilinear-resize branch dpt_head.py:297-300.
   metrics_ref.npz    outputs of the REFERENCE's src/util/metric.py + src/util/alignment.py on seeded arrays.
   batchsize_ref.npz  the REFERENCE's find_batch_size (genpercept/util/batchsize.py) on a grid of cards / resolutions / ensembles.
   infer_eval_ref.npz the REFERENCE's get_pred_name (all naming modes) and alignment variants (max_resolution, disparity-space protocol).
@@ -76,6 +77,38 @@ def make_dpt_golden():
         out[f"{tag}_out"] = y.numpy().astype(np.float32)
     np.savez_compressed(os.path.join(HERE, "dpt_head_ref.npz"), seed=np.array(7), **out)
     print("dpt_head_ref.npz", {k: v.shape for k, v in out.items()})
+
+
+def make_dpt_golden_odd():
+    """DPT head on the feature shapes a NON-multiple-of-4 latent produces (UNet stride-2 pad-1 downsamples: 9x11 -> 5x6 -> 3x3, 13x10 ->
+    7x5 -> 4x3): the fused map and the next neck feature then differ in size and the reference takes its bilinear-resize branch
+    (dpt_head.py:297-300), which the even-shape fixture above never reaches."""
+    _stub_diffusers()
+    sys.path.insert(0, REF)
+    from transformers import DPTConfig
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("ref_dpt_head", os.path.join(REF, "genpercept/models/dpt_head.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with open(os.path.join(REF, "hf_configs/dpt-sd2.1-unet-after-upsample-general/config.json")) as f:
+        cfg = DPTConfig(**json.load(f))
+    head = mod.DPTNeckHeadForUnetAfterUpsampleIdentity(cfg).eval()
+    sd = osd.synth_state_dict(odpt.dpt_manifest(), seed=7)
+    head.load_state_dict(sd, strict=True)
+    out = {}
+    for tag, (h, w) in {"c": (9, 11), "d": (13, 10), "e": (29, 39)}.items():
+        h2, w2 = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        h4, w4 = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
+        g = torch.Generator().manual_seed(200 + h * w)
+        feats = [torch.randn(1, 320, h, w, generator=g), torch.randn(1, 640, h, w, generator=g),
+                 torch.randn(1, 1280, h2, w2, generator=g), torch.randn(1, 1280, h4, w4, generator=g)]
+        with torch.no_grad():
+            y = head(hidden_states=[f.clone() for f in feats], return_depth_only=True)
+        out[f"{tag}_hw"] = np.array([h, w])
+        out[f"{tag}_out"] = y.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "dpt_head_ref_odd.npz"), seed=np.array(7), **out)
+    print("dpt_head_ref_odd.npz", {k: v.shape for k, v in out.items()}, os.path.getsize(os.path.join(HERE, "dpt_head_ref_odd.npz")) // 1024, "KiB")
 
 
 def make_metrics_golden():
@@ -273,6 +306,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["dpt", "metrics", "e2e", "batchsize", "infer_eval", "image_util"]
     if "dpt" in which:
         make_dpt_golden()
+    if "dpt" in which or "dpt_odd" in which:
+        make_dpt_golden_odd()
     if "metrics" in which:
         make_metrics_golden()
     if "e2e" in which:

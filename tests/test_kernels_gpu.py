@@ -442,3 +442,46 @@ def test_bilinear(case, metric_log):
     d = _dev()
     y = e.bilinear(e.to_nhwc_bf16(x.to(d)), (ho, wo), align)
     check(f"bilinear{case}", nhwc_to_nchw(y), ref, metric_log)
+
+
+HEAVY_CASES = [
+    # (Cin, Cout, H = W of the INPUT, x2 upsample, fused GroupNorm+SiLU input) -- the heaviest 3x3 layers of the 768x768 pass
+    # (SURVEY.md Appendix C), at BASELINE.json configs[1]'s batch 4: the persistent kernels size their grid as #CU / B, so B = 4 walks
+    # different tile lists than the small cases above
+    (512, 512, 192, False, False), (256, 256, 384, False, False), (128, 128, 768, False, False),
+    (512, 512, 192, True, False), (256, 256, 384, True, False), (512, 256, 384, False, False), (256, 128, 768, False, False),
+    (128, 128, 768, False, True), (256, 128, 768, False, True),
+]
+
+
+@pytest.mark.parametrize("case", HEAVY_CASES)
+def test_heaviest_layers_batch4_vs_fp32(case, metric_log):
+    """Per-layer parity at the benched batch: HIP conv (auto tile selection = what the engine launches) on [4, Cin, H, W] against an
+    fp32 torch conv of the same bf16-rounded operands, evaluated on the host CPU for the first and the last image of the batch."""
+    e = _eng()
+    cin, cout, hw, ups, fused = case
+    b = 4
+    g = torch.Generator().manual_seed(cin + cout + hw + 7 * ups + 13 * fused)
+    x = rbf(torch.randn(b, cin, hw, hw, generator=g) * (1.0 + torch.arange(b).float().view(b, 1, 1, 1) * 0.25))
+    wt = rbf(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
+    bias = torch.randn(cout, generator=g)
+    d = _dev()
+    xd = e.to_nhwc_bf16(x.to(d))
+    wp = e.pack_weight(wt, device=d)
+    if fused:
+        gamma = 1.0 + 0.1 * torch.randn(cin, generator=g)
+        beta = 0.1 * torch.randn(cin, generator=g)
+        y = e.conv2d_gn(xd, wp, bias.to(d), cout, gamma.to(d), beta.to(d), 32, 1e-6, silu=True)
+    else:
+        y = e.conv2d(xd, wp, bias.to(d), cout, 3, ups_hw=(2 * hw, 2 * hw) if ups else None, tile=0)
+    torch.cuda.synchronize()
+    yc = nhwc_to_nchw(y[[0, b - 1]]).cpu()
+    del y, xd
+    with torch.no_grad():
+        xi = x[[0, b - 1]]
+        if fused:
+            xi = rbf(F.silu(F.group_norm(xi, 32, gamma, beta, 1e-6)))  # the kernel rounds the normalised operand to bf16 for the MFMA
+        if ups:
+            xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+        ref = F.conv2d(xi, wt, bias, padding=1)
+    check(f"heavy_b4{case}", yc, ref, metric_log)

@@ -43,6 +43,27 @@ def test_dpt_oracle_matches_reference_outputs():
         np.testing.assert_allclose(y, g[f"{tag}_out"], rtol=1e-5, atol=1e-5)
 
 
+def _odd_dpt_feats(h, w):
+    h2, w2 = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    h4, w4 = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
+    gen = torch.Generator().manual_seed(200 + h * w)
+    return [torch.randn(1, 320, h, w, generator=gen), torch.randn(1, 640, h, w, generator=gen),
+            torch.randn(1, 1280, h2, w2, generator=gen), torch.randn(1, 1280, h4, w4, generator=gen)]
+
+
+def test_dpt_oracle_matches_reference_outputs_odd_shapes():
+    """dpt_head_ref_odd.npz: the reference's dpt_head.py on the feature shapes of latents 9x11, 13x10 and 29x39, where the fused map
+    and the next neck feature differ in size -- pins the bilinear-resize branch (dpt_head.py:297-300 / oracle/dpt.py) to the reference."""
+    g = np.load(os.path.join(GOLD, "dpt_head_ref_odd.npz"))
+    sd = osd.synth_state_dict(odpt.dpt_manifest(), int(g["seed"]))
+    for tag in "cde":
+        h, w = (int(x) for x in g[f"{tag}_hw"])
+        with torch.no_grad():
+            y = odpt.dpt_head_forward(sd, _odd_dpt_feats(h, w)).numpy()
+        assert y.shape == g[f"{tag}_out"].shape
+        np.testing.assert_allclose(y, g[f"{tag}_out"], rtol=1e-5, atol=2e-5)
+
+
 def test_scheduler_identity_and_timesteps():
     """beta == 1 => pred_original_sample == -model_output for ANY t; one leading-spaced step with offset 1 => t = 1."""
     assert opipe.ddim_timesteps(1).tolist() == [1]
