@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--head", default="vae", choices=["vae", "dpt"], help="BASELINE.json configs[1]/[2] = vae (depth/normal), configs[3] = dpt")
     ap.add_argument("--cpu-res", type=int, default=384, help="edge of the single image timed on the CPU oracle (BASELINE.json configs[0])")
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads for the baseline leg (256 oversubscribes badly)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"], help="element type of the engine (bf16 = BASELINE.json's dtype; fp16 = the 1e-3-parity build, same MFMA rate)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -75,7 +76,7 @@ def main():
     usd = gw.synth_state_dict(gw.unet_manifest(ucfg), seed=0)
     vsd = gw.synth_state_dict(gw.vae_manifest(vcfg), seed=1)
     ctx = torch.randn(2, ucfg.cross_attention_dim, generator=torch.Generator().manual_seed(2))
-    eng = Engine(local_rank, ucfg, vcfg, dcfg)
+    eng = Engine(local_rank, ucfg, vcfg, dcfg, precision=args.precision)
     eng.load_state_dict("vae", vsd)
     eng.load_state_dict("unet", usd)
     if dpt:
@@ -160,7 +161,7 @@ def main():
         head_name = "DPT disparity head" if dpt else f"{args.mode} head"
         line = {"metric": f"images/sec at 768x768 bf16 ({'depth' if not dpt and args.mode == 'depth' else head_name})", "value": round(value, 3), "unit": "images/sec", "n_gpus": n_gpus,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                 "config": {"workload": (f"{head_name}, SD2.1 VAE-enc + UNet(t=1) + " + ("DPT neck/head" if dpt else "VAE-dec") +
                                         f", {args.res}x{args.res}, batch {args.batch}/GPU (BASELINE.json configs[{3 if dpt else (1 if args.mode == 'depth' else 2)}])"), "global_batch": args.batch * n_gpus, "resolution": args.res,
                            "parallelism": f"dp{n_gpus} (batch-sharded, weights replicated, no data-path collective)",

@@ -1,4 +1,4 @@
-"""Build libgenpercept_hip.so (gfx950 only) in-tree with hipcc.  No JIT cache: the .so travels with the snapshot."""
+"""Build libgenpercept_hip.so / libgenpercept_hip_f16.so (gfx950 only) in-tree with hipcc.  No JIT cache: the .so files travel with the snapshot."""
 from __future__ import annotations
 
 import os
@@ -10,7 +10,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libgenpercept_hip.so")
+# one library per 16-bit element type (csrc/common.h): same sources, same C-ABI, GP_F16 selects IEEE fp16 instead of bf16
+LIBS = {"bf16": os.path.join(LIBDIR, "libgenpercept_hip.so"), "fp16": os.path.join(LIBDIR, "libgenpercept_hip_f16.so")}
+LIB = LIBS["bf16"]
 SOURCES = ["igemm.hip", "conv_halo.hip", "pgemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -29,19 +31,27 @@ def _stale(out: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = True) -> str:
+def build_library(force: bool = False, verbose: bool = True, precisions=("bf16", "fp16")) -> str:
+    """Compile (if stale) and link libgenpercept_hip.so (bf16 elements) and libgenpercept_hip_f16.so (fp16 elements); returns the bf16 path."""
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "genpercept_hip.h"))
-    objs = []
-    jobs = []
-    for src in SOURCES:
-        s = os.path.join(CSRC, src)
-        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        objs.append(o)
-        if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+    jobs, links = [], []
+    for prec in precisions:
+        objdir = os.path.join(LIBDIR, "obj_" + prec)
+        os.makedirs(objdir, exist_ok=True)
+        defs = ["-DGP_F16=1"] if prec == "fp16" else []
+        objs, dirty = [], False
+        for src in SOURCES:
+            s = os.path.join(CSRC, src)
+            o = os.path.join(objdir, src.replace(".hip", ".o"))
+            objs.append(o)
+            if force or _stale(o, [s] + headers):
+                jobs.append([hipcc, *FLAGS, *defs, "-c", s, "-o", o])
+                dirty = True
+        if force or dirty or not os.path.exists(LIBS[prec]):
+            links.append([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIBS[prec]])
 
     def run(cmd):
         if verbose:
@@ -49,13 +59,11 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
-        if verbose and r.stderr.strip():
-            print(r.stderr, file=sys.stderr)
 
-    with ThreadPoolExecutor(max_workers=min(len(jobs), 6) or 1) as ex:
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4) or 1) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or not os.path.exists(LIB):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+    for cmd in links:
+        run(cmd)
     return LIB
 
 

@@ -22,9 +22,9 @@ GP_DEV int attn_off128(int row, int slot) { return row * 128 + ((slot ^ ((row >>
 // NKB: 32-key blocks per KV tile (2: 64 keys, 4: 128 keys -- one online-softmax update, one barrier and one DMA wait per 128 keys,
 // longer independent MFMA runs)
 template <int NKB>
-__global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                            const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
-                                                            const bf16_t* __restrict__ zero, int T, int heads, int ldq, int ldk, int Tpad,
+__global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __restrict__ Q, const h16_t* __restrict__ K,
+                                                            const h16_t* __restrict__ Vt, h16_t* __restrict__ O,
+                                                            const h16_t* __restrict__ zero, int T, int heads, int ldq, int ldk, int Tpad,
                                                             int ldo) {
     constexpr int KEYS = 32 * NKB, KBYTES = KEYS * 128, NH = NKB / 2;  // NH 64-key halves, each with its own [64 d][64 keys] V^T tile
     constexpr int STAGE = 2 * KBYTES;  // K tile + V^T tiles
@@ -35,19 +35,19 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t* __re
     const int q0 = blockIdx.x * 128 + wave * 32;
     const int l31 = lane & 31, hh = lane >> 5;
 
-    const bf16_t* Qb = Q + (long long)b * T * ldq + h * 64;
-    const bf16_t* Kb = K + (long long)b * T * ldk + h * 64;
-    const bf16_t* Vb = Vt + ((long long)b * heads + h) * 64 * Tpad;
+    const h16_t* Qb = Q + (long long)b * T * ldq + h * 64;
+    const h16_t* Kb = K + (long long)b * T * ldk + h * 64;
+    const h16_t* Vb = Vt + ((long long)b * heads + h) * 64 * Tpad;
 
     // Q fragments (B operand of S^T = K Q^T): lane (q = l31, half hh) holds Q[q][16*ks + 8*hh .. +7]
-    bf16x8_t qf[4];
+    h16x8_t qf[4];
     {
         const int q = q0 + l31;
         const bool ok = q < T;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (ok) qf[ks] = *(const bf16x8_t*)(Qb + (long long)q * ldq + ks * 16 + hh * 8);
-            else qf[ks] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) qf[ks] = *(const h16x8_t*)(Qb + (long long)q * ldq + ks * 16 + hh * 8);
+            else qf[ks] = h16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
 
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t* __re
         for (int i = 0; i < NKB; ++i) {  // K rows: 8 * (wave + 4 i) + lane / 8
             const int g = wave + 4 * i;
             const int key = kt * KEYS + g * 8 + (lane >> 3);
-            const bf16_t* src = key < T ? Kb + (long long)key * ldk + chunk * 8 : zero + chunk * 8;
+            const h16_t* src = key < T ? Kb + (long long)key * ldk + chunk * 8 : zero + chunk * 8;
             glds16(src, sb + g * 1024);
         }
 #pragma unroll
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t* __re
             for (int i = 0; i < 2; ++i) {  // V^T rows = head channels d
                 const int r = (wave + 4 * i) * 8 + (lane >> 3);
                 const int k0 = kt * KEYS + hf * 64;
-                const bf16_t* vsrc = k0 < Tpad ? Vb + (long long)r * Tpad + k0 + chunk * 8 : zero + chunk * 8;  // (Tpad % 64 == 0)
+                const h16_t* vsrc = k0 < Tpad ? Vb + (long long)r * Tpad + k0 + chunk * 8 : zero + chunk * 8;  // (Tpad % 64 == 0)
                 glds16(vsrc, sb + KBYTES + hf * 8192 + (wave + 4 * i) * 1024);
             }
     };
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t* __re
             const int row = kb * 32 + l31;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8_t kf = *(const bf16x8_t*)(sb + attn_off128(row, ks * 2 + hh));
-                s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : s_acc[kb], 0, 0, 0);  // C = 0: inline constant
+                const h16x8_t kf = *(const h16x8_t*)(sb + attn_off128(row, ks * 2 + hh));
+                s_acc[kb] = mfma_32x32x16(kf, qf[ks], ks == 0 ? zero16 : s_acc[kb]);  // C = 0: inline constant
             }
         }
         // ---- online softmax over this lane's 32 keys (+ the other half's 32 via lane ^ 32)
@@ -144,19 +144,19 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t* __re
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                union { bf16x8_t v; unsigned u[4]; } pf;
+                union { h16x8_t v; unsigned u[4]; } pf;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16x2(s_acc[kb][8 * j + 2 * e], s_acc[kb][8 * j + 2 * e + 1]);
+                for (int e = 0; e < 4; ++e) pf.u[e] = pack_h16x2_ns(s_acc[kb][8 * j + 2 * e], s_acc[kb][8 * j + 2 * e + 1]);  // probabilities: in [0, 1]
                 const int ko = (kb & 1) * 32 + 16 * j + 4 * hh;  // key offset inside the 64-key half (multiple of 4)
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
                     const int row = d * 32 + l31;
                     const char* vr = sb + KBYTES + (kb >> 1) * 8192 + row * 128;
                     const int sw = (row >> 1) & 7;
-                    union { bf16x8_t v; uint2 h2[2]; } vf;
+                    union { h16x8_t v; uint2 h2[2]; } vf;
                     vf.h2[0] = *(const uint2*)(vr + ((((ko >> 3)) ^ sw) << 4) + (ko & 7) * 2);
                     vf.h2[1] = *(const uint2*)(vr + ((((ko >> 3) + 1) ^ sw) << 4) + (ko & 7) * 2);
-                    o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o_acc[d], 0, 0, 0);
+                    o_acc[d] = mfma_32x32x16(vf.v, pf.v, o_acc[d]);
                 }
             }
     };
@@ -176,18 +176,18 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t* __re
     const float inv = 1.f / l_run;
     const int q = q0 + l31;
     if (q < T) {
-        bf16_t* ob = O + ((long long)b * T + q) * ldo + h * 64;
+        h16_t* ob = O + ((long long)b * T + q) * ldo + h * 64;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const uint2 pk = pack_bf16x4(o_acc[d][4 * g] * inv, o_acc[d][4 * g + 1] * inv, o_acc[d][4 * g + 2] * inv, o_acc[d][4 * g + 3] * inv);
+                const uint2 pk = pack_h16x4(o_acc[d][4 * g] * inv, o_acc[d][4 * g + 1] * inv, o_acc[d][4 * g + 2] * inv, o_acc[d][4 * g + 3] * inv);
                 *(uint2*)(ob + d * 32 + 8 * g + 4 * hh) = pk;
             }
     }
 }
 
-void launch_flash_attn64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, const bf16_t* zero, int B, int T, int heads,
+void launch_flash_attn64(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t* out, const h16_t* zero, int B, int T, int heads,
                          int ldq, int ldk, int Tpad, int ldo, hipStream_t s) {
     dim3 grid((T + 127) / 128, heads, B);
     // 64-key tiles: 156 VGPRs, three waves per SIMD.  (128-key tiles -- one softmax update, barrier and DMA wait per 128 keys -- need 256
@@ -197,21 +197,21 @@ void launch_flash_attn64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf1
 
 // ---- cross-attention with a tiny constant context -------------------------------------------------------------------
 // One thread per (row, head): q (64 bf16) against L keys/values held in fp32 (folded at load time).
-__global__ __launch_bounds__(256) void cross_attn_small_kernel(const bf16_t* __restrict__ q, const float* __restrict__ kc,
-                                                                const float* __restrict__ vc, bf16_t* __restrict__ out, long long nrh,
+__global__ __launch_bounds__(256) void cross_attn_small_kernel(const h16_t* __restrict__ q, const float* __restrict__ kc,
+                                                                const float* __restrict__ vc, h16_t* __restrict__ out, long long nrh,
                                                                 int C, int heads, int L) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= nrh) return;
     const long long row = idx / heads;
     const int h = (int)(idx - row * heads);
     float qv[64];
-    const bf16_t* qp = q + row * C + h * 64;
+    const h16_t* qp = q + row * C + h * 64;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const uint4 raw = *(const uint4*)(qp + i * 8);
         const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { qv[i * 8 + 2 * k] = bflo(w[k]); qv[i * 8 + 2 * k + 1] = bfhi(w[k]); }
+        for (int k = 0; k < 4; ++k) { qv[i * 8 + 2 * k] = h16_lo(w[k]); qv[i * 8 + 2 * k + 1] = h16_hi(w[k]); }
     }
     float o[64];
 #pragma unroll
@@ -232,30 +232,30 @@ __global__ __launch_bounds__(256) void cross_attn_small_kernel(const bf16_t* __r
         for (int d = 0; d < 64; ++d) o[d] = o[d] * a + pj * vp[d];
     }
     const float inv = 1.f / l;
-    bf16_t* op = out + row * C + h * 64;
+    h16_t* op = out + row * C + h * 64;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         uint4 r;
-        r.x = pack_bf16x2(o[i * 8] * inv, o[i * 8 + 1] * inv);
-        r.y = pack_bf16x2(o[i * 8 + 2] * inv, o[i * 8 + 3] * inv);
-        r.z = pack_bf16x2(o[i * 8 + 4] * inv, o[i * 8 + 5] * inv);
-        r.w = pack_bf16x2(o[i * 8 + 6] * inv, o[i * 8 + 7] * inv);
+        r.x = pack_h16x2(o[i * 8] * inv, o[i * 8 + 1] * inv);
+        r.y = pack_h16x2(o[i * 8 + 2] * inv, o[i * 8 + 3] * inv);
+        r.z = pack_h16x2(o[i * 8 + 4] * inv, o[i * 8 + 5] * inv);
+        r.w = pack_h16x2(o[i * 8 + 6] * inv, o[i * 8 + 7] * inv);
         *(uint4*)(op + i * 8) = r;
     }
 }
 
-void launch_cross_attn_small(const bf16_t* q, const float* kc, const float* vc, bf16_t* out, int rows, int C, int L, hipStream_t s) {
+void launch_cross_attn_small(const h16_t* q, const float* kc, const float* vc, h16_t* out, int rows, int C, int L, hipStream_t s) {
     const int heads = C / 64;
     const long long nrh = (long long)rows * heads;
     hipLaunchKernelGGL(cross_attn_small_kernel, dim3((unsigned)((nrh + 255) / 256)), dim3(256), 0, s, q, kc, vc, out, nrh, C, heads, L);
 }
 
 // ---- row softmax (fp32 logits -> bf16 probabilities), one workgroup per row ----------------------------------------
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int T, int ld, float scale) {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ in, h16_t* __restrict__ out, int T, int ld, float scale) {
     __shared__ float red[8];
     const long long row = blockIdx.x;
     const float* x = in + row * ld;
-    bf16_t* y = out + row * ld;
+    h16_t* y = out + row * ld;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float sc = scale * 1.44269504088896340736f;
     float mx = -1e30f;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     if (lane == 0) red[4 + wv] = sum;
     __syncthreads();
     const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
-    for (int i = tid; i < ld; i += 256) y[i] = i < T ? f2bf(exp2f(x[i] * sc - mx) * inv) : (bf16_t)0;
+    for (int i = tid; i < ld; i += 256) y[i] = i < T ? f_to_h16(exp2f(x[i] * sc - mx) * inv) : (h16_t)0;
 }
 
 // The same with the row held in registers (ld <= 1024 * NV floats, ld % 4 == 0): ONE 16-byte-per-lane read pass instead of three
@@ -284,7 +284,7 @@ GP_DEV float4 load4(const _Float16* p, int i) {
     return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
 }
 template <int NV, typename TIN>
-__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const TIN* __restrict__ in, bf16_t* __restrict__ out, int T, int ld, float scale) {
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const TIN* __restrict__ in, h16_t* __restrict__ out, int T, int ld, float scale) {
     __shared__ float red[8];
     const long long row = blockIdx.x;
     const TIN* x = in + row * ld;
@@ -328,11 +328,11 @@ __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const TIN* __rest
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int i = k * 256 + tid;
-        if (i < nvec) y[i] = pack_bf16x4(v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv);  // masked tail: exp2(-huge) = 0
+        if (i < nvec) y[i] = pack_h16x4(v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv);  // masked tail: exp2(-huge) = 0
     }
 }
 
-void launch_softmax_rows(const float* in, bf16_t* out, int rows, int T, int ld, float scale, hipStream_t s) {
+void launch_softmax_rows(const float* in, h16_t* out, int rows, int T, int ld, float scale, hipStream_t s) {
     if ((ld & 3) == 0 && scale > 0.f && ld <= 16384) {
         if (ld <= 4096) hipLaunchKernelGGL((softmax_rows_reg_kernel<4, float>), dim3(rows), dim3(256), 0, s, in, out, T, ld, scale);
         else if (ld <= 9216) hipLaunchKernelGGL((softmax_rows_reg_kernel<9, float>), dim3(rows), dim3(256), 0, s, in, out, T, ld, scale);
@@ -344,7 +344,7 @@ void launch_softmax_rows(const float* in, bf16_t* out, int rows, int T, int ld, 
 
 // fp16 logits (written by the score GEMM with out_fp32 == 2): same kernel, half the read traffic; ld % 4 == 0, ld <= 16384
 bool softmax_rows_f16_supported(int ld) { return (ld & 3) == 0 && ld <= 16384; }
-void launch_softmax_rows_f16(const void* in, bf16_t* out, int rows, int T, int ld, float scale, hipStream_t s) {
+void launch_softmax_rows_f16(const void* in, h16_t* out, int rows, int T, int ld, float scale, hipStream_t s) {
     const _Float16* x = (const _Float16*)in;
     if (ld <= 4096) hipLaunchKernelGGL((softmax_rows_reg_kernel<4, _Float16>), dim3(rows), dim3(256), 0, s, x, out, T, ld, scale);
     else if (ld <= 9216) hipLaunchKernelGGL((softmax_rows_reg_kernel<9, _Float16>), dim3(rows), dim3(256), 0, s, x, out, T, ld, scale);

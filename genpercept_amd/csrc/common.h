@@ -3,30 +3,71 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef unsigned short bf16_t;  // raw bf16 bits in HBM
-typedef short bf16x8_t __attribute__((ext_vector_type(8)));   // MFMA A/B fragment (8 bf16 = 4 VGPR)
+// The 16-bit element of activations and weights in HBM / LDS and of the MFMA operands: bf16 in the default build
+// (libgenpercept_hip.so: 8 significant bits, fp32 range), IEEE fp16 in the GP_F16 build (libgenpercept_hip_f16.so: 11 significant bits,
+// range 65504 -- the reference's own half precision, run.py --half_precision).  v_mfma_f32_16x16x32_{bf16,f16} run at the same rate and
+// use the same fragment layouts; accumulation, statistics, softmax and every epilogue computation are fp32 in both builds.  Everything
+// format-specific lives in this block.
+#ifndef GP_F16
+#define GP_F16 0
+#endif
+typedef unsigned short h16_t;                                 // raw element bits
+typedef short h16x8_t __attribute__((ext_vector_type(8)));    // MFMA A/B fragment (8 elements = 4 VGPR)
 typedef float f32x4_t __attribute__((ext_vector_type(4)));    // 16x16 MFMA accumulator
 typedef float f32x16_t __attribute__((ext_vector_type(16)));  // 32x32 MFMA accumulator
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2n_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x4n_t __attribute__((ext_vector_type(4)));
 
 #define GP_DEV __device__ __forceinline__
 
-GP_DEV float bf2f(bf16_t x) { return __uint_as_float(((unsigned)x) << 16); }
-GP_DEV float bflo(unsigned u) { return __uint_as_float(u << 16); }          // low bf16 of a packed pair
-GP_DEV float bfhi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }  // high bf16 of a packed pair
-
-// fp32 -> bf16 round-to-nearest-even via v_cvt_pk_bf16_f32
-GP_DEV unsigned pack_bf16x2(float lo, float hi) {
+#if GP_F16
+typedef _Float16 f16x2n_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4n_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8n_t __attribute__((ext_vector_type(8)));
+GP_DEV float h16_to_f(h16_t x) { return (float)__builtin_bit_cast(_Float16, x); }
+GP_DEV float h16_lo(unsigned u) { return (float)__builtin_bit_cast(f16x2n_t, u)[0]; }  // low element of a packed pair
+GP_DEV float h16_hi(unsigned u) { return (float)__builtin_bit_cast(f16x2n_t, u)[1]; }  // high element of a packed pair
+GP_DEV float h16_sat(float x) { return __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }  // fp16 has no headroom: saturate, never inf
+// fp32 -> fp16, round-to-nearest-even, saturating (pack_*_ns: for values known to be in range -- probabilities, normalised inputs)
+GP_DEV unsigned pack_h16x2_ns(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2n_t));
+}
+GP_DEV unsigned pack_h16x2(float lo, float hi) { return pack_h16x2_ns(h16_sat(lo), h16_sat(hi)); }
+GP_DEV uint2 pack_h16x4(float a, float b, float c, float d) {
+    f32x4_t v = {h16_sat(a), h16_sat(b), h16_sat(c), h16_sat(d)};
+    return __builtin_bit_cast(uint2, __builtin_convertvector(v, f16x4n_t));
+}
+GP_DEV f32x4_t mfma_16x16x32(h16x8_t a, h16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8n_t, a), __builtin_bit_cast(f16x8n_t, b), c, 0, 0, 0);
+}
+GP_DEV f32x16_t mfma_32x32x16(h16x8_t a, h16x8_t b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8n_t, a), __builtin_bit_cast(f16x8n_t, b), c, 0, 0, 0);
+}
+#else
+typedef __bf16 bf16x2n_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4n_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8n_t __attribute__((ext_vector_type(8)));
+GP_DEV float h16_to_f(h16_t x) { return __uint_as_float(((unsigned)x) << 16); }
+GP_DEV float h16_lo(unsigned u) { return __uint_as_float(u << 16); }          // low element of a packed pair
+GP_DEV float h16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }  // high element of a packed pair
+// fp32 -> bf16 round-to-nearest-even via v_cvt_pk_bf16_f32 (bf16 has the fp32 range: nothing to saturate)
+GP_DEV unsigned pack_h16x2(float lo, float hi) {
     f32x2_t v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2n_t));
 }
-GP_DEV uint2 pack_bf16x4(float a, float b, float c, float d) {
+GP_DEV unsigned pack_h16x2_ns(float lo, float hi) { return pack_h16x2(lo, hi); }
+GP_DEV uint2 pack_h16x4(float a, float b, float c, float d) {
     f32x4_t v = {a, b, c, d};
     return __builtin_bit_cast(uint2, __builtin_convertvector(v, bf16x4n_t));
 }
-GP_DEV bf16_t f2bf(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
+GP_DEV f32x4_t mfma_16x16x32(h16x8_t a, h16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8n_t, a), __builtin_bit_cast(bf16x8n_t, b), c, 0, 0, 0);
+}
+GP_DEV f32x16_t mfma_32x32x16(h16x8_t a, h16x8_t b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8n_t, a), __builtin_bit_cast(bf16x8n_t, b), c, 0, 0, 0);
+}
+#endif
+GP_DEV h16_t f_to_h16(float f) { return (h16_t)(pack_h16x2(f, 0.f) & 0xffffu); }
 
 GP_DEV float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }  // v_exp + v_rcp (1 ulp), no IEEE division sequence
 GP_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
@@ -64,10 +105,10 @@ struct IC { static constexpr int value = V; };
 // LDS accesses through INTEGER byte addresses: (a) a constant added to the address becomes the instruction's immediate offset,
 // (b) hipcc does not treat them as possibly aliasing an LDS-DMA in flight (accesses it can trace to the `extern __shared__` array
 // make it wait for vmcnt(0) first).  Ordering against the DMA ring is therefore entirely the kernel's business.
-typedef const __attribute__((address_space(3))) bf16x8_t* lds_frag_ptr;
+typedef const __attribute__((address_space(3))) h16x8_t* lds_frag_ptr;
 typedef __attribute__((address_space(3))) f32x4_t* lds_f4_ptr;
 typedef __attribute__((address_space(3))) float* lds_f_ptr;
-GP_DEV bf16x8_t lds_frag(unsigned base, int imm) { return *(lds_frag_ptr)(base + (unsigned)imm); }
+GP_DEV h16x8_t lds_frag(unsigned base, int imm) { return *(lds_frag_ptr)(base + (unsigned)imm); }
 
 // one group of the scheduler's instruction pattern (masks: 0x002 VALU, 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x400 transcendental)
 template <int MASK, int N>

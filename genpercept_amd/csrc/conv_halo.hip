@@ -89,7 +89,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const IGemmParams p)
 
     // ---- DMA sources -----------------------------------------------------------------------------------------------------------
     const int sy0 = UPS ? ty * 8 - 1 : ty * 16 - 1, sx0 = UPS ? tx * 8 - 1 : tx * 16 - 1;
-    const bf16_t* h_ptr[A_IT];
+    const h16_t* h_ptr[A_IT];
     unsigned h_ok = 0;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -101,10 +101,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const IGemmParams p)
         h_ptr[i] = p.in + (((long long)b * Hi + iy) * Wi + ix) * Cin + chunk * 8;
         if (ok) h_ok |= 1u << i;
     }
-    const bf16_t* zsrc_a = p.zero;
+    const h16_t* zsrc_a = p.zero;
     const int chunk_w = (lane & 7) ^ (((lane >> 4) & 1) | ((wave & 1) << 1) | (((wave >> 1) & 1) << 2));
     // weight rows n0 .. n0+127 always exist (launch_conv_halo checks n_rows); wq[i] walks the (chunk, tap) tiles in issue order
-    const bf16_t* wq[B_IT];
+    const h16_t* wq[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) wq[i] = p.wt + (long long)(n0 + (wave + NW * i) * 8 + (lane >> 3)) * p.ldw + chunk_w * 8;
     const int w_step = Cin, w_wrap = 64 - 8 * Cin;  // elements: next tap / first tap of the next chunk
@@ -144,13 +144,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const IGemmParams p)
             : "=&v"(raw), "=&v"(s0), "=&v"(s1), "=&v"(h0), "=&v"(h1)
             : "v"(a_item), "v"(a_sc), "v"(a_sh)
             : "memory");
-        float v[8] = {bflo(raw.x) * s0.x + h0.x, bfhi(raw.x) * s0.y + h0.y, bflo(raw.y) * s0.z + h0.z, bfhi(raw.y) * s0.w + h0.w,
-                      bflo(raw.z) * s1.x + h1.x, bfhi(raw.z) * s1.y + h1.y, bflo(raw.w) * s1.z + h1.z, bfhi(raw.w) * s1.w + h1.w};
+        float v[8] = {h16_lo(raw.x) * s0.x + h0.x, h16_hi(raw.x) * s0.y + h0.y, h16_lo(raw.y) * s0.z + h0.z, h16_hi(raw.y) * s0.w + h0.w,
+                      h16_lo(raw.z) * s1.x + h1.x, h16_hi(raw.z) * s1.y + h1.y, h16_lo(raw.w) * s1.z + h1.z, h16_hi(raw.w) * s1.w + h1.w};
         if (p.in_silu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
         }
-        const u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        const u32x4_t ov = {pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]), pack_h16x2(v[6], v[7])};
         asm volatile("ds_write_b128 %0, %1" ::"v"(a_item), "v"(ov) : "memory");
     };
 
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const IGemmParams p)
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int g = wave + NW * i;
-            const bf16_t* src = ((h_ok >> i) & 1u) ? h_ptr[i] + (cc << 6) : zsrc_a;
+            const h16_t* src = ((h_ok >> i) & 1u) ? h_ptr[i] + (cc << 6) : zsrc_a;
             glds16(src, g < G::GROUPS ? dst + g * 1024 : dump);
         }
     };
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const IGemmParams p)
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // ---- fragment base addresses (LDS byte offsets) ----------------------------------------------------------------------------------
-    struct Half { bf16x8_t w[FN], x[FM]; };  // fragments of one k-half (32 channels) of one step
+    struct Half { h16x8_t w[FN], x[FM]; };  // fragments of one k-half (32 channels) of one step
     unsigned xb[3][2], wb[2];
     {
         const int xr_w = ((a15 >> 1) & 1) | (((a15 >> 2) & 1) << 1) | (((a15 >> 3) & 1) << 2);
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const IGemmParams p)
 #pragma unroll
         for (int i = 0; i < FN; ++i)
 #pragma unroll
-            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[i], f.x[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FM; ++j) acc[i][j] = mfma_16x16x32(f.w[i], f.x[j], acc[i][j]);
     };
     // 16 MFMAs interleaved with 8 LDS reads (2 : 1), pinned
     auto interleave = [&]() {
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     int sp_cur = jw / tiles_n;                       // spatial tile being computed
     const int n0 = nt * BN;
     const int cpt = Cin >> 6;
-    const bf16_t* const in_b = p.in + (long long)b * Hi * Wi * Cin;
+    const h16_t* const in_b = p.in + (long long)b * Hi * Wi * Cin;
 
     // ---- fetch state: the tile whose halo is being staged / normalised (one chunk ahead of the compute) ----------------------------
     constexpr int T_IT = (HROWS * 8 + 511) / 512;
@@ -410,9 +410,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
             }
         }
     };
-    const bf16_t* zsrc_a = p.zero;
+    const h16_t* zsrc_a = p.zero;
     const int chunk_w = (lane & 7) ^ (((lane >> 4) & 1) | ((wave & 1) << 1) | (((wave >> 1) & 1) << 2));
-    const bf16_t* wq[B_IT];
+    const h16_t* wq[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) wq[i] = p.wt + (long long)(n0 + (wave + NW * i) * 8 + (lane >> 3)) * p.ldw + chunk_w * 8;
     const int w_step = Cin, w_wrap = 64 - 8 * Cin, w_tile_wrap = -8 * Cin - (cpt - 1) * 64;  // next tap / next chunk / first tile again
@@ -455,10 +455,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     // arithmetic in two halves so that it can sit under BOTH MFMA batches of the step (one VALU pipe per SIMD, two waves on it: with
     // all of it under the second batch that batch was VALU-bound while the first one had idle VALU slots)
     auto tp_mid = [&](TPart& t) __attribute__((always_inline)) {
-        t.v[0] = bflo(t.raw.x) * t.s0.x + t.h0.x; t.v[1] = bfhi(t.raw.x) * t.s0.y + t.h0.y;
-        t.v[2] = bflo(t.raw.y) * t.s0.z + t.h0.z; t.v[3] = bfhi(t.raw.y) * t.s0.w + t.h0.w;
-        t.v[4] = bflo(t.raw.z) * t.s1.x + t.h1.x; t.v[5] = bfhi(t.raw.z) * t.s1.y + t.h1.y;
-        t.v[6] = bflo(t.raw.w) * t.s1.z + t.h1.z; t.v[7] = bfhi(t.raw.w) * t.s1.w + t.h1.w;
+        t.v[0] = h16_lo(t.raw.x) * t.s0.x + t.h0.x; t.v[1] = h16_hi(t.raw.x) * t.s0.y + t.h0.y;
+        t.v[2] = h16_lo(t.raw.y) * t.s0.z + t.h0.z; t.v[3] = h16_hi(t.raw.y) * t.s0.w + t.h0.w;
+        t.v[4] = h16_lo(t.raw.z) * t.s1.x + t.h1.x; t.v[5] = h16_hi(t.raw.z) * t.s1.y + t.h1.y;
+        t.v[6] = h16_lo(t.raw.w) * t.s1.z + t.h1.z; t.v[7] = h16_hi(t.raw.w) * t.s1.w + t.h1.w;
         if (FUSED == 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) t.v[e] = silu_f(t.v[e]);
@@ -469,7 +469,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
 #pragma unroll
             for (int e = 4; e < 8; ++e) t.v[e] = silu_f(t.v[e]);
         }
-        u32x4_t ov = {pack_bf16x2(t.v[0], t.v[1]), pack_bf16x2(t.v[2], t.v[3]), pack_bf16x2(t.v[4], t.v[5]), pack_bf16x2(t.v[6], t.v[7])};
+        // (normalised activations: |x| stays within a few tens, no saturation needed in the fp16 build)
+        u32x4_t ov = {pack_h16x2_ns(t.v[0], t.v[1]), pack_h16x2_ns(t.v[2], t.v[3]), pack_h16x2_ns(t.v[4], t.v[5]), pack_h16x2_ns(t.v[6], t.v[7])};
         ov = t.ok ? ov : t.raw;
         *(lds_u4_ptr)t.addr = ov;
     };
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int g = wave + NW * i;
-            const bf16_t* src = ((h_ok >> i) & 1u) ? in_b + (h_off[i] + (cc << 6)) : zsrc_a;
+            const h16_t* src = ((h_ok >> i) & 1u) ? in_b + (h_off[i] + (cc << 6)) : zsrc_a;
             if (!(ABL & 8)) glds16(src, g < G::GROUPS ? dst + g * 1024 : dump);
         }
     };
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    struct Half { bf16x8_t w[FN], x[FM]; };
+    struct Half { h16x8_t w[FN], x[FM]; };
     unsigned xb[3][2], wb[2];
     {
         const int xr_w = ((a15 >> 1) & 1) | (((a15 >> 2) & 1) << 1) | (((a15 >> 3) & 1) << 2);
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
 #pragma unroll
         for (int i = 0; i < FN; ++i)
 #pragma unroll
-            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[i], f.x[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FM; ++j) acc[i][j] = mfma_16x16x32(f.w[i], f.x[j], acc[i][j]);
     };
     auto interleave = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         const int col = n0 + wn * TN + 8 * sl8;
         const bool col_ok = col < p.n_store;
         const bool tail = col + 7 >= n_out;                // slot reaches into the zero-padded channels
-        bf16_t* outp = (bf16_t*)p.out;
+        h16_t* outp = (h16_t*)p.out;
         int m2[FM][2];
         uint4 rv[FM][2];
 #pragma unroll
@@ -609,8 +610,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
                     float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                     if (RES) {
                         const uint4 r4 = rv[j][h];
-                        v[0] += bflo(r4.x); v[1] += bfhi(r4.x); v[2] += bflo(r4.y); v[3] += bfhi(r4.y);
-                        v[4] += bflo(r4.z); v[5] += bfhi(r4.z); v[6] += bflo(r4.w); v[7] += bfhi(r4.w);
+                        v[0] += h16_lo(r4.x); v[1] += h16_hi(r4.x); v[2] += h16_lo(r4.y); v[3] += h16_hi(r4.y);
+                        v[4] += h16_lo(r4.z); v[5] += h16_hi(r4.z); v[6] += h16_lo(r4.w); v[7] += h16_hi(r4.w);
                     }
                     if (ACT) {
 #pragma unroll
@@ -625,11 +626,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
                             if (col + e >= n_out) v[e] = 0.f;
                     }
                     uint4 pk;
-                    pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+                    pk.x = pack_h16x2(v[0], v[1]); pk.y = pack_h16x2(v[2], v[3]); pk.z = pack_h16x2(v[4], v[5]); pk.w = pack_h16x2(v[6], v[7]);
                     if (!(ABL & 4)) *(uint4*)(outp + m * p.ldo + col) = pk;
                     else asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
                     if (STATS) {
-                        const float r[8] = {bflo(pk.x), bfhi(pk.x), bflo(pk.y), bfhi(pk.y), bflo(pk.z), bfhi(pk.z), bflo(pk.w), bfhi(pk.w)};
+                        const float r[8] = {h16_lo(pk.x), h16_hi(pk.x), h16_lo(pk.y), h16_hi(pk.y), h16_lo(pk.z), h16_hi(pk.z), h16_lo(pk.w), h16_hi(pk.w)};
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { st_s[e] += r[e]; st_q[e] += r[e] * r[e]; }
                     }

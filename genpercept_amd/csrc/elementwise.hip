@@ -12,7 +12,7 @@ static inline unsigned grid_for(long long n, int per_block = 256) {
 
 // RGB [B][3][H][W] (uint8 0..255, or float already normalised to [-1,1]) -> NHWC bf16 with Cpad channels (3 real + zeros).
 // u8 path computes x/255*2-1 in fp32 (genpercept_pipeline.py:245).
-__global__ __launch_bounds__(256) void rgb_prologue_kernel(const void* __restrict__ rgb, int is_u8, bf16_t* __restrict__ out, int B,
+__global__ __launch_bounds__(256) void rgb_prologue_kernel(const void* __restrict__ rgb, int is_u8, h16_t* __restrict__ out, int B,
                                                             long long HW, int Cpad) {
     const long long n = (long long)B * HW;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -23,24 +23,24 @@ __global__ __launch_bounds__(256) void rgb_prologue_kernel(const void* __restric
             const long long src = (b * 3 + c) * HW + p;
             v[c] = is_u8 ? ((float)((const unsigned char*)rgb)[src] / 255.0f * 2.0f - 1.0f) : ((const float*)rgb)[src];
         }
-        bf16_t* o = out + i * Cpad;
+        h16_t* o = out + i * Cpad;
         uint4 first;
-        first.x = pack_bf16x2(v[0], v[1]);
-        first.y = pack_bf16x2(v[2], 0.f);
+        first.x = pack_h16x2(v[0], v[1]);
+        first.y = pack_h16x2(v[2], 0.f);
         first.z = first.w = 0u;
         *(uint4*)o = first;
         const uint4 zz = make_uint4(0, 0, 0, 0);
         for (int c = 8; c < Cpad; c += 8) *(uint4*)(o + c) = zz;
     }
 }
-void launch_rgb_prologue(const void* rgb, int is_u8, bf16_t* out, int B, int H, int W, int Cpad, hipStream_t s) {
+void launch_rgb_prologue(const void* rgb, int is_u8, h16_t* out, int B, int H, int W, int Cpad, hipStream_t s) {
     const long long n = (long long)B * H * W;
     hipLaunchKernelGGL(rgb_prologue_kernel, dim3(grid_for(n)), dim3(256), 0, s, rgb, is_u8, out, B, (long long)H * W, Cpad);
 }
 
 // channel concat of two NHWC tensors (UNet skip connections: [hidden, skip])
-__global__ __launch_bounds__(256) void concat_kernel(const bf16_t* __restrict__ a, int Ca, const bf16_t* __restrict__ b, int Cb,
-                                                      bf16_t* __restrict__ out, long long pixels) {
+__global__ __launch_bounds__(256) void concat_kernel(const h16_t* __restrict__ a, int Ca, const h16_t* __restrict__ b, int Cb,
+                                                      h16_t* __restrict__ out, long long pixels) {
     const int va = Ca >> 3, vb = Cb >> 3, vt = va + vb;
     const long long n = pixels * vt;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -50,23 +50,23 @@ __global__ __launch_bounds__(256) void concat_kernel(const bf16_t* __restrict__ 
         *(uint4*)(out + i * 8) = x;
     }
 }
-void launch_concat(const bf16_t* a, int Ca, const bf16_t* b, int Cb, bf16_t* out, long long pixels, hipStream_t s) {
+void launch_concat(const h16_t* a, int Ca, const h16_t* b, int Cb, h16_t* out, long long pixels, hipStream_t s) {
     hipLaunchKernelGGL(concat_kernel, dim3(grid_for(pixels * ((Ca + Cb) / 8))), dim3(256), 0, s, a, Ca, b, Cb, out, pixels);
 }
 
 // The same concat, also leaving the GroupNorm statistics of the tensor it writes: per (bm consecutive pixels, channel) {sum, sum of
 // squares} in the layout of the conv epilogues (mode 0 of gn_finalize_tiles_kernel), so the resnet that consumes the concatenation
 // skips its statistics read pass.  A thread owns one 8-channel slot for the bm pixels of its tile: no cross-thread reduction.
-__global__ __launch_bounds__(256) void concat_stats_kernel(const bf16_t* __restrict__ a, int Ca, const bf16_t* __restrict__ b, int Cb,
-                                                            bf16_t* __restrict__ out, int bm, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void concat_stats_kernel(const h16_t* __restrict__ a, int Ca, const h16_t* __restrict__ b, int Cb,
+                                                            h16_t* __restrict__ out, int bm, float* __restrict__ part) {
     const int va = Ca >> 3, vt = (Ca + Cb) >> 3, C = Ca + Cb;
     const int v = blockIdx.y * 256 + threadIdx.x;
     if (v >= vt) return;
     const long long p0 = (long long)blockIdx.x * bm;
     const bool from_a = v < va;
-    const bf16_t* src = from_a ? a + p0 * Ca + v * 8 : b + p0 * Cb + (v - va) * 8;
+    const h16_t* src = from_a ? a + p0 * Ca + v * 8 : b + p0 * Cb + (v - va) * 8;
     const int ld = from_a ? Ca : Cb;
-    bf16_t* dst = out + p0 * C + v * 8;
+    h16_t* dst = out + p0 * C + v * 8;
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void concat_stats_kernel(const bf16_t* __restr
     for (int r = 0; r < bm; ++r) {
         const uint4 x = *(const uint4*)(src + (long long)r * ld);
         *(uint4*)(dst + (long long)r * C) = x;
-        const float f[8] = {bflo(x.x), bfhi(x.x), bflo(x.y), bfhi(x.y), bflo(x.z), bfhi(x.z), bflo(x.w), bfhi(x.w)};
+        const float f[8] = {h16_lo(x.x), h16_hi(x.x), h16_lo(x.y), h16_hi(x.y), h16_lo(x.z), h16_hi(x.z), h16_lo(x.w), h16_hi(x.w)};
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
     }
@@ -87,48 +87,48 @@ int concat_stats_bm(long long hw) {
         if (hw % bm == 0) return bm;
     return 0;
 }
-void launch_concat_stats(const bf16_t* a, int Ca, const bf16_t* b, int Cb, bf16_t* out, long long pixels, int bm, float* part, hipStream_t s) {
+void launch_concat_stats(const h16_t* a, int Ca, const h16_t* b, int Cb, h16_t* out, long long pixels, int bm, float* part, hipStream_t s) {
     hipLaunchKernelGGL(concat_stats_kernel, dim3((unsigned)(pixels / bm), ((Ca + Cb) / 8 + 255) / 256), dim3(256), 0, s, a, Ca, b, Cb, out, bm, part);
 }
 
 // fp32 NCHW -> bf16 NHWC with zero-padded channels (stage-level entry points: latents / features handed in by the host)
-__global__ __launch_bounds__(256) void nchw_f32_to_nhwc_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int B, int C,
+__global__ __launch_bounds__(256) void nchw_f32_to_nhwc_kernel(const float* __restrict__ in, h16_t* __restrict__ out, int B, int C,
                                                                 long long HW, int Cpad) {
     const long long n = (long long)B * HW * Cpad;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % Cpad);
         const long long bp = i / Cpad, b = bp / HW, p = bp - b * HW;
-        out[i] = c < C ? f2bf(in[(b * C + c) * HW + p]) : (bf16_t)0;
+        out[i] = c < C ? f_to_h16(in[(b * C + c) * HW + p]) : (h16_t)0;
     }
 }
-void launch_nchw_f32_to_nhwc(const float* in, bf16_t* out, int B, int C, int H, int W, int Cpad, hipStream_t s) {
+void launch_nchw_f32_to_nhwc(const float* in, h16_t* out, int B, int C, int H, int W, int Cpad, hipStream_t s) {
     hipLaunchKernelGGL(nchw_f32_to_nhwc_kernel, dim3(grid_for((long long)B * H * W * Cpad)), dim3(256), 0, s, in, out, B, C,
                        (long long)H * W, Cpad);
 }
 
 // bf16 NHWC (row stride ld) -> fp32 NCHW
-__global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, int B, int C,
+__global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const h16_t* __restrict__ in, float* __restrict__ out, int B, int C,
                                                                 long long HW, int ld) {
     const long long n = (long long)B * C * HW;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const long long p = i % HW, bc = i / HW;
         const int c = (int)(bc % C);
         const long long b = bc / C;
-        out[i] = bf2f(in[(b * HW + p) * ld + c]);
+        out[i] = h16_to_f(in[(b * HW + p) * ld + c]);
     }
 }
-void launch_nhwc_to_nchw_f32(const bf16_t* in, float* out, int B, int C, int H, int W, int ld, hipStream_t s) {
+void launch_nhwc_to_nchw_f32(const h16_t* in, float* out, int B, int C, int H, int W, int ld, hipStream_t s) {
     hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(grid_for((long long)B * C * H * W)), dim3(256), 0, s, in, out, B, C, (long long)H * W, ld);
 }
 
 // decoder output NHWC (3 real channels, row stride ld) -> fp32 NCHW [B][1|3][H][W]:
 // optional mean over the 3 channels, then (unless raw) clip(-1,1), (x+1)/2   (genpercept_pipeline.py:523-525,470-472)
-__global__ __launch_bounds__(256) void decode_epilogue_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, int B, long long HW,
+__global__ __launch_bounds__(256) void decode_epilogue_kernel(const h16_t* __restrict__ in, float* __restrict__ out, int B, long long HW,
                                                                int ld, int mean3, int raw) {
     const long long n = (long long)B * HW;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const uint2 rw = *(const uint2*)(in + i * ld);
-        float c[3] = {bflo(rw.x), bfhi(rw.x), bflo(rw.y)};
+        float c[3] = {h16_lo(rw.x), h16_hi(rw.x), h16_lo(rw.y)};
         const long long b = i / HW, p = i - b * HW;
         if (mean3) {
             float v = (c[0] + c[1] + c[2]) / 3.0f;
@@ -144,46 +144,46 @@ __global__ __launch_bounds__(256) void decode_epilogue_kernel(const bf16_t* __re
         }
     }
 }
-void launch_decode_epilogue(const bf16_t* in, float* out, int B, int H, int W, int ld, int mean3, int raw, hipStream_t s) {
+void launch_decode_epilogue(const h16_t* in, float* out, int B, int H, int W, int ld, int mean3, int raw, hipStream_t s) {
     hipLaunchKernelGGL(decode_epilogue_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, s, in, out, B, (long long)H * W, ld, mean3, raw);
 }
 
 // out[p][0..ldo) = {in[p][0..C) * scale, 0...}
-__global__ __launch_bounds__(256) void scale_pad_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, long long pixels, int C,
+__global__ __launch_bounds__(256) void scale_pad_kernel(const h16_t* __restrict__ in, h16_t* __restrict__ out, long long pixels, int C,
                                                          int ldi, int ldo, float scale) {
     const long long n = pixels * ldo;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const long long p = i / ldo;
         const int c = (int)(i - p * ldo);
-        out[i] = c < C ? f2bf(bf2f(in[p * ldi + c]) * scale) : (bf16_t)0;
+        out[i] = c < C ? f_to_h16(h16_to_f(in[p * ldi + c]) * scale) : (h16_t)0;
     }
 }
-void launch_scale_pad(const bf16_t* in, bf16_t* out, long long pixels, int C, int ldi, int ldo, float scale, hipStream_t s) {
+void launch_scale_pad(const h16_t* in, h16_t* out, long long pixels, int C, int ldi, int ldo, float scale, hipStream_t s) {
     hipLaunchKernelGGL(scale_pad_kernel, dim3(grid_for(pixels * ldo)), dim3(256), 0, s, in, out, pixels, C, ldi, ldo, scale);
 }
 
 // tiny 1x1 conv (Cin, Cout <= 8) on the first Cin channels of a padded NHWC tensor: out = W (in * in_scale) + bias, zero padded
 // to ldo channels.  Used for post_quant_conv (4->4) with in_scale = -1/0.18215 (pred_x0 = -v, then /scaling_factor).
-__global__ __launch_bounds__(256) void pointwise_small_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void pointwise_small_kernel(const h16_t* __restrict__ in, h16_t* __restrict__ out, const float* __restrict__ w,
                                                                const float* __restrict__ bias, long long pixels, int Cin, int Cout, int ldi,
                                                                int ldo, float in_scale) {
     for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (long long)gridDim.x * 256) {
         float x[8], y[8];
-        for (int c = 0; c < Cin; ++c) x[c] = bf2f(in[p * ldi + c]) * in_scale;
+        for (int c = 0; c < Cin; ++c) x[c] = h16_to_f(in[p * ldi + c]) * in_scale;
         for (int o = 0; o < Cout; ++o) {
             float a = bias ? bias[o] : 0.f;
             for (int c = 0; c < Cin; ++c) a += w[o * Cin + c] * x[c];
             y[o] = a;
         }
-        for (int o = 0; o < ldo; ++o) out[p * ldo + o] = o < Cout ? f2bf(y[o]) : (bf16_t)0;
+        for (int o = 0; o < ldo; ++o) out[p * ldo + o] = o < Cout ? f_to_h16(y[o]) : (h16_t)0;
     }
 }
-void launch_pointwise_small(const bf16_t* in, bf16_t* out, const float* w, const float* bias, long long pixels, int Cin, int Cout, int ldi,
+void launch_pointwise_small(const h16_t* in, h16_t* out, const float* w, const float* bias, long long pixels, int Cin, int Cout, int ldi,
                             int ldo, float in_scale, hipStream_t s) {
     hipLaunchKernelGGL(pointwise_small_kernel, dim3(grid_for(pixels)), dim3(256), 0, s, in, out, w, bias, pixels, Cin, Cout, ldi, ldo, in_scale);
 }
 
-__global__ __launch_bounds__(256) void relu_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, long long nvec) {
+__global__ __launch_bounds__(256) void relu_kernel(const h16_t* __restrict__ in, h16_t* __restrict__ out, long long nvec) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
         uint4 x = *(const uint4*)(in + i * 8);
         unsigned* w = (unsigned*)&x;
@@ -195,11 +195,11 @@ __global__ __launch_bounds__(256) void relu_kernel(const bf16_t* __restrict__ in
         *(uint4*)(out + i * 8) = x;
     }
 }
-void launch_relu(const bf16_t* in, bf16_t* out, long long n, hipStream_t s) {
+void launch_relu(const h16_t* in, h16_t* out, long long n, hipStream_t s) {
     hipLaunchKernelGGL(relu_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, in, out, n / 8);
 }
 
-__global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256) void add_kernel(const h16_t* __restrict__ a, const h16_t* __restrict__ b, h16_t* __restrict__ out,
                                                    long long nvec) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
         const uint4 x = *(const uint4*)(a + i * 8), y = *(const uint4*)(b + i * 8);
@@ -207,16 +207,16 @@ __global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, 
         uint4 r;
         unsigned* rw = (unsigned*)&r;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) rw[k] = pack_bf16x2(bflo(xw[k]) + bflo(yw[k]), bfhi(xw[k]) + bfhi(yw[k]));
+        for (int k = 0; k < 4; ++k) rw[k] = pack_h16x2(h16_lo(xw[k]) + h16_lo(yw[k]), h16_hi(xw[k]) + h16_hi(yw[k]));
         *(uint4*)(out + i * 8) = r;
     }
 }
-void launch_add(const bf16_t* a, const bf16_t* b, bf16_t* out, long long n, hipStream_t s) {
+void launch_add(const h16_t* a, const h16_t* b, h16_t* out, long long n, hipStream_t s) {
     hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, a, b, out, n / 8);
 }
 
 // bilinear resize of NHWC bf16, PyTorch semantics (align_corners True: src = dst*(in-1)/(out-1); False: (dst+.5)*in/out-.5, clamped at 0)
-__global__ __launch_bounds__(256) void bilinear_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int B, int Hi, int Wi, int Ho,
+__global__ __launch_bounds__(256) void bilinear_kernel(const h16_t* __restrict__ in, h16_t* __restrict__ out, int B, int Hi, int Wi, int Ho,
                                                         int Wo, int C, int align) {
     const int nvec = C >> 3;
     const long long n = (long long)B * Ho * Wo * nvec;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const bf16_t* __restrict_
         const int y0 = min((int)fy, Hi - 1), x0 = min((int)fx, Wi - 1);
         const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
         const float ly = fy - (float)y0, lx = fx - (float)x0;
-        const bf16_t* base = in + b * Hi * Wi * C + v * 8;
+        const h16_t* base = in + b * Hi * Wi * C + v * 8;
         const uint4 a = *(const uint4*)(base + ((long long)y0 * Wi + x0) * C), bq = *(const uint4*)(base + ((long long)y0 * Wi + x1) * C);
         const uint4 c = *(const uint4*)(base + ((long long)y1 * Wi + x0) * C), d = *(const uint4*)(base + ((long long)y1 * Wi + x1) * C);
         const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {bq.x, bq.y, bq.z, bq.w}, cw[4] = {c.x, c.y, c.z, c.w}, dw[4] = {d.x, d.y, d.z, d.w};
@@ -242,20 +242,20 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const bf16_t* __restrict_
         unsigned* rw = (unsigned*)&r;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float lo = w00 * bflo(aw[k]) + w01 * bflo(bw[k]) + w10 * bflo(cw[k]) + w11 * bflo(dw[k]);
-            const float hi = w00 * bfhi(aw[k]) + w01 * bfhi(bw[k]) + w10 * bfhi(cw[k]) + w11 * bfhi(dw[k]);
-            rw[k] = pack_bf16x2(lo, hi);
+            const float lo = w00 * h16_lo(aw[k]) + w01 * h16_lo(bw[k]) + w10 * h16_lo(cw[k]) + w11 * h16_lo(dw[k]);
+            const float hi = w00 * h16_hi(aw[k]) + w01 * h16_hi(bw[k]) + w10 * h16_hi(cw[k]) + w11 * h16_hi(dw[k]);
+            rw[k] = pack_h16x2(lo, hi);
         }
         *(uint4*)(out + i * 8) = r;
     }
 }
-void launch_bilinear(const bf16_t* in, bf16_t* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, hipStream_t s) {
+void launch_bilinear(const h16_t* in, h16_t* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, hipStream_t s) {
     hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for((long long)B * Ho * Wo * (C / 8))), dim3(256), 0, s, in, out, B, Hi, Wi, Ho, Wo, C,
                        align_corners);
 }
 
 // DPT head tail: out[b][p] = sum_c w[c] * in[p][c] + bias  (input already ReLU'd by the producing conv), fp32 out
-__global__ __launch_bounds__(256) void dpt_final_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w, float bias,
+__global__ __launch_bounds__(256) void dpt_final_kernel(const h16_t* __restrict__ in, const float* __restrict__ w, float bias,
                                                          float* __restrict__ out, long long n, int Cin) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         float a = bias;
@@ -263,12 +263,12 @@ __global__ __launch_bounds__(256) void dpt_final_kernel(const bf16_t* __restrict
             const uint4 x = *(const uint4*)(in + i * Cin + v);
             const unsigned xw[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a += bflo(xw[k]) * w[v + 2 * k] + bfhi(xw[k]) * w[v + 2 * k + 1];
+            for (int k = 0; k < 4; ++k) a += h16_lo(xw[k]) * w[v + 2 * k] + h16_hi(xw[k]) * w[v + 2 * k + 1];
         }
         out[i] = a;
     }
 }
-void launch_dpt_final(const bf16_t* in, const float* w, float bias, float* out, int B, int HW, int Cin, hipStream_t s) {
+void launch_dpt_final(const h16_t* in, const float* w, float bias, float* out, int B, int HW, int Cin, hipStream_t s) {
     const long long n = (long long)B * HW;
     hipLaunchKernelGGL(dpt_final_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, w, bias, out, n, Cin);
 }
@@ -314,12 +314,12 @@ void launch_minmax_norm(float* x, int B, long long n, float* ws, hipStream_t s) 
 // (302 MB written and read back) and a K = 576 conv of which 27/576 was real work; here K = 27 (padded to 32) is ONE
 // v_mfma_f32_16x16x32_bf16 per 16 pixels x 16 channels, the image is read as uint8 and the layer is bound by its 2 B/element output.
 //   workgroup: 4 waves, 16x16 output pixels x 128 channels; halo 18x18x3 normalised to bf16 in LDS ([pixel][4]); k = 3 * tap + c.
-__global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict__ rgb, int is_u8, const bf16_t* __restrict__ w27,
-                                                           const float* __restrict__ bias, bf16_t* __restrict__ out, float* __restrict__ stats,
+__global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict__ rgb, int is_u8, const h16_t* __restrict__ w27,
+                                                           const float* __restrict__ bias, h16_t* __restrict__ out, float* __restrict__ stats,
                                                            int B, int H, int W, int Cout) {
-    __shared__ bf16_t s_h[18 * 18 * 4];
+    __shared__ h16_t s_h[18 * 18 * 4];
     __shared__ float s_red[4 * 128 * 2];
-    __shared__ __attribute__((aligned(16))) bf16_t s_w[128 * 32];  // this slice's weights, [channel][k = 3 tap + c, zero for k >= 27]
+    __shared__ __attribute__((aligned(16))) h16_t s_w[128 * 32];  // this slice's weights, [channel][k = 3 tap + c, zero for k >= 27]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int a = lane & 15, q = lane >> 4;
     const int tiles_x = (W + 15) >> 4, tiles_y = (H + 15) >> 4;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict
             const long long src = ((long long)b * 3 + c) * HW + (long long)iy * W + ix;
             v = is_u8 ? ((float)((const unsigned char*)rgb)[src] / 255.0f * 2.0f - 1.0f) : ((const float*)rgb)[src];
         }
-        s_h[i] = f2bf(v);
+        s_h[i] = f_to_h16(v);
     }
     // weights: compact [Cout][32] matrix (pack_k27_kernel) -> LDS (two 16-byte pieces per thread), then 16 bytes per fragment and lane.
     // (Gathering the 27 taps per lane from the [rows][9][64] conv layout cost more than the whole rest of the kernel: ~32 cache lines
@@ -360,9 +360,9 @@ __global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict
     __syncthreads();
     // weight fragments: MFMA row a of fragment i (pair ip = i / 2) is output channel 32 ip + 8 (a / 4) + 4 (i & 1) + (a & 3), so that a
     // lane ends up with 8 consecutive channels of its pixel; this lane's k = 8 q .. 8 q + 7
-    bf16x8_t wf[8];
+    h16x8_t wf[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) wf[i] = *(const bf16x8_t*)(s_w + (32 * (i >> 1) + 8 * (a >> 2) + 4 * (i & 1) + (a & 3)) * 32 + 8 * q);
+    for (int i = 0; i < 8; ++i) wf[i] = *(const h16x8_t*)(s_w + (32 * (i >> 1) + 8 * (a >> 2) + 4 * (i & 1) + (a & 3)) * 32 + 8 * q);
 
     float st_s[4][8], st_q[4][8];
 #pragma unroll
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int py = 4 * wave + j;
-        bf16x8_t xf;  // B operand: pixel a of row py, k = 8 q + e
+        h16x8_t xf;  // B operand: pixel a of row py, k = 8 q + e
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = 8 * q + e;
@@ -382,19 +382,19 @@ __global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict
         }
         const int oy = ty * 16 + py, ox = tx * 16 + a;
         const bool ok = oy < H && ox < W;
-        bf16_t* o = out + (((long long)b * H + oy) * W + ox) * Cout + n0 + 8 * q;
+        h16_t* o = out + (((long long)b * H + oy) * W + ox) * Cout + n0 + 8 * q;
 #pragma unroll
         for (int ip = 0; ip < 4; ++ip) {
             if (ip >= npair) break;
-            const f32x4_t lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * ip], xf, zero4, 0, 0, 0);
-            const f32x4_t hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * ip + 1], xf, zero4, 0, 0, 0);
+            const f32x4_t lo = mfma_16x16x32(wf[2 * ip], xf, zero4);
+            const f32x4_t hi = mfma_16x16x32(wf[2 * ip + 1], xf, zero4);
             const float v[8] = {lo.x + bv[ip][0], lo.y + bv[ip][1], lo.z + bv[ip][2], lo.w + bv[ip][3],
                                 hi.x + bv[ip][4], hi.y + bv[ip][5], hi.z + bv[ip][6], hi.w + bv[ip][7]};
             uint4 pk;
-            pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+            pk.x = pack_h16x2(v[0], v[1]); pk.y = pack_h16x2(v[2], v[3]); pk.z = pack_h16x2(v[4], v[5]); pk.w = pack_h16x2(v[6], v[7]);
             if (ok) {
                 *(uint4*)(o + 32 * ip) = pk;
-                const float r[8] = {bflo(pk.x), bfhi(pk.x), bflo(pk.y), bfhi(pk.y), bflo(pk.z), bfhi(pk.z), bflo(pk.w), bfhi(pk.w)};
+                const float r[8] = {h16_lo(pk.x), h16_hi(pk.x), h16_lo(pk.y), h16_hi(pk.y), h16_lo(pk.z), h16_hi(pk.z), h16_lo(pk.w), h16_hi(pk.w)};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { st_s[ip][e] += r[e]; st_q[ip][e] += r[e] * r[e]; }
             }
@@ -428,17 +428,17 @@ __global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict
     }
 }
 // compact conv_in weights: [Cout][32] bf16 with k = 3 * tap + c (c < 3), zero for k >= 27, from the packed conv layout [rows][9][64]
-__global__ __launch_bounds__(256) void pack_k27_kernel(const bf16_t* __restrict__ wt, int ldw, int Cout, bf16_t* __restrict__ w27) {
+__global__ __launch_bounds__(256) void pack_k27_kernel(const h16_t* __restrict__ wt, int ldw, int Cout, h16_t* __restrict__ w27) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Cout * 32) return;
     const int ch = i >> 5, k = i & 31;
-    w27[i] = k < 27 ? wt[(long long)ch * ldw + (k / 3) * 64 + (k % 3)] : (bf16_t)0;
+    w27[i] = k < 27 ? wt[(long long)ch * ldw + (k / 3) * 64 + (k % 3)] : (h16_t)0;
 }
-void launch_pack_k27(const bf16_t* wt, int ldw, int Cout, bf16_t* w27, hipStream_t s) {
+void launch_pack_k27(const h16_t* wt, int ldw, int Cout, h16_t* w27, hipStream_t s) {
     hipLaunchKernelGGL(pack_k27_kernel, dim3((Cout * 32 + 255) / 256), dim3(256), 0, s, wt, ldw, Cout, w27);
 }
 // Cout % 32 == 0; w27 = launch_pack_k27 output; stats (optional): [B * tiles][Cout][2], 16x16 tiles (mode 1)
-void launch_rgb_conv_in(const void* rgb, int is_u8, const bf16_t* w27, const float* bias, bf16_t* out, float* stats, int B, int H, int W, int Cout,
+void launch_rgb_conv_in(const void* rgb, int is_u8, const h16_t* w27, const float* bias, h16_t* out, float* stats, int B, int H, int W, int Cout,
                         hipStream_t s) {
     const int tiles = ((W + 15) / 16) * ((H + 15) / 16) * B;
     hipLaunchKernelGGL(rgb_conv_in_kernel, dim3(tiles, (Cout + 127) / 128), dim3(256), 0, s, rgb, is_u8, w27, bias, out, stats, B, H, W, Cout);

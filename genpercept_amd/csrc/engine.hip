@@ -32,12 +32,29 @@
 namespace {
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
-inline bf16_t f2bf_host(float f) {
+// fp32 -> the library's 16-bit element (common.h), round-to-nearest-even
+inline h16_t f_to_h16_host(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+#if GP_F16
+    const uint32_t sign = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (h16_t)(sign | 0x7e00u);                    // NaN
+    if (a >= 0x477ff000u) return (h16_t)(sign | 0x7bffu);                   // >= 65520 rounds past the largest finite value: saturate
+    if (a < 0x33000001u) return (h16_t)sign;                                // <= 2^-25: rounds to zero
+    if (a < 0x38800000u) {                                                  // subnormal result: value = m * 2^-24
+        const int e = (int)(a >> 23);                                       // biased fp32 exponent, 102 .. 112
+        const uint32_t m = (a & 0x7fffffu) | 0x800000u;
+        const int sh = 126 - e;                                             // 14 .. 24: bits dropped from the 24-bit significand
+        const uint32_t q = m >> sh, rem = m & ((1u << sh) - 1u), half = 1u << (sh - 1);
+        return (h16_t)(sign | (q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u)));
+    }
+    const uint32_t r = a + 0xfffu + ((a >> 13) & 1u);                       // round the 13 dropped bits to nearest even
+    return (h16_t)(sign | ((r - 0x38000000u) >> 13));
+#else
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (h16_t)((u >> 16) | 0x40);  // NaN
     u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    return (h16_t)(u >> 16);
+#endif
 }
 inline float half_to_float(uint16_t h) {
     const uint32_t s = (h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ff;
@@ -93,7 +110,7 @@ struct Pool {
 };
 
 struct Act {
-    bf16_t* p = nullptr;
+    h16_t* p = nullptr;
     int B = 0, H = 0, W = 0, C = 0;  // C = allocated channels (row stride)
     // GroupNorm partial statistics written by the producing conv's epilogue ([pixel tile][C][2] fp32; owned with p)
     float* st = nullptr;
@@ -102,7 +119,7 @@ struct Act {
 };
 
 struct PackedW {
-    bf16_t* w = nullptr;   // [n_rows][taps][cin_pad]
+    h16_t* w = nullptr;   // [n_rows][taps][cin_pad]
     float* bias = nullptr; // [cout] or null
     int cout = 0, cin_pad = 0, ks = 1, n_rows = 0;
 };
@@ -143,11 +160,11 @@ struct gp_engine {
     hipStream_t st = nullptr;
     Pool pool;
     std::vector<void*> weights_dev;  // everything hipMalloc'ed for weights
-    bf16_t* zero = nullptr;
+    h16_t* zero = nullptr;
     float* gn_ws = nullptr;
     size_t gn_ws_floats = 0;
     float* mm_ws = nullptr;
-    bf16_t* conv_in_w27 = nullptr;  // VAE encoder conv_in as a [Cout][32] (K = 27) matrix for rgb_conv_in_kernel
+    h16_t* conv_in_w27 = nullptr;  // VAE encoder conv_in as a [Cout][32] (K = 27) matrix for rgb_conv_in_kernel
     bool fuse_gn = true;   // GENPERCEPT_NO_GN_FUSION=1 keeps the separate apply pass (A/B measurements)
     int gn_fuse_max_slices = 1;        // GENPERCEPT_GN_FUSE_MAX_SLICES: on large maps fuse the apply only into convs with at most this many 128-channel output slices
     int gn_fuse_always_below_px = 16384;  // maps with fewer pixels per image always fuse
@@ -202,7 +219,7 @@ struct gp_engine {
         return (r / 16) * 32 + ((r % 16) / 4) * 8 + (gate ? 4 : 0) + (r % 4);
     }
     // Pack [cout][cin][ks][ks] fp32 -> [n_rows][taps][cin_pad] bf16 (+ optional GEGLU row interleave).
-    static void pack_rows(const float* w, int cout, int cin, int ks, int cin_pad, bool geglu, std::vector<bf16_t>& out, int row0, int n_rows_total) {
+    static void pack_rows(const float* w, int cout, int cin, int ks, int cin_pad, bool geglu, std::vector<h16_t>& out, int row0, int n_rows_total) {
         const int taps = ks * ks;
         (void)n_rows_total;
         for (int n = 0; n < cout; ++n) {
@@ -210,16 +227,16 @@ struct gp_engine {
             if (geglu) {
                 dst = geglu_row(n, cout);
             }
-            bf16_t* o = out.data() + (size_t)(row0 + dst) * taps * cin_pad;
+            h16_t* o = out.data() + (size_t)(row0 + dst) * taps * cin_pad;
             const float* wi = w + (size_t)n * cin * taps;
             for (int c = 0; c < cin; ++c)
-                for (int t = 0; t < taps; ++t) o[(size_t)t * cin_pad + c] = f2bf_host(wi[(size_t)c * taps + t]);
+                for (int t = 0; t < taps; ++t) o[(size_t)t * cin_pad + c] = f_to_h16_host(wi[(size_t)c * taps + t]);
         }
     }
     PackedW pack(const float* w, const float* bias, int cout, int cin, int ks, int cin_pad, bool geglu = false) {
         PackedW pw;
         pw.cout = cout; pw.cin_pad = cin_pad; pw.ks = ks; pw.n_rows = gp_packed_rows(cout);
-        std::vector<bf16_t> buf((size_t)pw.n_rows * ks * ks * cin_pad, 0);
+        std::vector<h16_t> buf((size_t)pw.n_rows * ks * ks * cin_pad, 0);
         pack_rows(w, cout, cin, ks, cin_pad, geglu, buf, 0, pw.n_rows);
         pw.w = upload(buf.data(), buf.size());
         if (bias) {
@@ -383,7 +400,7 @@ struct gp_engine {
         if (const char* ms = getenv("GENPERCEPT_GN_FUSE_MAX_SLICES")) gn_fuse_max_slices = atoi(ms);
         fuse_stats = getenv("GENPERCEPT_NO_STATS_FUSION") == nullptr;
         {
-            std::vector<bf16_t> z(2048, 0);
+            std::vector<h16_t> z(2048, 0);
             zero = upload(z.data(), z.size());
         }
         const bool have_vae = has("vae.encoder.conv_in.weight") || has("vae.decoder.conv_in.weight");
@@ -501,7 +518,7 @@ struct gp_engine {
     Act new_act(int B, int H, int W, int C) {
         Act a;
         a.B = B; a.H = H; a.W = W; a.C = C;
-        a.p = (bf16_t*)pool.alloc((size_t)B * H * W * C * sizeof(bf16_t));
+        a.p = (h16_t*)pool.alloc((size_t)B * H * W * C * sizeof(h16_t));
         return a;
     }
     void drop(Act& a) {
@@ -578,12 +595,12 @@ struct gp_engine {
         int stride = 1, pad_t = 1, pad_l = 1;
         int Ho = 0, Wo = 0;     // 0: same as input (or upsampled size)
         int ups_h = 0, ups_w = 0;
-        const bf16_t* res = nullptr;
+        const h16_t* res = nullptr;
         int act = GP_ACT_NONE;
         int n_store = 0;        // 0: cout
         bool want_stats = false;  // the output feeds a GroupNorm
     };
-    IGemmParams conv_params(const Act& x, const PackedW& w, const ConvOpt& o, bf16_t* out) {
+    IGemmParams conv_params(const Act& x, const PackedW& w, const ConvOpt& o, h16_t* out) {
         if (x.C != w.cin_pad) throw std::logic_error("conv: channel mismatch (" + std::to_string(x.C) + " vs " + std::to_string(w.cin_pad) + ")");
         const int Hin = o.ups_h ? o.ups_h : x.H, Win = o.ups_w ? o.ups_w : x.W;
         const int Ho = o.Ho ? o.Ho : Hin, Wo = o.Wo ? o.Wo : Win;
@@ -610,7 +627,7 @@ struct gp_engine {
         return y;
     }
     // y[M][N] = x[M][K] W^T (+bias) (+res), N = w.cout (GEGLU halves it)
-    Act linear(const Act& x, const PackedW& w, const bf16_t* res = nullptr, int act = GP_ACT_NONE, bf16_t* out_inplace = nullptr,
+    Act linear(const Act& x, const PackedW& w, const h16_t* res = nullptr, int act = GP_ACT_NONE, h16_t* out_inplace = nullptr,
                bool want_stats = false) {
         if (x.C != w.cin_pad) throw std::logic_error("linear: channel mismatch");
         const int nout = act == GP_ACT_GEGLU ? w.cout / 2 : w.cout;
@@ -628,9 +645,9 @@ struct gp_engine {
         return y;
     }
     // V^T[b][c][t] = sum_k Wv[c][k] x[b][t][k] (+ bias[c]); zero-filled up to Tpad
-    bf16_t* v_transposed(const Act& x, const PackedW& wv, int T, int Tpad) {
+    h16_t* v_transposed(const Act& x, const PackedW& wv, int T, int Tpad) {
         const int C = wv.cout;
-        bf16_t* vt = (bf16_t*)pool.alloc((size_t)x.B * C * Tpad * sizeof(bf16_t));
+        h16_t* vt = (h16_t*)pool.alloc((size_t)x.B * C * Tpad * sizeof(h16_t));
         IGemmParams p{};
         p.in = wv.w; p.wt = x.p; p.bias = wv.bias; p.out = vt; p.zero = zero;
         p.M = C; p.N = T; p.Cin = wv.cin_pad; p.n_rows = T; p.ks = 1; p.stride = 1;
@@ -720,7 +737,7 @@ struct gp_engine {
         const int T = x.H * x.W, C = a.C, Tpad = round_up(T, 64), B = x.B;
         Act n = groupnorm(x, a.gn, cfg.vae_norm_eps, false);
         Act qk = linear(n, a.qk);  // [B*T][2C]
-        bf16_t* vt = v_transposed(n, a.v, T, Tpad);
+        h16_t* vt = v_transposed(n, a.v, T, Tpad);
         drop(n);
         // logits as fp16 (11 significant bits: finer than the bf16 probabilities they turn into) halve the score traffic, the largest HBM
         // item of the VAE.  They are the SCALED logits (1/sqrt(C) is folded into the query projection, build_vae_attn) and the fp16
@@ -738,7 +755,7 @@ struct gp_engine {
             run_igemm(p);
         }
         drop(qk);
-        bf16_t* P = (bf16_t*)pool.alloc((size_t)B * T * Tpad * sizeof(bf16_t));
+        h16_t* P = (h16_t*)pool.alloc((size_t)B * T * Tpad * sizeof(h16_t));
         mark("softmax_rows T=" + std::to_string(T));
         if (half_scores) launch_softmax_rows_f16(S, P, B * T, T, Tpad, 1.0f, st);
         else launch_softmax_rows(S, P, B * T, T, Tpad, 1.0f, st);
@@ -769,7 +786,7 @@ struct gp_engine {
         // self-attention
         Act l1 = layernorm(y, t.ln1);
         Act qk = linear(l1, t.qk);
-        bf16_t* vt = v_transposed(l1, t.v, T, Tpad);
+        h16_t* vt = v_transposed(l1, t.v, T, Tpad);
         drop(l1);
         Act a = new_act(x.B, x.H, x.W, C);
         tm.flops_attn += 4.0 * x.B * t.heads * (double)T * T * 64;
@@ -821,7 +838,7 @@ struct gp_engine {
             mark("rgb_conv_in " + dims(h), 2.0 * (double)h.pixels() * win.cout * 27.0);
             prof_begin(0);
             if (!conv_in_w27) {  // compact K = 27 weight matrix, built once from the packed conv weight
-                HIPCHK(hipMalloc((void**)&conv_in_w27, (size_t)win.cout * 32 * sizeof(bf16_t)));
+                HIPCHK(hipMalloc((void**)&conv_in_w27, (size_t)win.cout * 32 * sizeof(h16_t)));
                 weights_dev.push_back(conv_in_w27);
                 launch_pack_k27(win.w, 9 * win.cin_pad, win.cout, conv_in_w27, st);
             }
@@ -1117,10 +1134,10 @@ static gp_status guard(gp_engine* e, F&& f) {
     }
 }
 
-static bf16_t* g_zero = nullptr;
+static h16_t* g_zero = nullptr;
 static float* g_gn_ws = nullptr;
 static size_t g_gn_ws_floats = 0;
-static bf16_t* zero_page() {
+static h16_t* zero_page() {
     if (!g_zero) {
         HIPCHK(hipMalloc((void**)&g_zero, 4096));
         HIPCHK(hipMemset(g_zero, 0, 4096));
@@ -1130,7 +1147,8 @@ static bf16_t* zero_page() {
 
 extern "C" {
 
-const char* gp_version(void) { return "genpercept_hip 0.1 (gfx950)"; }
+const char* gp_version(void) { return GP_F16 ? "genpercept_hip 0.2 (gfx950, fp16 elements)" : "genpercept_hip 0.2 (gfx950, bf16 elements)"; }
+gp_dtype gp_element_dtype(void) { return GP_F16 ? GP_DT_F16 : GP_DT_BF16; }
 
 void gp_default_config(gp_config* c) {
     memset(c, 0, sizeof(*c));
@@ -1406,7 +1424,7 @@ gp_status gp_pack_weight(const float* w, int cout, int cin, int ks, int cin_pad,
     if (!w || !dev_out || (ks != 1 && ks != 3) || cin_pad < cin || (cin_pad % 64)) return GP_ERR_INVALID;
     try {
         const int n_rows = gp_packed_rows(cout);
-        std::vector<bf16_t> buf((size_t)n_rows * ks * ks * cin_pad, 0);
+        std::vector<h16_t> buf((size_t)n_rows * ks * ks * cin_pad, 0);
         gp_engine::pack_rows(w, cout, cin, ks, cin_pad, geglu != 0, buf, 0, n_rows);
         HIPCHK(hipMemcpy(dev_out, buf.data(), buf.size() * 2, hipMemcpyHostToDevice));
         return GP_OK;
@@ -1419,7 +1437,7 @@ gp_status gp_conv2d(const void* in, const void* w_packed, const float* bias, con
     if (!in || !w_packed || !out || (Cin % 64) || (ks != 1 && ks != 3)) return GP_ERR_INVALID;
     try {
         IGemmParams p{};
-        p.in = (const bf16_t*)in; p.wt = (const bf16_t*)w_packed; p.bias = bias; p.res = (const bf16_t*)residual; p.out = out; p.zero = zero_page();
+        p.in = (const h16_t*)in; p.wt = (const h16_t*)w_packed; p.bias = bias; p.res = (const h16_t*)residual; p.out = out; p.zero = zero_page();
         p.M = B * Ho * Wo; p.N = Cout; p.Cin = Cin; p.n_rows = gp_packed_rows(Cout); p.ks = ks;
         p.B = B; p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
         p.ups = ups_h > 0; p.Hu = ups_h; p.Wu = ups_w;
@@ -1440,7 +1458,7 @@ gp_status gp_conv2d_gn(const void* in, const void* w_packed, const float* bias, 
     try {
         const int Ho = ups ? 2 * H : H, Wo = ups ? 2 * W : W;
         IGemmParams p{};
-        p.in = (const bf16_t*)in; p.wt = (const bf16_t*)w_packed; p.bias = bias; p.res = (const bf16_t*)residual; p.out = out; p.zero = zero_page();
+        p.in = (const h16_t*)in; p.wt = (const h16_t*)w_packed; p.bias = bias; p.res = (const h16_t*)residual; p.out = out; p.zero = zero_page();
         p.M = B * Ho * Wo; p.N = Cout; p.Cin = Cin; p.n_rows = gp_packed_rows(Cout); p.ks = 3;
         p.B = B; p.Hi = H; p.Wi = W; p.Ho = Ho; p.Wo = Wo; p.stride = 1; p.pad_t = 1; p.pad_l = 1;
         p.ups = ups ? 1 : 0; p.Hu = ups ? Ho : 0; p.Wu = ups ? Wo : 0;
@@ -1454,7 +1472,7 @@ gp_status gp_conv2d_gn(const void* in, const void* w_packed, const float* bias, 
         }
         float* scale = g_gn_ws + groupnorm_ws_floats(B, H * W, Cin, groups);
         float* shift = scale + (size_t)B * Cin;
-        launch_groupnorm_stats((const bf16_t*)in, gamma, beta, B, H * W, Cin, groups, eps, g_gn_ws, scale, shift, (hipStream_t)stream);
+        launch_groupnorm_stats((const h16_t*)in, gamma, beta, B, H * W, Cin, groups, eps, g_gn_ws, scale, shift, (hipStream_t)stream);
         p.in_scale = scale; p.in_shift = shift; p.in_silu = silu;
         if (!conv_uses_halo(p, 5)) return GP_ERR_INVALID;
         launch_igemm(p, 5, (hipStream_t)stream);
@@ -1465,10 +1483,10 @@ gp_status gp_conv2d_gn(const void* in, const void* w_packed, const float* bias, 
 
 gp_status gp_rgb_conv_in(const void* rgb, int is_u8, const void* w_packed, const float* bias, void* out, int B, int H, int W, int Cout, void* stream) {
     if (!rgb || !w_packed || !out || B < 1 || H < 1 || W < 1 || (Cout % 32)) return GP_ERR_INVALID;
-    bf16_t* w27 = nullptr;
-    if (hipMalloc((void**)&w27, (size_t)Cout * 32 * sizeof(bf16_t)) != hipSuccess) return GP_ERR_HIP;
-    launch_pack_k27((const bf16_t*)w_packed, 9 * 64, Cout, w27, (hipStream_t)stream);
-    launch_rgb_conv_in(rgb, is_u8, w27, bias, (bf16_t*)out, nullptr, B, H, W, Cout, (hipStream_t)stream);
+    h16_t* w27 = nullptr;
+    if (hipMalloc((void**)&w27, (size_t)Cout * 32 * sizeof(h16_t)) != hipSuccess) return GP_ERR_HIP;
+    launch_pack_k27((const h16_t*)w_packed, 9 * 64, Cout, w27, (hipStream_t)stream);
+    launch_rgb_conv_in(rgb, is_u8, w27, bias, (h16_t*)out, nullptr, B, H, W, Cout, (hipStream_t)stream);
     const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(w27);
     return (e == hipSuccess && hipGetLastError() == hipSuccess) ? GP_OK : GP_ERR_HIP;
@@ -1482,7 +1500,7 @@ gp_status gp_conv2d_stats(const void* in, const void* w_packed, const float* bia
     try {
         const int Ho = ups ? 2 * H : H, Wo = ups ? 2 * W : W;
         IGemmParams p{};
-        p.in = (const bf16_t*)in; p.wt = (const bf16_t*)w_packed; p.bias = bias; p.res = (const bf16_t*)residual; p.out = out; p.zero = zero_page();
+        p.in = (const h16_t*)in; p.wt = (const h16_t*)w_packed; p.bias = bias; p.res = (const h16_t*)residual; p.out = out; p.zero = zero_page();
         p.M = B * Ho * Wo; p.N = Cout; p.Cin = Cin; p.n_rows = gp_packed_rows(Cout); p.ks = ks;
         p.B = B; p.Hi = H; p.Wi = W; p.Ho = Ho; p.Wo = Wo; p.stride = 1; p.pad_t = ks == 3; p.pad_l = ks == 3;
         p.ups = ups ? 1 : 0; p.Hu = ups ? Ho : 0; p.Wu = ups ? Wo : 0;
@@ -1514,7 +1532,7 @@ gp_status gp_gemm(const void* a, int lda, const void* bt, int ldb, const float* 
     if (!a || !bt || !out || (K % 64)) return GP_ERR_INVALID;
     try {
         IGemmParams p{};
-        p.in = (const bf16_t*)a; p.wt = (const bf16_t*)bt; p.bias = bias; p.res = (const bf16_t*)residual; p.out = out; p.zero = zero_page();
+        p.in = (const h16_t*)a; p.wt = (const h16_t*)bt; p.bias = bias; p.res = (const h16_t*)residual; p.out = out; p.zero = zero_page();
         p.M = M; p.N = N; p.Cin = K; p.n_rows = n_rows_bt; p.ks = 1; p.stride = 1;
         p.lda = lda; p.ldw = ldb; p.ldo = ldo; p.ldres = ldres; p.n_store = n_store > 0 ? n_store : N; p.out_fp32 = out_fp32; p.act = act;
         p.bias_mode = bias ? bias_mode : GP_BIAS_NONE; p.batch = batch > 0 ? batch : 1; p.in_bs = a_bs; p.wt_bs = bt_bs; p.out_bs = out_bs;
@@ -1533,7 +1551,7 @@ gp_status gp_groupnorm(const void* x, void* y, const float* gamma, const float* 
             HIPCHK(hipMalloc((void**)&g_gn_ws, need * 4));
             g_gn_ws_floats = need;
         }
-        launch_groupnorm((const bf16_t*)x, (bf16_t*)y, gamma, beta, B, HW, C, G, eps, silu, g_gn_ws, (hipStream_t)stream);
+        launch_groupnorm((const h16_t*)x, (h16_t*)y, gamma, beta, B, HW, C, G, eps, silu, g_gn_ws, (hipStream_t)stream);
         HIPCHK(hipGetLastError());
         return GP_OK;
     } catch (...) { return GP_ERR_HIP; }
@@ -1541,7 +1559,7 @@ gp_status gp_groupnorm(const void* x, void* y, const float* gamma, const float* 
 
 gp_status gp_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C, float eps, void* stream) {
     if (!x || !y || (C % 8) || C > 4096) return GP_ERR_INVALID;
-    launch_layernorm((const bf16_t*)x, (bf16_t*)y, gamma, beta, rows, C, eps, (hipStream_t)stream);
+    launch_layernorm((const h16_t*)x, (h16_t*)y, gamma, beta, rows, C, eps, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
 }
 
@@ -1549,7 +1567,7 @@ gp_status gp_flash_attention(const void* q, const void* k, const void* vt, void*
                              void* stream) {
     if (!q || !k || !vt || !out || (Tpad % 64) || Tpad < T) return GP_ERR_INVALID;
     try {
-        launch_flash_attn64((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, zero_page(), B, T, heads, ldq, ldk, Tpad, ldo,
+        launch_flash_attn64((const h16_t*)q, (const h16_t*)k, (const h16_t*)vt, (h16_t*)out, zero_page(), B, T, heads, ldq, ldk, Tpad, ldo,
                             (hipStream_t)stream);
         HIPCHK(hipGetLastError());
         return GP_OK;
@@ -1558,25 +1576,25 @@ gp_status gp_flash_attention(const void* q, const void* k, const void* vt, void*
 
 gp_status gp_cross_attention(const void* q, const float* kc, const float* vc, void* out, int rows, int C, int L, void* stream) {
     if (!q || !kc || !vc || !out || (C % 64)) return GP_ERR_INVALID;
-    launch_cross_attn_small((const bf16_t*)q, kc, vc, (bf16_t*)out, rows, C, L, (hipStream_t)stream);
+    launch_cross_attn_small((const h16_t*)q, kc, vc, (h16_t*)out, rows, C, L, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
 }
 
 gp_status gp_softmax_rows(const float* in, void* out, int rows, int T, int ld, float scale, void* stream) {
     if (!in || !out || ld < T) return GP_ERR_INVALID;
-    launch_softmax_rows(in, (bf16_t*)out, rows, T, ld, scale, (hipStream_t)stream);
+    launch_softmax_rows(in, (h16_t*)out, rows, T, ld, scale, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
 }
 
 gp_status gp_softmax_rows_f16(const void* in_f16, void* out, int rows, int T, int ld, float scale, void* stream) {
     if (!in_f16 || !out || ld < T || !softmax_rows_f16_supported(ld) || scale <= 0.f) return GP_ERR_INVALID;
-    launch_softmax_rows_f16(in_f16, (bf16_t*)out, rows, T, ld, scale, (hipStream_t)stream);
+    launch_softmax_rows_f16(in_f16, (h16_t*)out, rows, T, ld, scale, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
 }
 
 gp_status gp_bilinear(const void* in, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream) {
     if (!in || !out || (C % 8)) return GP_ERR_INVALID;
-    launch_bilinear((const bf16_t*)in, (bf16_t*)out, B, Hi, Wi, Ho, Wo, C, align_corners, (hipStream_t)stream);
+    launch_bilinear((const h16_t*)in, (h16_t*)out, B, Hi, Wi, Ho, Wo, C, align_corners, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
 }
 

@@ -23,7 +23,7 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
     const bool geglu = p.act == GP_ACT_GEGLU;
     const int n_out = geglu ? (p.N >> 1) : p.N;
     const float* bias = p.bias ? p.bias + (long long)z * p.bias_bs : nullptr;
-    const bf16_t* res = p.res ? p.res + (long long)z * p.res_bs : nullptr;
+    const h16_t* res = p.res ? p.res + (long long)z * p.res_bs : nullptr;
     const bool staged = !p.out_fp32 && !geglu && (p.ldo & 7) == 0 && !(p.dbg & 64);
 
     if (staged) {
@@ -46,7 +46,7 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
             }
         }
         __syncthreads();
-        bf16_t* outp = (bf16_t*)p.out + (long long)z * p.out_bs;
+        h16_t* outp = (h16_t*)p.out + (long long)z * p.out_bs;
         const bool res_vec = res && (p.ldres & 7) == 0;
         // GroupNorm statistics of the tensor being written (NTHREADS % SL == 0: a thread always handles the same 8 channels)
         static_assert(NTHREADS % SL == 0, "stats: a thread must keep its channel slot");
@@ -63,15 +63,15 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
             const float4 x0 = *(const float4*)sp, x1 = *(const float4*)(sp + 4);
             float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
             if (res) {
-                const bf16_t* rp = res + (long long)m * p.ldres + col;
+                const h16_t* rp = res + (long long)m * p.ldres + col;
                 if (res_vec && col + 7 < n_out) {
                     const uint4 rv = *(const uint4*)rp;
-                    v[0] += bflo(rv.x); v[1] += bfhi(rv.x); v[2] += bflo(rv.y); v[3] += bfhi(rv.y);
-                    v[4] += bflo(rv.z); v[5] += bfhi(rv.z); v[6] += bflo(rv.w); v[7] += bfhi(rv.w);
+                    v[0] += h16_lo(rv.x); v[1] += h16_hi(rv.x); v[2] += h16_lo(rv.y); v[3] += h16_hi(rv.y);
+                    v[4] += h16_lo(rv.z); v[5] += h16_hi(rv.z); v[6] += h16_lo(rv.w); v[7] += h16_hi(rv.w);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        if (col + e < n_out) v[e] += bf2f(rp[e]);
+                        if (col + e < n_out) v[e] += h16_to_f(rp[e]);
                 }
             }
 #pragma unroll
@@ -80,18 +80,18 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
                 else if (p.act == GP_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
                 if (col + e >= n_out) v[e] = 0.f;
             }
-            bf16_t* o = outp + (long long)m * p.ldo + col;
+            h16_t* o = outp + (long long)m * p.ldo + col;
             uint4 pk;
-            pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+            pk.x = pack_h16x2(v[0], v[1]); pk.y = pack_h16x2(v[2], v[3]); pk.z = pack_h16x2(v[4], v[5]); pk.w = pack_h16x2(v[6], v[7]);
             if (col + 7 < p.n_store) {
                 *(uint4*)o = pk;
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (col + e < p.n_store) o[e] = f2bf(v[e]);
+                    if (col + e < p.n_store) o[e] = f_to_h16(v[e]);
             }
             if (want_stats) {  // of the values as stored (bf16-rounded), exactly what a read pass would see
-                const float r[8] = {bflo(pk.x), bfhi(pk.x), bflo(pk.y), bfhi(pk.y), bflo(pk.z), bfhi(pk.z), bflo(pk.w), bfhi(pk.w)};
+                const float r[8] = {h16_lo(pk.x), h16_hi(pk.x), h16_lo(pk.y), h16_hi(pk.y), h16_lo(pk.z), h16_hi(pk.z), h16_lo(pk.w), h16_hi(pk.w)};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { st_s[e] += r[e]; st_q[e] += r[e] * r[e]; }
             }
@@ -145,13 +145,13 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
                     v[r] = a * gelu_erf_f(g);
                     if (col + r >= n_out) v[r] = 0.f;
                 }
-                bf16_t* o = (bf16_t*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
+                h16_t* o = (h16_t*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
                 if (col + 3 < p.n_store && (p.ldo & 3) == 0) {
-                    *(uint2*)o = pack_bf16x4(v[0], v[1], v[2], v[3]);
+                    *(uint2*)o = pack_h16x4(v[0], v[1], v[2], v[3]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (col + r < p.n_store) o[r] = f2bf(v[r]);
+                        if (col + r < p.n_store) o[r] = f_to_h16(v[r]);
                 }
                 continue;
             }
@@ -161,10 +161,10 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = acc[2 * ip + (e >> 2)][j][e & 3] + bcol[ip][e] + rb;
             if (res) {
-                const bf16_t* rp = res + (long long)m * p.ldres + col;
+                const h16_t* rp = res + (long long)m * p.ldres + col;
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (col + e < n_out) v[e] += bf2f(rp[e]);
+                    if (col + e < n_out) v[e] += h16_to_f(rp[e]);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -198,10 +198,10 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
                         if (col + e < p.n_store) o[e] = v[e];
                 }
             } else {
-                bf16_t* o = (bf16_t*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
+                h16_t* o = (h16_t*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (col + e < p.n_store) o[e] = f2bf(v[e]);
+                    if (col + e < p.n_store) o[e] = f_to_h16(v[e]);
             }
         }
     }

@@ -52,8 +52,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
     const int m0 = (sid / tiles_n) * BM, n0 = (sid % tiles_n) * BN;
     const int z = blockIdx.y;
 
-    const bf16_t* in = p.in + (long long)z * p.in_bs;
-    const bf16_t* wt = p.wt + (long long)z * p.wt_bs;
+    const h16_t* in = p.in + (long long)z * p.in_bs;
+    const h16_t* wt = p.wt + (long long)z * p.wt_bs;
     const int Cin = p.Cin;
     const int cpt = Cin >> 6;                       // 64-channel chunks per tap
     const int nk_all = (CONV ? 9 : 1) * cpt;
@@ -67,14 +67,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
     //   weight tile: slot ^ (b1 | b3 << 1 | b4 << 2) of the row    rows read as {8q + 4h + r}
     const int chunk_a = (lane & 7) ^ (lane >> 3);
     const int chunk_w = (lane & 7) ^ (((lane >> 4) & 1) | ((wave & 1) << 1) | (((wave >> 1) & 1) << 2));
-    const bf16_t* zsrc_a = p.zero + chunk_a * 8;
-    const bf16_t* zsrc_w = p.zero + chunk_w * 8;
+    const h16_t* zsrc_a = p.zero + chunk_a * 8;
+    const h16_t* zsrc_w = p.zero + chunk_w * 8;
 
     // ---- per-lane row descriptors ---------------------------------------------------------------------------------
-    const bf16_t* a_base[A_IT];   // plain: row pointer; conv: pointer of the (virtual) top-left tap pixel; ups: image base
+    const h16_t* a_base[A_IT];   // plain: row pointer; conv: pointer of the (virtual) top-left tap pixel; ups: image base
     unsigned a_mask[A_IT];        // bit t: tap t of this row is inside the image (plain rows: bit 0)
     int a_y0[UPS ? A_IT : 1], a_x0[UPS ? A_IT : 1];
-    const bf16_t* a_tap[UPS ? A_IT : 1];
+    const h16_t* a_tap[UPS ? A_IT : 1];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int m = m0 + (wave + NW * i) * 8 + (lane >> 3);
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             const int y0 = oy * p.stride - p.pad_t, x0 = ox * p.stride - p.pad_l;
-            const bf16_t* img = in + (long long)b * p.Hi * p.Wi * Cin + chunk_a * 8;
+            const h16_t* img = in + (long long)b * p.Hi * p.Wi * Cin + chunk_a * 8;
             unsigned mk = 0;
             const int hlim = UPS ? p.Hu : p.Hi, wlim = UPS ? p.Wu : p.Wi;
 #pragma unroll
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
             }
         }
     }
-    const bf16_t* w_base[B_IT];
+    const h16_t* w_base[B_IT];
     bool w_ok[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -134,15 +134,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const bool ok = (a_mask[i] >> st_tap) & 1u;
-            const bf16_t* ab;
+            const h16_t* ab;
             if constexpr (UPS) ab = a_tap[i]; else ab = a_base[i];
-            const bf16_t* src = ok ? ab + aoff : zsrc_a;
+            const h16_t* src = ok ? ab + aoff : zsrc_a;
             glds16(src, sb + (wave + NW * i) * 1024);
         }
         const int woff = st_tap * Cin + koff;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const bf16_t* src = w_ok[i] ? w_base[i] + woff : zsrc_w;
+            const h16_t* src = w_ok[i] ? w_base[i] + woff : zsrc_w;
             glds16(src, sb + A_BYTES + (wave + NW * i) * 1024);
         }
         if (++st_cc == cpt) {
@@ -172,15 +172,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
         const char* sb = smem + buf * STAGE;
         // all 2*(FN+FM) fragment reads are issued up front so the LDS latency of the second k-half hides under the first
         // half's MFMAs (hipcc otherwise emits read-batch / lgkmcnt(0) / MFMA-batch with the latency exposed each time)
-        bf16x8_t wf[2][FN], xf[2][FM];
+        h16x8_t wf[2][FN], xf[2][FM];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int sl = kk * 4 + (lane >> 4);
             const int so_a = (sl ^ xr_a) << 4, so_w = (sl ^ xr_w) << 4;
 #pragma unroll
-            for (int i = 0; i < FN; ++i) wf[kk][i] = *(const bf16x8_t*)(sb + w_row_off + (i >> 1) * 4096 + (i & 1) * 512 + so_w);
+            for (int i = 0; i < FN; ++i) wf[kk][i] = *(const h16x8_t*)(sb + w_row_off + (i >> 1) * 4096 + (i & 1) * 512 + so_w);
 #pragma unroll
-            for (int j = 0; j < FM; ++j) xf[kk][j] = *(const bf16x8_t*)(sb + a_row_off + j * 2048 + so_a);
+            for (int j = 0; j < FM; ++j) xf[kk][j] = *(const h16x8_t*)(sb + a_row_off + j * 2048 + so_a);
         }
         if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
 #pragma unroll
             for (int i = 0; i < FN; ++i)
 #pragma unroll
-                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FM; ++j) acc[i][j] = mfma_16x16x32(wf[kk][i], xf[kk][j], acc[i][j]);
         if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
@@ -241,8 +241,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
 
 // ---- split-K: out[m][n] = act( sum_z part[z][m][n] + bias[n] ) (+ res[m][n]); columns in [n_out, n_store) are written as 0 ----------
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, long long slice, int M, int N, int n_store,
-                                                             const float* __restrict__ bias, const bf16_t* __restrict__ res, int ldres, int act,
-                                                             bf16_t* __restrict__ out, int ldo) {
+                                                             const float* __restrict__ bias, const h16_t* __restrict__ res, int ldres, int act,
+                                                             h16_t* __restrict__ out, int ldo) {
     const int nv = n_store >> 2;  // 4 columns per thread (n_store % 4 == 0)
     const long long total = (long long)M * nv;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -258,14 +258,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         for (int e = 0; e < 4; ++e) {
             if (c + e < N) {
                 if (bias) v[e] += bias[c + e];
-                if (res) v[e] += bf2f(res[m * ldres + c + e]);
+                if (res) v[e] += h16_to_f(res[m * ldres + c + e]);
                 if (act == GP_ACT_SILU) v[e] = silu_f(v[e]);
                 else if (act == GP_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
             } else {
                 v[e] = 0.f;
             }
         }
-        *(uint2*)(out + m * ldo + c) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+        *(uint2*)(out + m * ldo + c) = pack_h16x4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -395,7 +395,7 @@ void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s) {
             int blocks = (int)((total + 255) / 256);
             if (blocks > 2048) blocks = 2048;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, S, (long long)slice, p.M, p.N, p.n_store,
-                               p.bias_mode == GP_BIAS_COL ? p.bias : nullptr, p.res, p.ldres, p.act, (bf16_t*)p.out, p.ldo);
+                               p.bias_mode == GP_BIAS_COL ? p.bias : nullptr, p.res, p.ldres, p.act, (h16_t*)p.out, p.ldo);
             return;
         }
     }

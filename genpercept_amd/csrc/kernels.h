@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef unsigned short bf16_t;
+#ifndef GP_F16
+#define GP_F16 0  // 1: the library's 16-bit element is IEEE fp16 instead of bf16 (common.h)
+#endif
+typedef unsigned short h16_t;  // raw bits of one element (bf16 or fp16)
 
 enum { GP_ACT_NONE = 0, GP_ACT_SILU = 1, GP_ACT_RELU = 2, GP_ACT_GEGLU = 3 };
 enum { GP_BIAS_NONE = 0, GP_BIAS_COL = 1, GP_BIAS_ROW = 2 };
@@ -13,12 +16,12 @@ enum { GP_BIAS_NONE = 0, GP_BIAS_COL = 1, GP_BIAS_ROW = 2 };
 //   cols n  = output channels; W is [n][tap][cin] (k-contiguous), i.e. "B transposed"
 //   k       = (tap, cin), cin % 64 == 0
 struct IGemmParams {
-    const bf16_t* in;     // NHWC input [B][Hi][Wi][Cin] (row stride lda elements when ks == 1)
-    const bf16_t* wt;     // [n_rows][taps][Cin]
+    const h16_t* in;     // NHWC input [B][Hi][Wi][Cin] (row stride lda elements when ks == 1)
+    const h16_t* wt;     // [n_rows][taps][Cin]
     const float* bias;    // [Cout] (COL) or [M] (ROW) or nullptr
-    const bf16_t* res;    // residual [M][ldres] bf16 or nullptr
+    const h16_t* res;    // residual [M][ldres] bf16 or nullptr
     void* out;            // bf16 or fp32 [M][ldo]
-    const bf16_t* zero;   // >= 256 bytes of zeros (source for padding / out-of-range rows)
+    const h16_t* zero;   // >= 256 bytes of zeros (source for padding / out-of-range rows)
     const float* in_scale;  // optional fused input transform x -> act(x * in_scale[b][c] + in_shift[b][c]) (GroupNorm apply);
     const float* in_shift;  //   only honoured by conv_halo.hip (callers check conv_uses_halo())
     int in_silu;
@@ -67,46 +70,46 @@ void launch_groupnorm_from_partials(const float* partials, int mode, int bm, int
 // GroupNorm over NHWC bf16 (fp32 statistics), optional fused SiLU.  Three passes: partial statistics, per-(image, channel)
 // scale/shift, apply; the apply pass is skipped when the consuming conv fuses it (IGemmParams::in_scale).
 // ws for launch_groupnorm: >= groupnorm_ws_floats() + 2*B*C floats.
-void launch_groupnorm_stats(const bf16_t* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, float* ws,
+void launch_groupnorm_stats(const h16_t* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, float* ws,
                             float* scale, float* shift, hipStream_t s);
-void launch_groupnorm_apply(const bf16_t* x, bf16_t* y, const float* scale, const float* shift, int B, int HW, int C, int silu, hipStream_t s);
-void launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps,
+void launch_groupnorm_apply(const h16_t* x, h16_t* y, const float* scale, const float* shift, int B, int HW, int C, int silu, hipStream_t s);
+void launch_groupnorm(const h16_t* x, h16_t* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps,
                       int silu, float* ws, hipStream_t s);
 int groupnorm_ws_floats(int B, int HW, int C, int G);
 
 // LayerNorm over the last dim of [rows][C] bf16.
-void launch_layernorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int rows, int C, float eps, hipStream_t s);
+void launch_layernorm(const h16_t* x, h16_t* y, const float* gamma, const float* beta, int rows, int C, float eps, hipStream_t s);
 
 // Flash self-attention, head_dim 64.  q/k: [B][T][ld] bf16 (head h at column h*64), vt: [B][heads*64][Tpad] bf16,
 // out [B][T][ldo].
-void launch_flash_attn64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, const bf16_t* zero, int B, int T, int heads,
+void launch_flash_attn64(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t* out, const h16_t* zero, int B, int T, int heads,
                          int ldq, int ldk, int Tpad, int ldo, hipStream_t s);
 
 // Cross-attention against a small constant context: q [rows][C] bf16, kc/vc [L][C] fp32, head_dim 64.
-void launch_cross_attn_small(const bf16_t* q, const float* kc, const float* vc, bf16_t* out, int rows, int C, int L, hipStream_t s);
+void launch_cross_attn_small(const h16_t* q, const float* kc, const float* vc, h16_t* out, int rows, int C, int L, hipStream_t s);
 
 // Row softmax: in fp32 [rows][ld] (first T columns valid) -> bf16 [rows][ld], columns >= T written as 0.
-void launch_softmax_rows(const float* in, bf16_t* out, int rows, int T, int ld, float scale, hipStream_t s);
+void launch_softmax_rows(const float* in, h16_t* out, int rows, int T, int ld, float scale, hipStream_t s);
 bool softmax_rows_f16_supported(int ld);
-void launch_softmax_rows_f16(const void* in_f16, bf16_t* out, int rows, int T, int ld, float scale, hipStream_t s);  // fp16 logits
+void launch_softmax_rows_f16(const void* in_f16, h16_t* out, int rows, int T, int ld, float scale, hipStream_t s);  // fp16 logits
 
 // Elementwise / layout kernels
-void launch_rgb_prologue(const void* rgb, int is_u8, bf16_t* out, int B, int H, int W, int Cpad, hipStream_t s);  // NCHW -> NHWC, x/255*2-1
+void launch_rgb_prologue(const void* rgb, int is_u8, h16_t* out, int B, int H, int W, int Cpad, hipStream_t s);  // NCHW -> NHWC, x/255*2-1
 // fused RGB prologue + VAE-encoder conv_in (3 -> Cout, Cout % 32 == 0) + GroupNorm partial statistics (16x16 tiles) of the output
-void launch_pack_k27(const bf16_t* wt, int ldw, int Cout, bf16_t* w27, hipStream_t s);  // [rows][9][64] conv layout -> compact [Cout][32]
-void launch_rgb_conv_in(const void* rgb, int is_u8, const bf16_t* w27, const float* bias, bf16_t* out, float* stats, int B, int H, int W, int Cout,
+void launch_pack_k27(const h16_t* wt, int ldw, int Cout, h16_t* w27, hipStream_t s);  // [rows][9][64] conv layout -> compact [Cout][32]
+void launch_rgb_conv_in(const void* rgb, int is_u8, const h16_t* w27, const float* bias, h16_t* out, float* stats, int B, int H, int W, int Cout,
                         hipStream_t s);
-void launch_concat(const bf16_t* a, int Ca, const bf16_t* b, int Cb, bf16_t* out, long long pixels, hipStream_t s);
+void launch_concat(const h16_t* a, int Ca, const h16_t* b, int Cb, h16_t* out, long long pixels, hipStream_t s);
 int concat_stats_bm(long long hw);  // pixels per statistics tile launch_concat_stats can use for an image of hw pixels (0: none)
-void launch_concat_stats(const bf16_t* a, int Ca, const bf16_t* b, int Cb, bf16_t* out, long long pixels, int bm, float* part, hipStream_t s);
-void launch_nchw_f32_to_nhwc(const float* in, bf16_t* out, int B, int C, int H, int W, int Cpad, hipStream_t s);
-void launch_nhwc_to_nchw_f32(const bf16_t* in, float* out, int B, int C, int H, int W, int ld, hipStream_t s);
-void launch_decode_epilogue(const bf16_t* in, float* out, int B, int H, int W, int ld, int mean3, int raw, hipStream_t s);  // mean, clip, (x+1)/2
-void launch_scale_pad(const bf16_t* in, bf16_t* out, long long pixels, int C, int ldi, int ldo, float scale, hipStream_t s);
-void launch_pointwise_small(const bf16_t* in, bf16_t* out, const float* w, const float* bias, long long pixels, int Cin, int Cout, int ldi,
+void launch_concat_stats(const h16_t* a, int Ca, const h16_t* b, int Cb, h16_t* out, long long pixels, int bm, float* part, hipStream_t s);
+void launch_nchw_f32_to_nhwc(const float* in, h16_t* out, int B, int C, int H, int W, int Cpad, hipStream_t s);
+void launch_nhwc_to_nchw_f32(const h16_t* in, float* out, int B, int C, int H, int W, int ld, hipStream_t s);
+void launch_decode_epilogue(const h16_t* in, float* out, int B, int H, int W, int ld, int mean3, int raw, hipStream_t s);  // mean, clip, (x+1)/2
+void launch_scale_pad(const h16_t* in, h16_t* out, long long pixels, int C, int ldi, int ldo, float scale, hipStream_t s);
+void launch_pointwise_small(const h16_t* in, h16_t* out, const float* w, const float* bias, long long pixels, int Cin, int Cout, int ldi,
                             int ldo, float in_scale, hipStream_t s);  // 1x1 conv for Cin, Cout <= 8 (post_quant_conv)
-void launch_relu(const bf16_t* in, bf16_t* out, long long n, hipStream_t s);
-void launch_add(const bf16_t* a, const bf16_t* b, bf16_t* out, long long n, hipStream_t s);
-void launch_bilinear(const bf16_t* in, bf16_t* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, hipStream_t s);
-void launch_dpt_final(const bf16_t* in, const float* w, float bias, float* out, int B, int HW, int Cin, hipStream_t s);  // ReLU'd 32ch -> 1
+void launch_relu(const h16_t* in, h16_t* out, long long n, hipStream_t s);
+void launch_add(const h16_t* a, const h16_t* b, h16_t* out, long long n, hipStream_t s);
+void launch_bilinear(const h16_t* in, h16_t* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, hipStream_t s);
+void launch_dpt_final(const h16_t* in, const float* w, float bias, float* out, int B, int HW, int Cin, hipStream_t s);  // ReLU'd 32ch -> 1
 void launch_minmax_norm(float* x, int B, long long n, float* ws, hipStream_t s);  // per-image (x-min)/(max-min)

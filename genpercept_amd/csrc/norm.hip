@@ -16,7 +16,7 @@ int groupnorm_ws_floats(int B, int HW, int C, int G) { return B * gn_nchunk(HW) 
 // ---- pass 1: per (image, pixel-chunk, group) partial sum / sum of squares -----------------------------------------
 // Thread t owns VPT fixed 8-channel vectors (v = tv, tv + tpp, ...) and walks pixels p = pl, pl + PL, ... of the chunk.
 template <int VPT>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ ws, int HW, int C, int G,
+__global__ __launch_bounds__(256) void gn_stats_kernel(const h16_t* __restrict__ x, float* __restrict__ ws, int HW, int C, int G,
                                                         int nchunk, int tpp, int PL) {
     extern __shared__ __attribute__((aligned(16))) float sred[];  // [PL][C][2]
     const int b = blockIdx.y, ck = blockIdx.x;
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[u][e] = q[u][e] = 0.f;
     if (pl < PL) {
-        const bf16_t* xb = x + (long long)b * HW * C;
+        const h16_t* xb = x + (long long)b * HW * C;
         for (int p = p0 + pl; p < p1; p += PL) {
 #pragma unroll
             for (int u = 0; u < VPT; ++u) {
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
                     const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float lo = bflo(w[e]), hi = bfhi(w[e]);
+                        const float lo = h16_lo(w[e]), hi = h16_hi(w[e]);
                         s[u][2 * e] += lo; q[u][2 * e] += lo * lo;
                         s[u][2 * e + 1] += hi; q[u][2 * e + 1] += hi * hi;
                     }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 }
 
 // ---- pass 3 (only when the consumer cannot fuse it): y = act(x * scale + shift) ----------------------------------------------
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* __restrict__ scale,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const h16_t* __restrict__ x, h16_t* __restrict__ y, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int HW, int C, int nchunk, int silu) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [C] scale, [C] shift
     float* s_scale = sm;
@@ -142,20 +142,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = v * 8 + 2 * k;
-            o[2 * k] = bflo(w[k]) * s_scale[c] + s_shift[c];
-            o[2 * k + 1] = bfhi(w[k]) * s_scale[c + 1] + s_shift[c + 1];
+            o[2 * k] = h16_lo(w[k]) * s_scale[c] + s_shift[c];
+            o[2 * k + 1] = h16_hi(w[k]) * s_scale[c + 1] + s_shift[c + 1];
         }
         if (silu) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = silu_f(o[k]);
         }
         uint4 r;
-        r.x = pack_bf16x2(o[0], o[1]); r.y = pack_bf16x2(o[2], o[3]); r.z = pack_bf16x2(o[4], o[5]); r.w = pack_bf16x2(o[6], o[7]);
+        r.x = pack_h16x2(o[0], o[1]); r.y = pack_h16x2(o[2], o[3]); r.z = pack_h16x2(o[4], o[5]); r.w = pack_h16x2(o[6], o[7]);
         *(uint4*)(y + base + e * 8) = r;
     }
 }
 
-void launch_groupnorm_stats(const bf16_t* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, float* ws,
+void launch_groupnorm_stats(const h16_t* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, float* ws,
                             float* scale, float* shift, hipStream_t s) {
     const int nchunk = gn_nchunk(HW);
     const int nvec = C / 8;
@@ -169,13 +169,13 @@ void launch_groupnorm_stats(const bf16_t* x, const float* gamma, const float* be
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, (const float*)ws, gamma, beta, scale, shift, HW, C, G, nchunk, eps);
 }
 
-void launch_groupnorm_apply(const bf16_t* x, bf16_t* y, const float* scale, const float* shift, int B, int HW, int C, int silu, hipStream_t s) {
+void launch_groupnorm_apply(const h16_t* x, h16_t* y, const float* scale, const float* shift, int B, int HW, int C, int silu, hipStream_t s) {
     const int nchunk = gn_nchunk(HW);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(256), (size_t)2 * C * sizeof(float), s, x, y, scale, shift, HW, C, nchunk, silu);
 }
 
 // ws: >= groupnorm_ws_floats() + 2*B*C floats (partials, then scale, then shift)
-void launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int silu,
+void launch_groupnorm(const h16_t* x, h16_t* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int silu,
                       float* ws, hipStream_t s) {
     float* scale = ws + groupnorm_ws_floats(B, HW, C, G);
     float* shift = scale + (size_t)B * C;
@@ -245,7 +245,7 @@ void launch_groupnorm_from_partials(const float* partials, int mode, int bm, int
 
 // ---- LayerNorm: one wave per row, row kept in registers (C <= 4096), exact two-pass statistics -------------------
 template <int VPT>
-__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void layernorm_kernel(const h16_t* __restrict__ x, h16_t* __restrict__ y, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
             const uint4 raw = *(const uint4*)(x + (long long)row * C + vi * 8);
             const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { v[u][2 * k] = bflo(w[k]); v[u][2 * k + 1] = bfhi(w[k]); }
+            for (int k = 0; k < 4; ++k) { v[u][2 * k] = h16_lo(w[k]); v[u][2 * k + 1] = h16_hi(w[k]); }
 #pragma unroll
             for (int k = 0; k < 8; ++k) sum += v[u][k];
         } else {
@@ -295,13 +295,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = (v[u][k] - mean) * rstd * gg[k] + bb[k];
             uint4 r;
-            r.x = pack_bf16x2(o[0], o[1]); r.y = pack_bf16x2(o[2], o[3]); r.z = pack_bf16x2(o[4], o[5]); r.w = pack_bf16x2(o[6], o[7]);
+            r.x = pack_h16x2(o[0], o[1]); r.y = pack_h16x2(o[2], o[3]); r.z = pack_h16x2(o[4], o[5]); r.w = pack_h16x2(o[6], o[7]);
             *(uint4*)(y + (long long)row * C + vi * 8) = r;
         }
     }
 }
 
-void launch_layernorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int rows, int C, float eps, hipStream_t s) {
+void launch_layernorm(const h16_t* x, h16_t* y, const float* gamma, const float* beta, int rows, int C, float eps, hipStream_t s) {
     const int nvec = C / 8;
     const int vpt = (nvec + 63) / 64;
     dim3 grid((rows + 3) / 4);

@@ -66,8 +66,8 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
     // ---- DMA sources: A rows advance 64 elements per step, by a_wrap at the end of a tile; W rows wrap back -----------------------
     const int chunk_a = (lane & 7) ^ (lane >> 3);
     const int chunk_w = (lane & 7) ^ (((lane >> 4) & 1) | ((wave & 1) << 1) | (((wave >> 1) & 1) << 2));
-    const bf16_t* aq[A_IT];
-    const bf16_t* wq[B_IT];
+    const h16_t* aq[A_IT];
+    const h16_t* wq[B_IT];
     unsigned a_ok = 0, w_ok = 0;
     int im0 = g * BM;                                     // first row of the tile being STAGED (runs ahead of the compute)
     int ikt = 0;
@@ -88,19 +88,19 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
     set_a_ok();
     const long long a_wrap = (long long)tile_adv * p.lda - (nk - 1) * 64;
     const int w_wrap = -(nk - 1) * 64;
-    const bf16_t* zsrc = p.zero;
+    const h16_t* zsrc = p.zero;
     auto stage = [&](int slot) __attribute__((always_inline)) {  // next stage in (tile, k) order into ring slot `slot`
         char* sb = smem + slot * STAGE;
         const bool wrap = ikt == nk - 1;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const bf16_t* src = ((a_ok >> i) & 1u) ? aq[i] : zsrc;
+            const h16_t* src = ((a_ok >> i) & 1u) ? aq[i] : zsrc;
             if (!(ABL & 8)) glds16(src, sb + (wave + 8 * i) * 1024);
             aq[i] += wrap ? a_wrap : 64;
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const bf16_t* src = ((w_ok >> i) & 1u) ? wq[i] : zsrc;
+            const h16_t* src = ((w_ok >> i) & 1u) ? wq[i] : zsrc;
             if (!(ABL & 8)) glds16(src, sb + A_BYTES + (wave + 8 * i) * 1024);
             wq[i] += wrap ? w_wrap : 64;
         }
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // ---- fragment bases (LDS byte addresses); slot, fragment row block and k-half offsets are immediates ----------------------------
-    struct Half { bf16x8_t w[FN], x[FM]; };
+    struct Half { h16x8_t w[FN], x[FM]; };
     unsigned xb[2], wb[2];
     {
         const int xr_w = ((a15 >> 1) & 1) | (((a15 >> 2) & 1) << 1) | (((a15 >> 3) & 1) << 2);
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
 #pragma unroll
         for (int i = 0; i < FN; ++i)
 #pragma unroll
-            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[i], f.x[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FM; ++j) acc[i][j] = mfma_16x16x32(f.w[i], f.x[j], acc[i][j]);
     };
     auto interleave = [&]() __attribute__((always_inline)) {  // FN*FM MFMAs with FN+FM LDS reads between them
         if (FN == 4) {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
         const int col = n0 + wn * TN + 8 * sl8;
         const bool col_ok = col < p.n_store;
         const bool tail = col + 7 >= n_out;
-        bf16_t* outp = (bf16_t*)p.out;
+        h16_t* outp = (h16_t*)p.out;
         // window: staged row r (0..15) of TN fp32 lives in DMA piece r / RPP of this wave: slot base + (wave + 8 * piece) KiB
         constexpr int RPP = 1024 / (TN * 4);
         const unsigned win = smem_base + S * STAGE + wave * 1024;
@@ -227,8 +227,8 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
                     float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                     if (RES) {
                         const uint4 r4 = rv[j][h];
-                        v[0] += bflo(r4.x); v[1] += bfhi(r4.x); v[2] += bflo(r4.y); v[3] += bfhi(r4.y);
-                        v[4] += bflo(r4.z); v[5] += bfhi(r4.z); v[6] += bflo(r4.w); v[7] += bfhi(r4.w);
+                        v[0] += h16_lo(r4.x); v[1] += h16_hi(r4.x); v[2] += h16_lo(r4.y); v[3] += h16_hi(r4.y);
+                        v[4] += h16_lo(r4.z); v[5] += h16_hi(r4.z); v[6] += h16_lo(r4.w); v[7] += h16_hi(r4.w);
                     }
                     if (ACT) {
 #pragma unroll
@@ -243,11 +243,11 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
                             if (col + e >= n_out) v[e] = 0.f;
                     }
                     uint4 pk;
-                    pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+                    pk.x = pack_h16x2(v[0], v[1]); pk.y = pack_h16x2(v[2], v[3]); pk.z = pack_h16x2(v[4], v[5]); pk.w = pack_h16x2(v[6], v[7]);
                     if (!(ABL & 4)) *(uint4*)(outp + m * p.ldo + col) = pk;
                     else asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
                     if (STATS) {
-                        const float r[8] = {bflo(pk.x), bfhi(pk.x), bflo(pk.y), bfhi(pk.y), bflo(pk.z), bfhi(pk.z), bflo(pk.w), bfhi(pk.w)};
+                        const float r[8] = {h16_lo(pk.x), h16_hi(pk.x), h16_lo(pk.y), h16_hi(pk.y), h16_lo(pk.z), h16_hi(pk.z), h16_lo(pk.w), h16_hi(pk.w)};
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { st_s[e] += r[e]; st_q[e] += r[e] * r[e]; }
                     }
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
         asm volatile("" : "+v"(lane_o));
         const int q = lane_o >> 4, a = lane_o & 15;
         const int n_half = p.N >> 1;
-        bf16_t* outp = (bf16_t*)p.out;
+        h16_t* outp = (h16_t*)p.out;
 #pragma unroll
         for (int ip = 0; ip < FP; ++ip) {
             const f32x4_t bl = *(lds_f4_ptr)(bias_base + (wn * TN + 32 * ip + 8 * q) * 4);
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (col + r >= n_half) v[r] = 0.f;
-                if (!(ABL & 4)) *(uint2*)(outp + (long long)m * p.ldo + col) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+                if (!(ABL & 4)) *(uint2*)(outp + (long long)m * p.ldo + col) = pack_h16x4(v[0], v[1], v[2], v[3]);
             }
         }
     };

@@ -11,7 +11,34 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgenpercept_hip.so")
+# One library per 16-bit element type (csrc/common.h): identical C-ABI, bf16 or IEEE fp16 activations / weights / MFMA operands.
+# "bf16" is the default (BASELINE.json's dtype); "fp16" is the reference's half precision (run.py --half_precision), 8x finer
+# rounding at the same speed -- the build that meets north_star's 1e-3 tolerance (profiles/r02_precision_ablation.json).
+LIB_PATHS = {"bf16": os.path.join(_HERE, "lib", "libgenpercept_hip.so"), "fp16": os.path.join(_HERE, "lib", "libgenpercept_hip_f16.so")}
+LIB_PATH = LIB_PATHS["bf16"]
+ELT_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16}
+_default_precision = "bf16"
+
+
+def set_default_precision(precision: str):
+    """Element type used by the per-kernel wrappers below (tests); engines name theirs explicitly."""
+    global _default_precision
+    assert precision in LIB_PATHS
+    _default_precision = precision
+
+
+def act_dtype(precision: Optional[str] = None) -> torch.dtype:
+    return ELT_DTYPE[precision or _default_precision]
+
+
+def precision_of(dtype) -> str:
+    """torch dtype a caller asks for (from_pretrained(torch_dtype=...), .to(dtype=...)) -> library: bf16 -> bf16, fp16 and fp32 -> fp16
+    (there is no fp32-storage engine; fp16 elements with fp32 accumulation is the closest the matrix cores offer at full rate)."""
+    if dtype is None or dtype == torch.bfloat16:
+        return "bf16"
+    if dtype in (torch.float16, torch.float32):
+        return "fp16"
+    raise ValueError(f"unsupported dtype {dtype}")
 
 GP_OK = 0
 MODES = {"depth": 0, "normal": 1, "seg": 2, "matting": 3, "dis": 4, "disparity": 5}
@@ -42,7 +69,7 @@ class GpTimings(C.Structure):
     ]
 
 
-_lib = None
+_libs: Dict[str, C.CDLL] = {}
 
 # (name, restype, argtypes) for every symbol include/genpercept_hip.h declares
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -52,6 +79,7 @@ SYMBOLS = {
     "gp_destroy": (None, [_vp]),
     "gp_last_error": (C.c_char_p, [_vp]),
     "gp_version": (C.c_char_p, []),
+    "gp_element_dtype": (_i, []),
     "gp_load_tensor": (_i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i, _i]),
     "gp_set_context": (_i, [_vp, _vp, _i, _i]),
     "gp_set_timestep": (_i, [_vp, _f]),
@@ -85,21 +113,23 @@ SYMBOLS = {
 }
 
 
-def load_library(path: Optional[str] = None):
-    """dlopen the HIP library and bind every C-ABI symbol.  Raises (never falls back) when it is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = path or os.environ.get("GENPERCEPT_HIP_LIB", LIB_PATH)
+def load_library(precision: Optional[str] = None, path: Optional[str] = None):
+    """dlopen the HIP library of the given element type and bind every C-ABI symbol.  Raises (never falls back) when it is missing."""
+    precision = precision or _default_precision
+    if precision in _libs and path is None:
+        return _libs[precision]
+    path = path or (os.environ.get("GENPERCEPT_HIP_LIB") if precision == "bf16" else None) or LIB_PATHS[precision]
     if not os.path.exists(path):
         raise ImportError(f"{path} not found: build it with `python -m genpercept_amd.build` (hipcc, gfx950). "
                           "There is no CPU/PyTorch fallback for the inference path.")
-    lib = C.CDLL(path)
+    lib = C.CDLL(path)  # RTLD_LOCAL: the two libraries export the same symbol names
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    if lib.gp_element_dtype() != _DT[ELT_DTYPE[precision]]:
+        raise ImportError(f"{path} is not the {precision} build")
+    _libs[precision] = lib
     return lib
 
 
@@ -114,8 +144,9 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 class Engine:
     """One engine per GPU (not re-entrant).  Mirrors the reference's module handles: weights in, stages out."""
 
-    def __init__(self, device: int = 0, unet_cfg=None, vae_cfg=None, dpt_cfg=None):
-        lib = load_library()
+    def __init__(self, device: int = 0, unet_cfg=None, vae_cfg=None, dpt_cfg=None, precision: str = "bf16"):
+        lib = load_library(precision)
+        self.precision = precision
         if not torch.cuda.is_available():
             raise RuntimeError("genpercept_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU path")
         self.lib = lib
@@ -298,13 +329,16 @@ def _up(x: int, levels: int, ups: int) -> int:
 
 
 # ---- per-kernel wrappers (used by tests/) -----------------------------------------------------------------------------
-def to_nhwc_bf16(x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
-    """[B,C,H,W] float -> contiguous [B,H,W,Cpad] bf16 (zero-padded channels)."""
+def to_nhwc_h16(x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
+    """[B,C,H,W] float -> contiguous [B,H,W,Cpad] in the default library's element type (zero-padded channels)."""
     b, c, h, w = x.shape
     cp = cpad or c
-    out = torch.zeros((b, h, w, cp), dtype=torch.bfloat16, device=x.device)
-    out[..., :c] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    out = torch.zeros((b, h, w, cp), dtype=act_dtype(), device=x.device)
+    out[..., :c] = x.permute(0, 2, 3, 1).to(act_dtype())
     return out.contiguous()
+
+
+to_nhwc_bf16 = to_nhwc_h16  # (name kept for the bf16-era call sites)
 
 
 def pack_weight(w: torch.Tensor, cin_pad: Optional[int] = None, geglu: bool = False, device="cuda") -> torch.Tensor:
@@ -315,7 +349,7 @@ def pack_weight(w: torch.Tensor, cin_pad: Optional[int] = None, geglu: bool = Fa
     cout, cin, ks, _ = w.shape
     cp = cin_pad or ((cin + 63) // 64 * 64)
     rows = lib.gp_packed_rows(cout)
-    out = torch.empty((rows, ks * ks, cp), dtype=torch.bfloat16, device=device)
+    out = torch.empty((rows, ks * ks, cp), dtype=act_dtype(), device=device)
     st = lib.gp_pack_weight(w.data_ptr(), cout, cin, ks, cp, int(geglu), out.data_ptr())
     if st != GP_OK:
         raise RuntimeError(f"gp_pack_weight failed ({st})")
@@ -332,7 +366,7 @@ def conv2d(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
     ho, wo = out_hw if out_hw else (hin, win)
     nout = cout // 2 if act == "geglu" else cout
     nst = n_store or nout
-    out = torch.empty((b, ho, wo, nst), dtype=torch.float32 if out_fp32 else torch.bfloat16, device=x_nhwc.device)
+    out = torch.empty((b, ho, wo, nst), dtype=torch.float32 if out_fp32 else act_dtype(), device=x_nhwc.device)
     st = lib.gp_conv2d(x_nhwc.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), b, hi, wi, cin, cout, ks, stride,
                        pad_t if ks == 3 else 0, pad_l if ks == 3 else 0, ho, wo, uh, uw, ACT[act], nst, int(out_fp32), tile, _stream_ptr())
     if st != GP_OK:
@@ -346,7 +380,7 @@ def conv2d_gn(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, gam
     lib = load_library()
     b, h, w, cin = x_nhwc.shape
     ho, wo = (2 * h, 2 * w) if ups else (h, w)
-    out = torch.empty((b, ho, wo, cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    out = torch.empty((b, ho, wo, cout), dtype=act_dtype(), device=x_nhwc.device)
     st = lib.gp_conv2d_gn(x_nhwc.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), b, h, w, cin, cout, int(ups), ACT[act],
                           gamma.data_ptr(), beta.data_ptr(), groups, eps, int(silu), _stream_ptr())
     if st != GP_OK:
@@ -359,7 +393,7 @@ def rgb_conv_in(rgb: torch.Tensor, w_packed: torch.Tensor, bias, cout: int) -> t
     lib = load_library()
     b, _, h, w = rgb.shape
     rgb = rgb.contiguous()
-    out = torch.empty((b, h, w, cout), dtype=torch.bfloat16, device=rgb.device)
+    out = torch.empty((b, h, w, cout), dtype=act_dtype(), device=rgb.device)
     st = lib.gp_rgb_conv_in(rgb.data_ptr(), int(rgb.dtype == torch.uint8), w_packed.data_ptr(), _ptr(bias), out.data_ptr(), b, h, w, cout, _stream_ptr())
     if st != GP_OK:
         raise RuntimeError(f"gp_rgb_conv_in failed ({st})")
@@ -372,7 +406,7 @@ def conv2d_stats(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, 
     lib = load_library()
     b, h, w, cin = x_nhwc.shape
     ho, wo = (2 * h, 2 * w) if ups else (h, w)
-    out = torch.empty((b, ho, wo, cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    out = torch.empty((b, ho, wo, cout), dtype=act_dtype(), device=x_nhwc.device)
     scale = torch.empty((b, cout), dtype=torch.float32, device=x_nhwc.device)
     shift = torch.empty((b, cout), dtype=torch.float32, device=x_nhwc.device)
     st = lib.gp_conv2d_stats(x_nhwc.data_ptr(), w_packed.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), b, h, w, cin, cout, ks, int(ups),
@@ -393,7 +427,7 @@ def gemm(a: torch.Tensor, bt: torch.Tensor, bias=None, bias_mode: int = 1, resid
     n = bt.shape[1]
     nout = n // 2 if act == "geglu" else n
     nst = n_store or nout
-    out = torch.empty((bsz, m, nst), dtype=torch.float16 if int(out_fp32) == 2 else (torch.float32 if out_fp32 else torch.bfloat16), device=a.device)
+    out = torch.empty((bsz, m, nst), dtype=torch.float16 if int(out_fp32) == 2 else (torch.float32 if out_fp32 else act_dtype()), device=a.device)
     st = lib.gp_gemm(a.data_ptr(), a.stride(1), bt.data_ptr(), bt.stride(1), _ptr(bias), bias_mode, _ptr(residual), nst, out.data_ptr(), nst, m, n,
                      k, n, nst, ACT[act], int(out_fp32), bsz, a.stride(0), bt.stride(0), m * nst, tile, _stream_ptr())
     if st != GP_OK:
@@ -425,7 +459,7 @@ def flash_attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: i
     """q, k: [B,T,C] bf16 (row stride may exceed C); vt: [B,C,Tpad] bf16, zero beyond T."""
     lib = load_library()
     b, t, c = q.shape
-    out = torch.empty((b, t, c), dtype=torch.bfloat16, device=q.device)
+    out = torch.empty((b, t, c), dtype=act_dtype(), device=q.device)
     st = lib.gp_flash_attention(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), b, t, heads, q.stride(1), k.stride(1), vt.shape[2], c,
                                 _stream_ptr())
     if st != GP_OK:
@@ -446,7 +480,7 @@ def cross_attention(q: torch.Tensor, kc: torch.Tensor, vc: torch.Tensor) -> torc
 def softmax_rows(x: torch.Tensor, t: int, scale: float) -> torch.Tensor:
     lib = load_library()
     rows, ld = x.shape
-    out = torch.empty((rows, ld), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty((rows, ld), dtype=act_dtype(), device=x.device)
     if x.dtype == torch.float16:
         st = lib.gp_softmax_rows_f16(x.data_ptr(), out.data_ptr(), rows, t, ld, scale, _stream_ptr())
     else:
@@ -459,7 +493,7 @@ def softmax_rows(x: torch.Tensor, t: int, scale: float) -> torch.Tensor:
 def bilinear(x_nhwc: torch.Tensor, out_hw, align_corners: bool) -> torch.Tensor:
     lib = load_library()
     b, h, w, c = x_nhwc.shape
-    out = torch.empty((b, out_hw[0], out_hw[1], c), dtype=torch.bfloat16, device=x_nhwc.device)
+    out = torch.empty((b, out_hw[0], out_hw[1], c), dtype=act_dtype(), device=x_nhwc.device)
     st = lib.gp_bilinear(x_nhwc.data_ptr(), out.data_ptr(), b, h, w, out_hw[0], out_hw[1], c, int(align_corners), _stream_ptr())
     if st != GP_OK:
         raise RuntimeError(f"gp_bilinear failed ({st})")

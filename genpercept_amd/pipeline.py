@@ -87,7 +87,7 @@ class GenPerceptPipeline:
 
     def __init__(self, unet, vae, scheduler=None, text_encoder=None, tokenizer=None, default_denoising_steps: Optional[int] = 10,
                  default_processing_resolution: Optional[int] = 768, rgb_blending=False, customized_head=None, genpercept_pipeline=True,
-                 device: Union[str, int, torch.device, None] = None):
+                 device: Union[str, int, torch.device, None] = None, torch_dtype: Optional[torch.dtype] = None):
         self.genpercept_pipeline = genpercept_pipeline
         if not genpercept_pipeline:
             raise NotImplementedError("only the one-step archs=genpercept path is implemented (multi-step marigold/rgb_blending are out of scope)")
@@ -112,6 +112,11 @@ class GenPerceptPipeline:
             self.text_embed = self.text_embed.reshape(1, -1, self.text_embed.shape[-1])
             self.text_encoder = None
         self._engine = None
+        # element type of the engine: bf16 (default; BASELINE.json's dtype) or fp16 -- the reference's --half_precision, also used when
+        # fp32 is asked for (run.py's default torch_dtype): there is no fp32-storage engine, fp16 elements + fp32 accumulation is the
+        # most precise build (final maps within 1e-3 of the fp32 path)
+        from .engine import precision_of
+        self._precision = precision_of(torch_dtype)
         self._timestep = None
         self._device = torch.device("cuda", 0) if device is None else torch.device(device if not isinstance(device, int) else f"cuda:{device}")
         self.mode = None
@@ -121,6 +126,7 @@ class GenPerceptPipeline:
     def from_pretrained(cls, checkpoint: str, variant=None, torch_dtype=None, **kwargs):
         """run.py:370-376 call shape: sub-folders unet/, vae/ (+ text_encoder/, tokenizer/) unless passed as kwargs."""
         kw = dict(kwargs)
+        kw.setdefault("torch_dtype", torch_dtype)
         for name in ("unet", "vae"):
             if kw.get(name) is None:
                 kw[name] = os.path.join(checkpoint, name)
@@ -138,6 +144,12 @@ class GenPerceptPipeline:
             if self._engine is not None and dev != self._device:
                 raise RuntimeError("the engine is already bound to " + str(self._device))
             self._device = dev if dev.index is not None else torch.device("cuda", 0)
+        dt = dtype if dtype is not None else (device if isinstance(device, torch.dtype) else None)
+        if dt is not None:
+            from .engine import precision_of
+            if self._engine is not None and precision_of(dt) != self._precision:
+                raise RuntimeError("the engine is already built with " + self._precision + " elements")
+            self._precision = precision_of(dt)
         return self
 
     @property
@@ -146,7 +158,8 @@ class GenPerceptPipeline:
 
     @property
     def dtype(self) -> torch.dtype:
-        return torch.bfloat16  # storage dtype of the engine; accumulation is fp32
+        from .engine import ELT_DTYPE
+        return ELT_DTYPE[self._precision]  # storage / MFMA-operand dtype of the engine; accumulation is fp32
 
     def enable_xformers_memory_efficient_attention(self):  # run.py:382-385 — attention is always flash-style here
         return None
@@ -168,7 +181,7 @@ class GenPerceptPipeline:
             if not any(k.startswith("neck.fusion_stage") for k in head_sd):
                 raise ValueError("unsupported customized_head (genpercept_pipeline.py:483-484)")
             ucfg = gcfg.UNetConfig(**{**ucfg.__dict__, "has_out": False})
-        eng = Engine(self._device.index or 0, ucfg, vcfg, dcfg)
+        eng = Engine(self._device.index or 0, ucfg, vcfg, dcfg, precision=self._precision)
         eng.load_state_dict("vae", vae_sd)
         eng.load_state_dict("unet", {k: v for k, v in unet_sd.items() if not (dcfg and (k.startswith("conv_out") or k.startswith("conv_norm_out")))})
         if head_sd is not None:

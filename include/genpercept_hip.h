@@ -73,6 +73,10 @@ gp_status gp_create(const gp_config* cfg, gp_engine** out);
 void gp_destroy(gp_engine* e);
 const char* gp_last_error(const gp_engine* e);
 const char* gp_version(void);
+/* Storage / MFMA-operand element of THIS library: GP_DT_BF16 (libgenpercept_hip.so) or GP_DT_F16 (libgenpercept_hip_f16.so, the
+ * reference's half precision: run.py --half_precision / torch_dtype=torch.float16).  Per-kernel entry points take and return
+ * tensors of this element type; stage-level entry points are fp32 at the boundary in both libraries. */
+gp_dtype gp_element_dtype(void);
 
 /* One call per state-dict entry.  `name` = "<module>.<diffusers key>" with module in {vae, unet, dpt}.  The engine copies
  * (and converts to fp32); the caller keeps ownership of host_ptr. */

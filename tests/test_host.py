@@ -16,22 +16,25 @@ def test_library_exports_every_header_symbol():
     import __graft_entry__ as ge
     ge.build()
     from genpercept_amd import engine
-    lib = engine.load_library()
     hdr = open(os.path.join(ROOT, "include", "genpercept_hip.h")).read()
     declared = set(re.findall(r"\b(gp_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations found"
     assert declared == set(engine.SYMBOLS), declared ^ set(engine.SYMBOLS)
-    for name in declared:
-        assert hasattr(lib, name), name
-    assert lib.gp_version().startswith(b"genpercept_hip")
+    for prec, code in (("fp16", 1), ("bf16", 2)):  # both element-type builds carry the whole C-ABI
+        lib = engine.load_library(prec)
+        for name in declared:
+            assert hasattr(lib, name), (prec, name)
+        assert lib.gp_version().startswith(b"genpercept_hip") and prec.encode() in lib.gp_version()
+        assert lib.gp_element_dtype() == code
     assert lib.gp_packed_rows(320) == 512 and lib.gp_latent_size(768) == 96 and lib.gp_latent_size(511) == 63
     assert lib.gp_dpt_out_size(96) == 768 and lib.gp_dpt_out_size(9) == 96
 
 
 def test_library_contains_gfx950_code_objects():
     from genpercept_amd import engine
-    blob = open(engine.LIB_PATH, "rb").read()
-    assert b"gfx950" in blob and b"igemm_kernel" in blob and b"flash_attn64_kernel" in blob
+    for path in engine.LIB_PATHS.values():
+        blob = open(path, "rb").read()
+        assert b"gfx950" in blob and b"igemm_kernel" in blob and b"flash_attn64_kernel" in blob
 
 
 def test_default_config_is_sd21():

@@ -3,7 +3,8 @@ the same op evaluated on the same bf16-rounded operands.
 
 Tolerances (written here, used below):
   * bf16 output of an fp32-accumulated kernel: one rounding to bf16 => relative error <= 2^-8 per element; we require
-    max|err| <= 1.2e-2 * max|ref| and mean|err| <= 2e-3 * mean|ref|   (TOL_BF16)
+    max|err| <= 1.2e-2 * max|ref| and mean|err| <= 2e-3 * mean|ref|   (TOL_BF16); the fp16-element library (11 significant
+    bits) is held to 1/8 of both
   * fp32 output: accumulation-order differences only => max|err| <= 2e-4 * max|ref|                      (TOL_F32)
 """
 import math
@@ -28,8 +29,22 @@ def _eng():
     return engine
 
 
-def rbf(x):  # round to bf16 and back: the kernels see exactly these values
-    return x.to(torch.bfloat16).float()
+@pytest.fixture(autouse=True, params=["bf16", "fp16"])
+def precision(request):
+    """Every kernel test runs against both libraries: bf16 elements (libgenpercept_hip.so) and fp16 elements (libgenpercept_hip_f16.so)."""
+    from genpercept_amd import engine
+    engine.set_default_precision(request.param)
+    yield request.param
+    engine.set_default_precision("bf16")
+
+
+def rbf(x):  # round to the library's 16-bit element and back: the kernels see exactly these values
+    return x.to(_eng().act_dtype()).float()
+
+
+def _tol16():
+    """bf16: one rounding to 8 significant bits; fp16: 11 bits => 8x tighter."""
+    return TOL_BF16 if _eng().act_dtype() == torch.bfloat16 else (TOL_BF16[0] / 8, TOL_BF16[1] / 8)
 
 
 def check(name, out, ref, log, fp32=False):
@@ -40,12 +55,13 @@ def check(name, out, ref, log, fp32=False):
     err = (out - ref).abs()
     mx, mean = err.max().item(), err.mean().item()
     rmx, rmean = ref.abs().max().item() + 1e-12, ref.abs().mean().item() + 1e-12
-    log(name, max_err=mx, mean_err=mean, ref_max=rmx, ref_mean=rmean, rel_max=mx / rmx, rel_mean=mean / rmean)
+    log(name + ("" if _eng().act_dtype() == torch.bfloat16 else "[fp16]"), max_err=mx, mean_err=mean, ref_max=rmx, ref_mean=rmean, rel_max=mx / rmx, rel_mean=mean / rmean)
     if fp32:
         assert mx <= TOL_F32 * rmx, f"{name}: max err {mx:.3e} vs ref max {rmx:.3e}"
     else:
-        assert mx <= TOL_BF16[0] * rmx, f"{name}: max err {mx:.3e} vs ref max {rmx:.3e}"
-        assert mean <= TOL_BF16[1] * rmean + 1e-6, f"{name}: mean err {mean:.3e} vs ref mean {rmean:.3e}"
+        t = _tol16()
+        assert mx <= t[0] * rmx, f"{name}: max err {mx:.3e} vs ref max {rmx:.3e}"
+        assert mean <= t[1] * rmean + 1e-6, f"{name}: mean err {mean:.3e} vs ref mean {rmean:.3e}"
 
 
 def nhwc_to_nchw(y, c=None):
@@ -266,10 +282,10 @@ def test_gemm_bias_residual(case, metric_log):
     bias = torch.randn(n, generator=g)
     res = rbf(torch.randn(m, n, generator=g))
     d = _dev()
-    ad, bd = a.to(d).to(torch.bfloat16), bt.to(d).to(torch.bfloat16)
+    ad, bd = a.to(d).to(_eng().act_dtype()), bt.to(d).to(_eng().act_dtype())
     nst = (n + 3) // 4 * 4
-    resd = torch.zeros(m, nst, dtype=torch.bfloat16, device=d)
-    resd[:, :n] = res.to(d).to(torch.bfloat16)
+    resd = torch.zeros(m, nst, dtype=_eng().act_dtype(), device=d)
+    resd[:, :n] = res.to(d).to(_eng().act_dtype())
     y = e.gemm(ad, bd, bias=bias.to(d), residual=resd, n_store=nst, tile=tile)
     check(f"gemm{case}", y[:, :n], a @ bt.t() + bias + res, metric_log)
     y32 = e.gemm(ad, bd, out_fp32=True, n_store=nst, tile=tile)
@@ -291,8 +307,8 @@ def test_gemm_row_bias_batched_zero_fill(metric_log):
     bias = torch.randn(c, generator=g)
     d = _dev()
     lib = e.load_library()
-    out = torch.full((bsz, c, tpad), 7.0, dtype=torch.bfloat16, device=d)
-    wd, xd, bd = wv.to(d).to(torch.bfloat16), x.to(d).to(torch.bfloat16), bias.to(d)
+    out = torch.full((bsz, c, tpad), 7.0, dtype=_eng().act_dtype(), device=d)
+    wd, xd, bd = wv.to(d).to(_eng().act_dtype()), x.to(d).to(_eng().act_dtype()), bias.to(d)
     st = lib.gp_gemm(wd.data_ptr(), c, xd.data_ptr(), c, bd.data_ptr(), 2, None, 0, out.data_ptr(), tpad, c, t, c, t, tpad, 0, 0, bsz, 0, t * c, c * tpad, 0,
                      torch.cuda.current_stream().cuda_stream)
     assert st == 0
@@ -322,7 +338,7 @@ def test_gemm_geglu(mc, metric_log):
     dst = (r // 16) * 32 + ((r % 16) // 4) * 8 + (idx >= half).long() * 4 + (r % 4)
     pb = torch.empty_like(bias)
     pb[dst] = bias
-    y = e.conv2d(a.to(d).to(torch.bfloat16).reshape(1, 1, m, c), wp, pb.to(d), 8 * c, 1, act="geglu")
+    y = e.conv2d(a.to(d).to(_eng().act_dtype()).reshape(1, 1, m, c), wp, pb.to(d), 8 * c, 1, act="geglu")
     check(f"gemm_geglu{mc}", y.reshape(m, 4 * c), ref, metric_log)
 
 
@@ -352,7 +368,7 @@ def test_layernorm(case, metric_log):
     x = rbf(torch.randn(rows, c, generator=g) * 3 - 1)
     gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.3 * torch.randn(c, generator=g)
     d = _dev()
-    y = e.layernorm(x.to(d).to(torch.bfloat16), gamma.to(d), beta.to(d))
+    y = e.layernorm(x.to(d).to(_eng().act_dtype()), gamma.to(d), beta.to(d))
     check(f"layernorm{case}", y, F.layer_norm(x, (c,), gamma, beta, 1e-5), metric_log)
 
 
@@ -376,9 +392,9 @@ def test_flash_attention_hd64(case, metric_log):
     ref = _attn_ref(q, k, v, heads)
     d = _dev()
     tpad = (t + 63) // 64 * 64
-    vt = torch.zeros(b, c, tpad, dtype=torch.bfloat16, device=d)
-    vt[:, :, :t] = v.transpose(1, 2).to(d).to(torch.bfloat16)
-    qkd = qk.to(d).to(torch.bfloat16)
+    vt = torch.zeros(b, c, tpad, dtype=_eng().act_dtype(), device=d)
+    vt[:, :, :t] = v.transpose(1, 2).to(d).to(_eng().act_dtype())
+    qkd = qk.to(d).to(_eng().act_dtype())
     y = e.flash_attention(qkd[..., :c], qkd[..., c:], vt, heads)
     check(f"flash64{case}", y, ref, metric_log)
 
@@ -394,9 +410,9 @@ def test_flash_attention_spiky_scores(metric_log):
     v = rbf(torch.randn(b, t, c, generator=g))
     ref = _attn_ref(q, k, v, heads)
     d = _dev()
-    vt = torch.zeros(b, c, 320, dtype=torch.bfloat16, device=d)
-    vt[:, :, :t] = v.transpose(1, 2).to(d).to(torch.bfloat16)
-    y = e.flash_attention(q.to(d).to(torch.bfloat16).contiguous(), k.to(d).to(torch.bfloat16).contiguous(), vt, heads)
+    vt = torch.zeros(b, c, 320, dtype=_eng().act_dtype(), device=d)
+    vt[:, :, :t] = v.transpose(1, 2).to(d).to(_eng().act_dtype())
+    y = e.flash_attention(q.to(d).to(_eng().act_dtype()).contiguous(), k.to(d).to(_eng().act_dtype()).contiguous(), vt, heads)
     check("flash64_spiky", y, ref, metric_log)
 
 
@@ -409,7 +425,7 @@ def test_cross_attention_small(L, metric_log):
     kc, vc = torch.randn(L, c, generator=g), torch.randn(L, c, generator=g)
     ref = _attn_ref(q[None], kc[None], vc[None], c // 64)[0]
     d = _dev()
-    y = e.cross_attention(q.to(d).to(torch.bfloat16), kc.to(d), vc.to(d))
+    y = e.cross_attention(q.to(d).to(_eng().act_dtype()), kc.to(d), vc.to(d))
     check(f"cross_attn_L{L}", y, ref, metric_log)
 
 
