@@ -142,6 +142,9 @@ struct TfW {
     float* kc = nullptr;  // folded cross-attention keys / values [L][C] fp32
     float* vc = nullptr;
     std::vector<float> wk_h, wv_h;  // attn2.to_k / to_v [C][D]
+    // two-token context: the whole attn2 branch folded into per-head vectors (norm.hip: cross_fold_kernel); null when L != 2
+    float *fU = nullptr, *fu0 = nullptr, *fG = nullptr, *fc0 = nullptr;
+    std::vector<float> wq2_h, wo2_h, bo2_h, ln2g_h, ln2b_h;  // attn2.to_q / to_out.0, norm2 (host copies for the fold)
     int C = 0, heads = 0;
 };
 struct VaeAttnW {
@@ -322,6 +325,11 @@ struct gp_engine {
         t.proj_out = pack_named(p + ".proj_out", 1);
         t.wk_h = H(b + ".attn2.to_k.weight").v;
         t.wv_h = H(b + ".attn2.to_v.weight").v;
+        t.wq2_h = H(b + ".attn2.to_q.weight").v;
+        t.wo2_h = H(b + ".attn2.to_out.0.weight").v;
+        t.bo2_h = H(b + ".attn2.to_out.0.bias").v;
+        t.ln2g_h = H(b + ".norm2.weight").v;
+        t.ln2b_h = H(b + ".norm2.bias").v;
         tfs[p] = std::move(t);
     }
     void build_vae_attn(const std::string& p) {
@@ -390,6 +398,37 @@ struct gp_engine {
                 }
             t.kc = upload(kc.data(), kc.size());
             t.vc = upload(vc.data(), vc.size());
+            t.fU = t.fu0 = t.fG = t.fc0 = nullptr;
+            if (L == 2 && !getenv("GENPERCEPT_NO_CROSS_FOLD")) {
+                // softmax over two keys = sigmoid of the logit difference; see cross_fold_kernel (norm.hip) for the algebra
+                const int hd = 64, nh = t.heads;
+                std::vector<float> U((size_t)nh * C), u0(nh), G((size_t)nh * C), c0(C);
+                for (int h = 0; h < nh; ++h) {
+                    double b0 = 0;
+                    for (int c = 0; c < C; ++c) {
+                        double a = 0;
+                        for (int j = h * hd; j < (h + 1) * hd; ++j) a += (double)t.wq2_h[(size_t)j * C + c] * ((double)kc[j] - (double)kc[(size_t)C + j]);
+                        a *= 0.125;  // 1 / sqrt(head_dim)
+                        U[(size_t)h * C + c] = (float)(a * t.ln2g_h[c]);
+                        b0 += a * t.ln2b_h[c];
+                    }
+                    u0[h] = (float)b0;
+                }
+                for (int c = 0; c < C; ++c) {
+                    double a = t.bo2_h[c];
+                    for (int j = 0; j < C; ++j) a += (double)t.wo2_h[(size_t)c * C + j] * vc[(size_t)C + j];
+                    c0[c] = (float)a;
+                    for (int h = 0; h < nh; ++h) {
+                        double g = 0;
+                        for (int j = h * hd; j < (h + 1) * hd; ++j) g += (double)t.wo2_h[(size_t)c * C + j] * ((double)vc[j] - (double)vc[(size_t)C + j]);
+                        G[(size_t)h * C + c] = (float)g;
+                    }
+                }
+                t.fU = upload(U.data(), U.size());
+                t.fu0 = upload(u0.data(), u0.size());
+                t.fG = upload(G.data(), G.size());
+                t.fc0 = upload(c0.data(), c0.size());
+            }
         }
     }
 
@@ -800,17 +839,24 @@ struct gp_engine {
         linear(a, t.o1, y.p, GP_ACT_NONE, y.p);  // y += to_out(attn), in place
         drop(a);
         // cross-attention against the folded constant context
-        Act l2 = layernorm(y, t.ln2);
-        Act q2 = linear(l2, t.q2);
-        drop(l2);
-        Act a2 = new_act(x.B, x.H, x.W, C);
-        mark("cross_attn_small " + dims(q2));
-        launch_cross_attn_small(q2.p, t.kc, t.vc, a2.p, (int)x.pixels(), C, ctx_L, st);
-        drop(q2);
-        linear(a2, t.o2, y.p, GP_ACT_NONE, y.p);
-        drop(a2);
+        Act l3;
+        if (t.fU) {  // two context tokens: LayerNorm + to_q + attention + to_out + residual + the feed-forward's LayerNorm in ONE pass
+            l3 = new_act(x.B, x.H, x.W, C);
+            mark("cross_attn_fold " + dims(y));
+            launch_cross_attn_fold(y.p, y.p, l3.p, t.fU, t.fu0, t.fG, t.fc0, t.ln3.g, t.ln3.b, (int)x.pixels(), C, t.heads, 1e-5f, st);
+        } else {
+            Act l2 = layernorm(y, t.ln2);
+            Act q2 = linear(l2, t.q2);
+            drop(l2);
+            Act a2 = new_act(x.B, x.H, x.W, C);
+            mark("cross_attn_small " + dims(q2));
+            launch_cross_attn_small(q2.p, t.kc, t.vc, a2.p, (int)x.pixels(), C, ctx_L, st);
+            drop(q2);
+            linear(a2, t.o2, y.p, GP_ACT_NONE, y.p);
+            drop(a2);
+            l3 = layernorm(y, t.ln3);
+        }
         // GEGLU feed-forward
-        Act l3 = layernorm(y, t.ln3);
         Act ff = linear(l3, t.ff1, nullptr, GP_ACT_GEGLU);
         drop(l3);
         linear(ff, t.ff2, y.p, GP_ACT_NONE, y.p);
@@ -1577,6 +1623,13 @@ gp_status gp_flash_attention(const void* q, const void* k, const void* vt, void*
 gp_status gp_cross_attention(const void* q, const float* kc, const float* vc, void* out, int rows, int C, int L, void* stream) {
     if (!q || !kc || !vc || !out || (C % 64)) return GP_ERR_INVALID;
     launch_cross_attn_small((const h16_t*)q, kc, vc, (h16_t*)out, rows, C, L, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
+}
+
+gp_status gp_cross_attention_fold(const void* y, void* y_out, void* n3_out, const float* U, const float* u0, const float* G, const float* c0,
+                                  const float* g3, const float* b3, int rows, int C, int heads, float eps, void* stream) {
+    if (!y || !y_out || !U || !u0 || !G || !c0 || (C % 8) || C > 1536 || heads < 1 || (n3_out && (!g3 || !b3))) return GP_ERR_INVALID;
+    launch_cross_attn_fold((const h16_t*)y, (h16_t*)y_out, (h16_t*)n3_out, U, u0, G, c0, g3, b3, rows, C, heads, eps, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
 }
 

@@ -88,6 +88,11 @@ void launch_flash_attn64(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t*
 // Cross-attention against a small constant context: q [rows][C] bf16, kc/vc [L][C] fp32, head_dim 64.
 void launch_cross_attn_small(const h16_t* q, const float* kc, const float* vc, h16_t* out, int rows, int C, int L, hipStream_t s);
 
+// Cross-attention against a 2-token constant context folded into per-head vectors (norm.hip): y_out = y + c0 + sum_h sigmoid(LNhat(y) . U[h]
+// + u0[h]) G[h]; optionally n3_out = LayerNorm(y_out; g3, b3).  U, G: [heads][C] fp32; u0 [heads]; c0, g3, b3 [C].  C <= 1536.
+void launch_cross_attn_fold(const h16_t* y, h16_t* y_out, h16_t* n3_out, const float* U, const float* u0, const float* G, const float* c0,
+                            const float* g3, const float* b3, int rows, int C, int heads, float eps, hipStream_t s);
+
 // Row softmax: in fp32 [rows][ld] (first T columns valid) -> bf16 [rows][ld], columns >= T written as 0.
 void launch_softmax_rows(const float* in, h16_t* out, int rows, int T, int ld, float scale, hipStream_t s);
 bool softmax_rows_f16_supported(int ld);

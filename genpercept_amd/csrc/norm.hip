@@ -310,3 +310,169 @@ void launch_layernorm(const h16_t* x, h16_t* y, const float* gamma, const float*
     else if (vpt <= 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, y, gamma, beta, rows, C, eps);
     else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, x, y, gamma, beta, rows, C, eps);
 }
+
+// ---- cross-attention against a TWO-token constant context, folded (GenPercept's empty prompt: BOS, EOS) -----------------
+// With two keys the softmax is a sigmoid of the logit difference, and both projections around it collapse into per-head vectors:
+//   d_h   = LN2(y) . (Wq_h^T (k0 - k1)_h) / 8            = yhat . U[h] + u0[h]        (LayerNorm affine folded into U, u0)
+//   attn2 = v1 + sigmoid(d_h) (v0 - v1)_h  ->  to_out:    o = c0 + sum_h sigmoid(d_h) G[h],   c0 = Wo v1 + bo,  G[h] = Wo[:, h] (v0 - v1)_h
+// so   y <- y + c0 + sum_h sigmoid(yhat . U[h] + u0[h]) G[h]   replaces LayerNorm, the to_q GEMM, the attention and the to_out GEMM
+// (custom_unet.py / BasicTransformerBlock attn2, genpercept_pipeline.py:425-429) -- exactly, in fp32, with the row in registers.  The
+// kernel also emits LN3 of the row it just stored (the input of the feed-forward GEMM), saving that pass too.  HBM-bound: 6 B / element.
+// One wave handles R rows at a time (the U / G rows it streams from L2 are reused R times); lane owns 8-channel vectors lane + 64 u.
+template <int VPT, int R>
+__global__ __launch_bounds__(256) void cross_fold_kernel(const h16_t* __restrict__ y, h16_t* __restrict__ y_out, h16_t* __restrict__ n3_out,
+                                                          const float* __restrict__ U, const float* __restrict__ u0, const float* __restrict__ G,
+                                                          const float* __restrict__ c0, const float* __restrict__ g3, const float* __restrict__ b3,
+                                                          int rows, int C, int heads, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
+    const int nvec = C >> 3;
+    const float invC = 1.f / (float)C;
+    float v[R][VPT][8];
+    // ---- load, LayerNorm statistics (exact two-pass, row in registers)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) {
+            const int vi = lane + u * 64;
+            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+            if (vi < nvec && row0 + r < rows) raw = *(const uint4*)(y + (long long)(row0 + r) * C + vi * 8);
+            const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[r][u][2 * k] = h16_lo(w[k]); v[r][u][2 * k + 1] = h16_hi(w[k]); }
+        }
+    float mean[R], rstd[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < VPT; ++u)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[r][u][k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        mean[r] = s * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int u = 0; u < VPT; ++u)
+            if (lane + u * 64 < nvec) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float d = v[r][u][k] - mean[r]; q += d * d; }
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        rstd[r] = rsqrtf(q * invC + eps);
+    }
+    // ---- out accumulators start as y + c0; the per-head logits use yhat = (y - mean) rstd on the fly
+    float acc[R][VPT][8];
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int vi = lane + u * 64;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (vi < nvec) { a = *(const float4*)(c0 + vi * 8); b = *(const float4*)(c0 + vi * 8 + 4); }
+        const float cc[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[r][u][k] = v[r][u][k] + cc[k];
+    }
+    for (int h = 0; h < heads; ++h) {
+        float d[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) d[r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) {
+            const int vi = lane + u * 64;
+            if (vi < nvec) {
+                const float4 a = *(const float4*)(U + (long long)h * C + vi * 8), b = *(const float4*)(U + (long long)h * C + vi * 8 + 4);
+                const float uu[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) d[r] += (v[r][u][k] - mean[r]) * uu[k];
+            }
+        }
+        float p[R];
+        const float uh = u0[h];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float t = d[r];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+            p[r] = __builtin_amdgcn_rcpf(1.f + __expf(-(t * rstd[r] + uh)));
+        }
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) {
+            const int vi = lane + u * 64;
+            if (vi < nvec) {
+                const float4 a = *(const float4*)(G + (long long)h * C + vi * 8), b = *(const float4*)(G + (long long)h * C + vi * 8 + 4);
+                const float gg[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[r][u][k] += p[r] * gg[k];
+            }
+        }
+    }
+    // ---- store the new trunk row, then LN3 of the values AS STORED (what a separate LayerNorm pass would read)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) {
+            const int vi = lane + u * 64;
+            uint4 pk;
+            pk.x = pack_h16x2(acc[r][u][0], acc[r][u][1]); pk.y = pack_h16x2(acc[r][u][2], acc[r][u][3]);
+            pk.z = pack_h16x2(acc[r][u][4], acc[r][u][5]); pk.w = pack_h16x2(acc[r][u][6], acc[r][u][7]);
+            if (vi < nvec && row0 + r < rows) *(uint4*)(y_out + (long long)(row0 + r) * C + vi * 8) = pk;
+            const unsigned w[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[r][u][2 * k] = h16_lo(w[k]); acc[r][u][2 * k + 1] = h16_hi(w[k]); }
+            if (vi < nvec) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += acc[r][u][k];
+            }
+        }
+        if (!n3_out) continue;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float m3 = s * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int u = 0; u < VPT; ++u)
+            if (lane + u * 64 < nvec) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float d = acc[r][u][k] - m3; q += d * d; }
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float r3 = rsqrtf(q * invC + eps);
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) {
+            const int vi = lane + u * 64;
+            if (vi < nvec && row0 + r < rows) {
+                const float4 ga = *(const float4*)(g3 + vi * 8), gb = *(const float4*)(g3 + vi * 8 + 4);
+                const float4 ba = *(const float4*)(b3 + vi * 8), bb = *(const float4*)(b3 + vi * 8 + 4);
+                const float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w}, bt[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+                float o8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o8[k] = (acc[r][u][k] - m3) * r3 * gg[k] + bt[k];
+                uint4 pk;
+                pk.x = pack_h16x2(o8[0], o8[1]); pk.y = pack_h16x2(o8[2], o8[3]); pk.z = pack_h16x2(o8[4], o8[5]); pk.w = pack_h16x2(o8[6], o8[7]);
+                *(uint4*)(n3_out + (long long)(row0 + r) * C + vi * 8) = pk;
+            }
+        }
+    }
+}
+
+// y_out may alias y (a wave reads its rows completely before it writes them); n3_out optional.  C % 8 == 0, C <= 1536.
+void launch_cross_attn_fold(const h16_t* y, h16_t* y_out, h16_t* n3_out, const float* U, const float* u0, const float* G, const float* c0,
+                            const float* g3, const float* b3, int rows, int C, int heads, float eps, hipStream_t s) {
+    const int vpt = (C / 8 + 63) / 64;
+    constexpr int R = 4;
+    dim3 grid((rows + 4 * R - 1) / (4 * R));
+    if (vpt <= 1) hipLaunchKernelGGL((cross_fold_kernel<1, R>), grid, dim3(256), 0, s, y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, heads, eps);
+    else if (vpt <= 2) hipLaunchKernelGGL((cross_fold_kernel<2, R>), grid, dim3(256), 0, s, y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, heads, eps);
+    else hipLaunchKernelGGL((cross_fold_kernel<3, R>), grid, dim3(256), 0, s, y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, heads, eps);
+}

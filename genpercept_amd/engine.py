@@ -107,6 +107,7 @@ SYMBOLS = {
     "gp_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "gp_flash_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "gp_cross_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "gp_cross_attention_fold": (_i, [_vp] * 9 + [_i, _i, _i, _f, _vp]),
     "gp_softmax_rows": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "gp_softmax_rows_f16": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "gp_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -475,6 +476,19 @@ def cross_attention(q: torch.Tensor, kc: torch.Tensor, vc: torch.Tensor) -> torc
     if st != GP_OK:
         raise RuntimeError(f"gp_cross_attention failed ({st})")
     return out
+
+
+def cross_attention_fold(y: torch.Tensor, U: torch.Tensor, u0: torch.Tensor, G: torch.Tensor, c0: torch.Tensor, g3: torch.Tensor, b3: torch.Tensor,
+                         eps: float = 1e-5):
+    """y [rows, C] (16-bit elements); returns (y_out, LayerNorm(y_out)).  See gp_cross_attention_fold."""
+    lib = load_library()
+    rows, c = y.shape
+    y_out, n3 = torch.empty_like(y), torch.empty_like(y)
+    st = lib.gp_cross_attention_fold(y.data_ptr(), y_out.data_ptr(), n3.data_ptr(), U.data_ptr(), u0.data_ptr(), G.data_ptr(), c0.data_ptr(),
+                                     g3.data_ptr(), b3.data_ptr(), rows, c, U.shape[0], eps, _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_cross_attention_fold failed ({st})")
+    return y_out, n3
 
 
 def softmax_rows(x: torch.Tensor, t: int, scale: float) -> torch.Tensor:

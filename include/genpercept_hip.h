@@ -145,6 +145,11 @@ gp_status gp_layernorm(const void* x, void* y, const float* gamma, const float* 
 gp_status gp_flash_attention(const void* q, const void* k, const void* vt, void* out, int B, int T, int heads, int ldq, int ldk, int Tpad, int ldo,
                              void* stream);
 gp_status gp_cross_attention(const void* q, const float* kc, const float* vc, void* out, int rows, int C, int L, void* stream);
+/* BasicTransformerBlock.attn2 (+ norm2, + residual, + norm3 of the result) for a TWO-token context, folded into per-head vectors
+ * (gp_set_context does the fold for the engine; csrc/norm.hip states the algebra): y_out = y + c0 + sum_h sigmoid(LNhat(y) . U[h] + u0[h]) G[h],
+ * n3_out = LayerNorm(y_out; g3, b3) (optional).  U, G: [heads][C] fp32, u0 [heads], c0 / g3 / b3 [C]; y_out may alias y. */
+gp_status gp_cross_attention_fold(const void* y, void* y_out, void* n3_out, const float* U, const float* u0, const float* G, const float* c0,
+                                  const float* g3, const float* b3, int rows, int C, int heads, float eps, void* stream);
 gp_status gp_softmax_rows(const float* in, void* out, int rows, int T, int ld, float scale, void* stream);
 /* the same for fp16 logits (gp_gemm with out_fp32 = 2 writes them): ld % 4 == 0, ld <= 16384 */
 gp_status gp_softmax_rows_f16(const void* in_f16, void* out, int rows, int T, int ld, float scale, void* stream);

@@ -501,3 +501,34 @@ def test_heaviest_layers_batch4_vs_fp32(case, metric_log):
             xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
         ref = F.conv2d(xi, wt, bias, padding=1)
     check(f"heavy_b4{case}", yc, ref, metric_log)
+
+
+@pytest.mark.parametrize("case", [(150, 320, 5), (37, 640, 10), (64, 1280, 20), (5, 192, 3)])
+def test_cross_attention_two_token_fold(case, metric_log):
+    """attn2 of the BasicTransformerBlock against a 2-token context (GenPercept's empty prompt, genpercept_pipeline.py:425-429) folded into
+    per-head vectors: the kernel must equal LayerNorm -> to_q -> softmax(q k^T / 8) v -> to_out -> + residual, then norm3, computed
+    the long way in fp32 (oracle/sd21.transformer_2d's attn2 lines).  The fold is redone here in float64, independently of the engine's."""
+    e = _eng()
+    rows, c, heads = case
+    g = torch.Generator().manual_seed(rows + c)
+    y = rbf(torch.randn(rows, c, generator=g) * 1.5 + 0.3)
+    wq, wo = torch.randn(c, c, generator=g) / math.sqrt(c), torch.randn(c, c, generator=g) / math.sqrt(c)
+    bo = 0.1 * torch.randn(c, generator=g)
+    kc, vc = torch.randn(2, c, generator=g), torch.randn(2, c, generator=g)
+    g2, b2 = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    g3, b3 = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    n2 = F.layer_norm(y, (c,), g2, b2, 1e-5)
+    q = (n2 @ wq.t()).view(rows, heads, 64)
+    w = torch.softmax(torch.einsum("rhd,lhd->rhl", q, kc.view(2, heads, 64)) / 8.0, dim=-1)
+    a = torch.einsum("rhl,lhd->rhd", w, vc.view(2, heads, 64)).reshape(rows, c)
+    ref_y = y + a @ wo.t() + bo
+    ref_n3 = F.layer_norm(rbf(ref_y), (c,), g3, b3, 1e-5)  # norm3 reads the trunk as stored
+    dk, dv = (kc[0] - kc[1]).double(), (vc[0] - vc[1]).double()
+    A = torch.stack([(wq.double()[h * 64:(h + 1) * 64] * dk[h * 64:(h + 1) * 64, None]).sum(0) for h in range(heads)]) / 8.0  # [heads][C]
+    U, u0 = (A * g2.double()).float(), (A @ b2.double()).float()
+    c0 = (wo.double() @ vc[1].double() + bo.double()).float()
+    G = torch.stack([wo.double()[:, h * 64:(h + 1) * 64] @ dv[h * 64:(h + 1) * 64] for h in range(heads)]).float()
+    d = _dev()
+    yo, n3 = e.cross_attention_fold(y.to(d).to(e.act_dtype()), U.to(d).contiguous(), u0.to(d), G.to(d).contiguous(), c0.to(d), g3.to(d), b3.to(d))
+    check(f"cross_fold_y{case}", yo, ref_y, metric_log)
+    check(f"cross_fold_n3{case}", n3, ref_n3, metric_log)
