@@ -1,22 +1,26 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec of the one-step GenPercept path (depth head: SD2.1 VAE encoder -> UNet (t=1) -> VAE
-decoder) at 768x768, bf16 storage / fp32 accumulate, batch 4 per GPU, synthetic RGB resident in HBM, random-init weights
+decoder) at 768x768, bf16 elements / fp32 accumulate, batch 4 per GPU, synthetic RGB resident in HBM, random-init weights
 of the exact SD2.1 architecture (BASELINE.json configs[1]; no checkpoints exist offline).
 
   python bench.py --gpus 1 --steps 5 --warmup 2
+  python bench.py --gpus 8 ...                     # spawns its own 8 ranks (re-executes itself under torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch per GPU (gp_infer).  N > 1: one process per GPU, the batch of
-N*B independent images is sharded contiguously, weights replicated, no collective on the data path ("weak" scaling).
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the implicit-GEMM conv/linear MFMA kernel):
-algorithmic flops of its launches / their summed duration, measured with HIP events on the engine's stream in a separate
-instrumented pass right after the timed region (events around ~330 launches would perturb the timed region itself).
-`cpu_baseline` = the fp32 oracle (oracle/, a restatement: kind "port") on the host cores, rank 0, N == 1 only, on a
-bounded sample (one 384x384 image = BASELINE.json configs[0], 32 threads) so the default run stays within minutes.
+One "step" = one pass of the hot path over one batch per GPU (gp_infer).  N > 1: one process per GPU, the batch of N*B
+independent images is sharded contiguously, weights replicated, no collective on the data path ("weak" scaling); the step
+then ends with the optional result gather of BASELINE.json configs[4] (RCCL gather of the fp32 maps to rank 0 over xGMI),
+inside the timed region, its own cost reported as `gather_ms`.  Rank 0 prints ONE JSON line.
+  roofline     the dominant kernel, conv3x3_halo3_kernel: algorithmic flops of its launches / their summed duration, from HIP events
+               on the engine's stream in an instrumented pass right after the timed region (events around ~300 launches would perturb
+               the timed region itself); `family_*` = the whole implicit-GEMM conv / linear family; `peak` = the nominal 2.5 PFLOP/s,
+               `peak_measured` = this chip's own back-to-back-MFMA rate (gp_mfma_peak_tflops) measured in the same run.
+  cpu_baseline the fp32 oracle (oracle/, a restatement: kind "port") timed on the host cores at the benched size: ONE 768x768 image.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -27,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 TFLOP_PER_IMAGE_768_DPT = 5.473  # VAE-enc 2.609 + UNet 2.137 + DPT head 0.726
 TFLOP_PER_IMAGE_768 = 10.50  # VAE-enc 2.609 + UNet 2.137 + VAE-dec 5.754 (2*MAC of conv/linear/QK^T/PV)
-PEAK_BF16_TFLOPS = 2500.0    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0    # MI355X dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)
 
 
 def synthetic_rgb(batch: int, res: int, seed: int, device) -> torch.Tensor:
@@ -36,6 +40,26 @@ def synthetic_rgb(batch: int, res: int, seed: int, device) -> torch.Tensor:
     yy, xx = torch.meshgrid(torch.linspace(0, 1, res), torch.linspace(0, 1, res), indexing="ij")
     smooth = torch.stack([yy, xx, (yy + xx) / 2])[None] * 255.0
     return (0.5 * noise + 0.5 * smooth).round().clamp(0, 255).to(torch.uint8).to(device)
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def respawn_under_torchrun(n: int):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
 
 
 def main():
@@ -47,20 +71,27 @@ def main():
     ap.add_argument("--res", type=int, default=768)
     ap.add_argument("--mode", default="depth", help="depth | normal | ... (VAE-decoder head); use --head dpt for the DPT disparity head")
     ap.add_argument("--head", default="vae", choices=["vae", "dpt"], help="BASELINE.json configs[1]/[2] = vae (depth/normal), configs[3] = dpt")
-    ap.add_argument("--cpu-res", type=int, default=384, help="edge of the single image timed on the CPU oracle (BASELINE.json configs[0])")
+    ap.add_argument("--cpu-res", type=int, default=768, help="edge of the single image timed on the CPU oracle (the benched size)")
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads for the baseline leg (256 oversubscribes badly)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"], help="element type of the engine (bf16 = BASELINE.json's dtype; fp16 = the 1e-3-parity build, same MFMA rate)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"],
+                    help="element type of the engine (bf16 = BASELINE.json's dtype; fp16 = the 1e-3-parity build, same MFMA rate)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the result maps on their GPUs")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args.gpus)  # does not return
+
     from genpercept_amd import config as gc
     from genpercept_amd import distributed as gd
+    from genpercept_amd import engine as ge
     from genpercept_amd import weights as gw
     from genpercept_amd.engine import Engine
 
     rank, local_rank, world = gd.init_process_group()
-    assert world == max(args.gpus, 1) or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: WORLD_SIZE {world} != --gpus {args.gpus} (the multi-GPU configuration would silently not be measured)")
     n_gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -87,24 +118,46 @@ def main():
     if not (rank == 0 and n_gpus == 1 and not args.no_cpu and not dpt):
         del usd  # the CPU-baseline leg needs the fp32 weights
 
-    lo, hi = gd.shard_range(args.batch * n_gpus, rank, n_gpus)
-    rgb = synthetic_rgb(args.batch * n_gpus, args.res, 1234, "cpu")[lo:hi].to(dev)
+    n_total = args.batch * n_gpus
+    lo, hi = gd.shard_range(n_total, rank, n_gpus)
+    rgb = synthetic_rgb(n_total, args.res, 1234, "cpu")[lo:hi].to(dev)
+    do_gather = n_gpus > 1 and not args.no_gather
+
+    def step():
+        out = eng.infer(rgb, args.mode)
+        if do_gather:
+            return gd.gather_results(out, n_total, dst=0)  # rank 0: [N*B, C, H, W]; others: None
+        return out
 
     for _ in range(args.warmup):
-        out = eng.infer(rgb, args.mode)
+        out = step()
     torch.cuda.synchronize()
     gd.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = eng.infer(rgb, args.mode)
+        out = step()
     torch.cuda.synchronize()
     gd.barrier()
     elapsed = gd.max_over_ranks(time.perf_counter() - t0, dev)
     ms_per_step = elapsed / args.steps * 1e3
-    images = args.batch * n_gpus * args.steps
+    images = n_total * args.steps
     value = images / elapsed
-    assert torch.isfinite(out).all()
+    if out is not None:
+        assert torch.isfinite(out).all()
+        if do_gather:
+            assert out.shape[0] == n_total
+
+    gather_ms = None
+    if do_gather:  # the gather alone (same tensors), max over ranks
+        loc = eng.infer(rgb, args.mode)
+        torch.cuda.synchronize()
+        gd.barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            gd.gather_results(loc, n_total, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = round(gd.max_over_ranks(time.perf_counter() - t0, dev) / 5 * 1e3, 3)
 
     roofline = None
     stages = None
@@ -114,29 +167,38 @@ def main():
         eng.infer(rgb, args.mode)
         tm = eng.timings()
         eng.set_profile(0)
+        peak_meas = ge.mfma_peak_tflops(local_rank, args.precision) if rank == 0 else None
         scale = (args.res / 768.0) ** 2 * ((TFLOP_PER_IMAGE_768_DPT / TFLOP_PER_IMAGE_768) if dpt else 1.0)
-        if tm["ms_igemm"] > 0:
-            ach = tm["flops_igemm"] / (tm["ms_igemm"] * 1e-3) / 1e12
-            traffic = None  # HBM bytes per launch from the committed PMC passes (tools/gpu_pmc_traffic.sh; FETCH_SIZE doubled on gfx950)
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_summary_v2.json")))
-                fam = lambda d: sum(v["sum_kb"] for k, v in d.items() if "gemm_kernel" in k or "conv3x3_halo" in k)  # noqa: E731
-                nd = sum(v["dispatches"] for k, v in tj["FETCH_SIZE"].items() if "gemm_kernel" in k or "conv3x3_halo" in k)
-                traffic = round((2.0 * fam(tj["FETCH_SIZE"]) + fam(tj["WRITE_SIZE"])) * 1024.0 / max(nd, 1))
+        if tm["ms_halo"] > 0:
+            ach = tm["flops_halo"] / (tm["ms_halo"] * 1e-3) / 1e12
+            fam = tm["flops_igemm"] / (tm["ms_igemm"] * 1e-3) / 1e12
+            traffic, traffic_note = None, "not collected for this build (tools/gpu_pmc_traffic.sh writes profiles/r02_pmc_traffic_summary.json)"
+            try:  # PMC passes of THIS round's build, if they were taken (separate --pmc runs; FETCH_SIZE doubled on gfx950)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_summary.json")))
+                sel = lambda d: sum(v["sum_kb"] for k, v in d.items() if "conv3x3_halo3" in k)  # noqa: E731
+                nd = sum(v["dispatches"] for k, v in tj["FETCH_SIZE"].items() if "conv3x3_halo3" in k)
+                traffic = round((2.0 * sel(tj["FETCH_SIZE"]) + sel(tj["WRITE_SIZE"])) * 1024.0 / max(nd, 1))
+                traffic_note = f"HBM bytes per launch, PMC (2*FETCH_SIZE + WRITE_SIZE), build {tj.get('commit', '?')}, profiles/r02_pmc_traffic_summary.json"
             except Exception:
                 pass
-            roofline = {"bound": "mfma", "kernel": "implicit-GEMM conv/linear family (conv3x3_halo3_kernel + pgemm_kernel + igemm_kernel, v_mfma_f32_16x16x32_bf16)",
-                        "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                        "traffic_note": "bytes per launch, PMC (2*FETCH_SIZE + WRITE_SIZE) of profiles/r01_pmc_traffic_summary_v2.json",
-                        "launches": tm["n_igemm"], "flops_per_launch_avg": tm["flops_igemm"] / max(tm["n_igemm"], 1),
-                        "avg_launch_ms": tm["ms_igemm"] / max(tm["n_igemm"], 1),
+            roofline = {"bound": "mfma", "kernel": f"conv3x3_halo3_kernel (3x3 stride-1 convs of the large maps, v_mfma_f32_16x16x32_{'f16' if args.precision == 'fp16' else 'bf16'})",
+                        "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                        "peak_measured": round(peak_meas, 1) if peak_meas and peak_meas > 0 else None,
+                        "frac_of_measured_peak": round(ach / peak_meas, 4) if peak_meas and peak_meas > 0 else None,
+                        "traffic": traffic, "traffic_note": traffic_note,
+                        "launches": tm["n_halo"], "flops_per_launch_avg": tm["flops_halo"] / max(tm["n_halo"], 1),
+                        "avg_launch_ms": tm["ms_halo"] / max(tm["n_halo"], 1), "sum_ms": round(tm["ms_halo"], 3),
+                        "family_kernel": "conv3x3_halo3_kernel + pgemm_kernel + igemm_kernel (every conv / linear launch)",
+                        "family_achieved": round(fam, 2), "family_frac": round(fam / PEAK_BF16_TFLOPS, 4), "family_launches": tm["n_igemm"],
+                        "family_sum_ms": round(tm["ms_igemm"], 3),
                         "attn_achieved": round(tm["flops_attn"] / max(tm["ms_attn"], 1e-9) / 1e9, 2), "attn_launches": tm["n_attn"],
                         "pipeline_achieved": round(TFLOP_PER_IMAGE_768 * scale * args.batch / (ms_per_step * 1e-3), 2),
                         "pipeline_frac": round(TFLOP_PER_IMAGE_768 * scale * args.batch / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4)}
         stages = {"ms_encode": round(tm["ms_encode"], 3), "ms_unet": round(tm["ms_unet"], 3), "ms_head": round(tm["ms_head"], 3),
                   "ms_igemm_sum": round(tm["ms_igemm"], 3), "ms_attn_sum": round(tm["ms_attn"], 3), "kernel_launches": tm["n_launches"],
-                  "algorithmic_tflop_counted": round((tm["flops_igemm"] + tm["flops_attn"]) / 1e12 / args.batch, 3),
-                  # second half of BASELINE.json's metric: UNet stage alone, 2.137 TFLOP per 768x768 image
+                  # executed conv / linear / attention flops; below SURVEY's 10.50 because the 2-token cross-attention is folded (F6)
+                  "executed_tflop_per_image": round((tm["flops_igemm"] + tm["flops_attn"]) / 1e12 / args.batch, 3),
+                  # second half of BASELINE.json's metric: UNet stage alone, 2.137 ALGORITHMIC TFLOP per 768x768 image
                   "unet_mfma_util": round(2.137 * (args.res / 768.0) ** 2 * args.batch / (max(tm["ms_unet"], 1e-9) * 1e-3) / PEAK_BF16_TFLOPS, 4)}
 
     cpu = None
@@ -151,20 +213,25 @@ def main():
             t0 = time.perf_counter()
             ref = opipe.single_infer(vsd, osd.VAECfg(), usd, osd.UNetCfg(), x, ctx, args.mode)
             dt = time.perf_counter() - t0
-        cpu = {"value": round(1.0 / dt, 5), "unit": f"images/sec at {r}x{r} fp32", "cores": nthr, "kind": "port",
+        cpu = {"value": round(1.0 / dt, 5), "unit": f"images/sec at {r}x{r} fp32", "cores": nthr, "cpu_model": cpu_model(), "kind": "port",
                "sample": f"1 image {r}x{r} ({TFLOP_PER_IMAGE_768 * (r / 768.0) ** 2:.3f} TFLOP), torch-CPU fp32 restatement of the diffusers path "
-                         f"(oracle/), {dt:.1f} s; scaled by pixel count to 768x768: {1.0 / (dt * (768.0 / r) ** 2):.5f} images/sec",
+                         f"(oracle/), timed directly at this size: {dt:.1f} s",
                "seconds": round(dt, 2)}
         assert torch.isfinite(ref).all()
 
     if rank == 0:
         head_name = "DPT disparity head" if dpt else f"{args.mode} head"
+        cfg_idx = 3 if dpt else (1 if args.mode == "depth" else 2)
         line = {"metric": f"images/sec at 768x768 bf16 ({'depth' if not dpt and args.mode == 'depth' else head_name})", "value": round(value, 3), "unit": "images/sec", "n_gpus": n_gpus,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                 "config": {"workload": (f"{head_name}, SD2.1 VAE-enc + UNet(t=1) + " + ("DPT neck/head" if dpt else "VAE-dec") +
-                                        f", {args.res}x{args.res}, batch {args.batch}/GPU (BASELINE.json configs[{3 if dpt else (1 if args.mode == 'depth' else 2)}])"), "global_batch": args.batch * n_gpus, "resolution": args.res,
-                           "parallelism": f"dp{n_gpus} (batch-sharded, weights replicated, no data-path collective)",
+                                        f", {args.res}x{args.res}, batch {args.batch}/GPU (BASELINE.json configs[{cfg_idx}]" +
+                                        (f"; N = {n_gpus}: configs[4]'s sharding, {args.batch} per GPU" if n_gpus > 1 else "") + ")"),
+                           "global_batch": n_total, "resolution": args.res,
+                           "parallelism": f"dp{n_gpus} (batch-sharded, weights replicated, no data-path collective" +
+                                          (", result maps gathered to rank 0 over RCCL inside the step)" if do_gather else ")"),
+                           "gather_ms": gather_ms,
                            "weights": "random-init SD2.1 architecture (865.9M + 83.7M params)", "load_s": round(t_load, 1)},
                 "roofline": roofline, "cpu_baseline": cpu, "stages": stages}
         print(json.dumps(line), flush=True)

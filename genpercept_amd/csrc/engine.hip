@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -83,29 +84,37 @@ struct HostTensor {
 struct Pool {
     std::multimap<size_t, void*> free_;
     std::unordered_map<void*, size_t> size_;
+    std::unordered_map<void*, int> live_;  // buffers handed out and not yet returned (an aborted call returns them all: release_live)
     size_t total = 0;
     void* alloc(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
         auto it = free_.lower_bound(bytes);
-        if (it != free_.end() && it->first <= bytes * 2 + (1u << 20)) {
-            void* p = it->second;
-            free_.erase(it);
-            return p;
-        }
         void* p = nullptr;
-        HIPCHK(hipMalloc(&p, bytes));
-        size_[p] = bytes;
-        total += bytes;
+        if (it != free_.end() && it->first <= bytes * 2 + (1u << 20)) {
+            p = it->second;
+            free_.erase(it);
+        } else {
+            HIPCHK(hipMalloc(&p, bytes));
+            size_[p] = bytes;
+            total += bytes;
+        }
+        live_[p] = 1;
         return p;
     }
     void release(void* p) {
         if (!p) return;
+        if (!live_.erase(p)) return;  // not outstanding (already returned by release_live)
         free_.insert({size_.at(p), p});
+    }
+    void release_live() {
+        for (auto& kv : live_) free_.insert({size_.at(kv.first), kv.first});
+        live_.clear();
     }
     void destroy() {
         for (auto& kv : size_) hipFree(kv.first);
         size_.clear();
         free_.clear();
+        live_.clear();
     }
 };
 
@@ -166,7 +175,8 @@ struct gp_engine {
     h16_t* zero = nullptr;
     float* gn_ws = nullptr;
     size_t gn_ws_floats = 0;
-    float* mm_ws = nullptr;
+    hipStream_t last_stream = nullptr;  // the pool recycles buffers in stream order: a change of stream is fenced (check_ready)
+    bool stream_seen = false;
     h16_t* conv_in_w27 = nullptr;  // VAE encoder conv_in as a [Cout][32] (K = 27) matrix for rgb_conv_in_kernel
     bool fuse_gn = true;   // GENPERCEPT_NO_GN_FUSION=1 keeps the separate apply pass (A/B measurements)
     int gn_fuse_max_slices = 1;        // GENPERCEPT_GN_FUSE_MAX_SLICES: on large maps fuse the apply only into convs with at most this many 128-channel output slices
@@ -399,7 +409,7 @@ struct gp_engine {
             t.kc = upload(kc.data(), kc.size());
             t.vc = upload(vc.data(), vc.size());
             t.fU = t.fu0 = t.fG = t.fc0 = nullptr;
-            if (L == 2 && !getenv("GENPERCEPT_NO_CROSS_FOLD")) {
+            if (L == 2 && cross_attn_fold_supported(C, t.heads) && !getenv("GENPERCEPT_NO_CROSS_FOLD")) {
                 // softmax over two keys = sigmoid of the logit difference; see cross_fold_kernel (norm.hip) for the algebra
                 const int hd = 64, nh = t.heads;
                 std::vector<float> U((size_t)nh * C), u0(nh), G((size_t)nh * C), c0(C);
@@ -546,8 +556,6 @@ struct gp_engine {
             dpt_b = H("dpt.head.head.4.bias").v[0];
         }
         (void)have_vae;
-        HIPCHK(hipMalloc((void**)&mm_ws, 64 * 64 * 2 * sizeof(float)));
-        weights_dev.push_back(mm_ws);
         host.clear();
         finalized = true;
     }
@@ -614,8 +622,11 @@ struct gp_engine {
     }
     void run_igemm(const IGemmParams& p, int hint = 0) {
         const int taps = p.ks == 3 ? 9 : 1;
-        tm.flops_igemm += 2.0 * (double)p.M * (double)p.N * (double)p.Cin * taps * (p.batch > 0 ? p.batch : 1);
+        const double fl = 2.0 * (double)p.M * (double)p.N * (double)p.Cin * taps * (p.batch > 0 ? p.batch : 1);
+        const bool halo = conv_uses_halo(p, hint);
+        tm.flops_igemm += fl;
         tm.n_igemm++;
+        if (halo) { tm.flops_halo += fl; tm.n_halo++; }
         if (prof >= 3) {
             const char* path = conv_uses_halo(p, hint) ? (p.in_scale ? (p.in_silu ? "halo+gn+silu" : "halo+gn") : "halo") : igemm_uses_pgemm(p, hint) ? "pgemm" : "igemm";
             mark(std::string(p.ks == 3 ? (p.ups ? "conv3x3up " : (p.stride == 2 ? "conv3x3s2 " : "conv3x3 ")) : (p.batch > 1 ? "bgemm " : "gemm ")) + path + " M=" + std::to_string(p.M) +
@@ -625,9 +636,18 @@ struct gp_engine {
         } else {
             tm.n_launches++;
         }
-        prof_begin(0);
-        launch_igemm(p, hint, st);
+        IGemmParams q = p;
+        void* ws = nullptr;
+        const int S = halo ? 1 : igemm_ksplit(q, hint);
+        if (S > 1) {  // split-K partial sums: from this engine's pool (stream-ordered reuse), never process-global
+            q.splitk_ws_floats = (long long)S * q.M * q.n_store;
+            ws = pool.alloc((size_t)q.splitk_ws_floats * sizeof(float));
+            q.splitk_ws = (float*)ws;
+        }
+        prof_begin(halo ? 2 : 0);
+        launch_igemm(q, hint, st);
         prof_end();
+        if (ws) pool.release(ws);
     }
 
     struct ConvOpt {
@@ -710,7 +730,17 @@ struct gp_engine {
             launch_groupnorm_stats(x.p, n.g, n.b, x.B, x.H * x.W, x.C, cfg.norm_groups, eps, ws, scale, shift, st);
         }
     }
+    // one-launch GroupNorm for small maps whose producer left no statistics behind (split-K convs of the 12x12 level, ...)
+    bool gn_small(const Act& x) const { return !x.st && groupnorm_small_applicable(x.B, x.H * x.W, x.C, cfg.norm_groups) && !getenv("GENPERCEPT_NO_GN_SMALL"); }
+    Act groupnorm_small(const Act& x, const NormW& n, float eps, bool silu) {
+        if (x.C != n.C) throw std::logic_error("groupnorm: channel mismatch");
+        Act y = new_act(x.B, x.H, x.W, x.C);
+        mark("gn_small " + dims(x));
+        launch_groupnorm_small(x.p, y.p, n.g, n.b, x.B, x.H * x.W, x.C, cfg.norm_groups, eps, silu ? 1 : 0, st);
+        return y;
+    }
     Act groupnorm(const Act& x, const NormW& n, float eps, bool silu) {
+        if (gn_small(x)) return groupnorm_small(x, n, eps, silu);
         float *scale, *shift;
         gn_scale_shift(x, n, eps, scale, shift);
         Act y = new_act(x.B, x.H, x.W, x.C);
@@ -721,8 +751,9 @@ struct gp_engine {
     float* gn_workspace(const Act& x) {  // partial statistics + per-(image, channel) scale / shift
         const size_t need = (size_t)groupnorm_ws_floats(x.B, x.H * x.W, x.C, cfg.norm_groups) + 2 * (size_t)x.B * x.C;
         if (need > gn_ws_floats) {
-            if (gn_ws) pool.release(gn_ws);
+            if (gn_ws) { pool.live_[gn_ws] = 1; pool.release(gn_ws); }
             gn_ws = (float*)pool.alloc(need * 4 * 2);
+            pool.live_.erase(gn_ws);  // kept across calls: not part of a call's outstanding set
             gn_ws_floats = need * 2;
         }
         return gn_ws;
@@ -730,6 +761,15 @@ struct gp_engine {
     // conv(act(GroupNorm(x))): statistics pass, then the normalisation is applied either inside the conv kernel on the staged
     // input halo (conv_halo.hip) or, when that kernel does not take the layer, by the separate apply pass.
     Act conv_gn(const Act& x, const NormW& n, float eps, bool silu, const PackedW& w, const ConvOpt& o) {
+        if (gn_small(x)) {
+            IGemmParams p0 = conv_params(x, w, o, nullptr);
+            if (!conv_uses_halo(p0, 0)) {  // (a halo conv would fuse the apply: keep the statistics path for it)
+                Act y = groupnorm_small(x, n, eps, silu);
+                Act out = conv(y, w, o);
+                drop(y);
+                return out;
+            }
+        }
         float *scale, *shift;
         gn_scale_shift(x, n, eps, scale, shift);
         IGemmParams p = conv_params(x, w, o, nullptr);
@@ -1150,8 +1190,9 @@ struct gp_engine {
         for (size_t i = 0; i < ev_used; ++i) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, ev_pool[i].first, ev_pool[i].second));
-            if (ev_kind[i] == 0) tm.ms_igemm += ms;
-            else tm.ms_attn += ms;
+            if (ev_kind[i] == 1) tm.ms_attn += ms;
+            else tm.ms_igemm += ms;                  // the whole conv / GEMM family ...
+            if (ev_kind[i] == 2) tm.ms_halo += ms;   // ... and its dominant member, conv3x3_halo3_kernel, on its own
         }
         ev_used = 0;
     }
@@ -1162,33 +1203,70 @@ struct gp_engine {
 // =====================================================================================================================
 template <typename F>
 static gp_status guard(gp_engine* e, F&& f) {
+    gp_status st = GP_OK;
     try {
         f();
         return GP_OK;
     } catch (const std::out_of_range& ex) {
         if (e) e->err = ex.what();
-        return GP_ERR_MISSING_WEIGHT;
+        st = GP_ERR_MISSING_WEIGHT;
     } catch (const std::invalid_argument& ex) {
         if (e) e->err = ex.what();
-        return GP_ERR_INVALID;
+        st = GP_ERR_INVALID;
     } catch (const std::logic_error& ex) {
         if (e) e->err = ex.what();
-        return GP_ERR_STATE;
+        st = GP_ERR_STATE;
     } catch (const std::exception& ex) {
         if (e) e->err = ex.what();
-        return GP_ERR_HIP;
+        st = GP_ERR_HIP;
     }
+    // a stage that threw abandoned its activations: wait for whatever it had enqueued, then hand every outstanding buffer back to the pool
+    if (e && !e->pool.live_.empty()) {
+        (void)hipSetDevice(e->cfg.device);
+        (void)hipDeviceSynchronize();
+        e->pool.release_live();
+    }
+    return st;
 }
 
-static h16_t* g_zero = nullptr;
-static float* g_gn_ws = nullptr;
-static size_t g_gn_ws_floats = 0;
+// Scratch of the per-kernel entry points (the parity-test interface below; engines use their own pool): one set per DEVICE, and the
+// entry points that use it hold g_scratch_mu for the duration of their enqueue, so two host threads cannot resize it under each other.
+struct DevScratch {
+    h16_t* zero = nullptr;
+    float* bufs[3] = {nullptr, nullptr, nullptr};  // 0: GroupNorm workspace, 1: statistics partials, 2: split-K partial sums
+    size_t floats[3] = {0, 0, 0};
+};
+static std::mutex g_scratch_mu;
+static std::map<int, DevScratch> g_scratch;
+static DevScratch& dev_scratch() {  // call with g_scratch_mu held
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    return g_scratch[dev];
+}
 static h16_t* zero_page() {
-    if (!g_zero) {
-        HIPCHK(hipMalloc((void**)&g_zero, 4096));
-        HIPCHK(hipMemset(g_zero, 0, 4096));
+    DevScratch& d = dev_scratch();
+    if (!d.zero) {
+        HIPCHK(hipMalloc((void**)&d.zero, 4096));
+        HIPCHK(hipMemset(d.zero, 0, 4096));
     }
-    return g_zero;
+    return d.zero;
+}
+static float* scratch_floats(int which, size_t need) {
+    DevScratch& d = dev_scratch();
+    if (need > d.floats[which]) {
+        if (d.bufs[which]) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(d.bufs[which])); d.bufs[which] = nullptr; d.floats[which] = 0; }
+        HIPCHK(hipMalloc((void**)&d.bufs[which], need * sizeof(float)));
+        d.floats[which] = need;
+    }
+    return d.bufs[which];
+}
+// split-K workspace for a per-kernel call (engines take theirs from the pool)
+static void attach_splitk_scratch(IGemmParams& p, int tile_hint) {
+    const int S = igemm_ksplit(p, tile_hint);
+    if (S > 1) {
+        p.splitk_ws_floats = (long long)S * p.M * p.n_store;
+        p.splitk_ws = scratch_floats(2, (size_t)p.splitk_ws_floats);
+    }
 }
 
 extern "C" {
@@ -1331,6 +1409,11 @@ int gp_get_launch_log(gp_engine* e, char* buf, int cap) {
 static void check_ready(gp_engine* e, void* stream) {
     if (!e->finalized) throw std::logic_error("engine not finalized");
     HIPCHK(hipSetDevice(e->cfg.device));
+    // the activation pool hands a buffer to its next user as soon as the last consumer is ENQUEUED, which is only safe within one
+    // stream: when the caller switches streams, everything issued on the previous one is waited for first
+    if (e->stream_seen && e->last_stream != (hipStream_t)stream) HIPCHK(hipStreamSynchronize(e->last_stream));
+    e->last_stream = (hipStream_t)stream;
+    e->stream_seen = true;
     e->st = (hipStream_t)stream;
 }
 
@@ -1368,7 +1451,9 @@ gp_status gp_infer(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, i
             e->dpt_head(rev, out_dev);
             for (int i = 0; i < 4; ++i) e->drop(feats[i]);
             e->mark("minmax_norm", 0.0, 2);
-            launch_minmax_norm(out_dev, B, out_px, e->mm_ws, e->st);
+            float* mm_ws = (float*)e->pool.alloc((size_t)B * 64 * 2 * sizeof(float));  // [B][64 partials][min, max]
+            launch_minmax_norm(out_dev, B, out_px, mm_ws, e->st);
+            e->pool.release(mm_ws);
         }
         e->mark("END", 0.0, 0);
         if (stage_ev) {
@@ -1482,6 +1567,7 @@ gp_status gp_conv2d(const void* in, const void* w_packed, const float* bias, con
                     int out_fp32, int tile_hint, void* stream) {
     if (!in || !w_packed || !out || (Cin % 64) || (ks != 1 && ks != 3)) return GP_ERR_INVALID;
     try {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
         IGemmParams p{};
         p.in = (const h16_t*)in; p.wt = (const h16_t*)w_packed; p.bias = bias; p.res = (const h16_t*)residual; p.out = out; p.zero = zero_page();
         p.M = B * Ho * Wo; p.N = Cout; p.Cin = Cin; p.n_rows = gp_packed_rows(Cout); p.ks = ks;
@@ -1492,6 +1578,7 @@ gp_status gp_conv2d(const void* in, const void* w_packed, const float* bias, con
         p.lda = Cin; p.ldo = nst; p.ldres = nst; p.ldw = (ks == 3 ? 9 : 1) * Cin; p.n_store = nst; p.out_fp32 = out_fp32; p.act = act;
         p.bias_mode = bias ? GP_BIAS_COL : GP_BIAS_NONE; p.batch = 1;
         if (const char* dbg = getenv("GENPERCEPT_IGEMM_DBG")) p.dbg = atoi(dbg);  // profiling ablations (tools/conv_bench.py)
+        attach_splitk_scratch(p, tile_hint);
         launch_igemm(p, tile_hint, (hipStream_t)stream);
         HIPCHK(hipGetLastError());
         return GP_OK;
@@ -1502,6 +1589,7 @@ gp_status gp_conv2d_gn(const void* in, const void* w_packed, const float* bias, 
                        int Cout, int ups, int act, const float* gamma, const float* beta, int groups, float eps, int silu, void* stream) {
     if (!in || !w_packed || !out || !gamma || !beta || (Cin % 64) || (Cin % groups)) return GP_ERR_INVALID;
     try {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
         const int Ho = ups ? 2 * H : H, Wo = ups ? 2 * W : W;
         IGemmParams p{};
         p.in = (const h16_t*)in; p.wt = (const h16_t*)w_packed; p.bias = bias; p.res = (const h16_t*)residual; p.out = out; p.zero = zero_page();
@@ -1511,11 +1599,7 @@ gp_status gp_conv2d_gn(const void* in, const void* w_packed, const float* bias, 
         p.lda = Cin; p.ldo = Cout; p.ldres = Cout; p.ldw = 9 * Cin; p.n_store = Cout; p.act = act;
         p.bias_mode = bias ? GP_BIAS_COL : GP_BIAS_NONE; p.batch = 1;
         const size_t need = (size_t)groupnorm_ws_floats(B, H * W, Cin, groups) + 2 * (size_t)B * Cin;
-        if (need > g_gn_ws_floats) {
-            if (g_gn_ws) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(g_gn_ws)); }
-            HIPCHK(hipMalloc((void**)&g_gn_ws, need * 4));
-            g_gn_ws_floats = need;
-        }
+        float* g_gn_ws = scratch_floats(0, need);
         float* scale = g_gn_ws + groupnorm_ws_floats(B, H * W, Cin, groups);
         float* shift = scale + (size_t)B * Cin;
         launch_groupnorm_stats((const h16_t*)in, gamma, beta, B, H * W, Cin, groups, eps, g_gn_ws, scale, shift, (hipStream_t)stream);
@@ -1544,6 +1628,7 @@ gp_status gp_conv2d_stats(const void* in, const void* w_packed, const float* bia
     if (!in || !w_packed || !out || !gamma || !beta || !scale_out || !shift_out || (Cin % 64) || (ks != 1 && ks != 3) || groups < 1 || (Cout % groups))
         return GP_ERR_INVALID;
     try {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
         const int Ho = ups ? 2 * H : H, Wo = ups ? 2 * W : W;
         IGemmParams p{};
         p.in = (const h16_t*)in; p.wt = (const h16_t*)w_packed; p.bias = bias; p.res = (const h16_t*)residual; p.out = out; p.zero = zero_page();
@@ -1557,13 +1642,7 @@ gp_status gp_conv2d_stats(const void* in, const void* w_packed, const float* bia
         const int nt = igemm_tile_info(p, tile_hint, &mode, &bm);
         if (nt <= 0) return GP_ERR_INVALID;
         const size_t need = (size_t)nt * (Cout * 2 + 1);
-        static float* part = nullptr;
-        static size_t part_floats = 0;
-        if (need > part_floats) {
-            if (part) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(part)); }
-            HIPCHK(hipMalloc((void**)&part, need * 4));
-            part_floats = need;
-        }
+        float* part = scratch_floats(1, need);
         p.stats_out = part;
         launch_igemm(p, tile_hint, (hipStream_t)stream);
         launch_groupnorm_from_partials(part, mode, bm, B, Ho, Wo, Cout, groups, eps, gamma, beta, scale_out, shift_out, (hipStream_t)stream);
@@ -1577,6 +1656,7 @@ gp_status gp_gemm(const void* a, int lda, const void* bt, int ldb, const float* 
                   long long out_bs, int tile_hint, void* stream) {
     if (!a || !bt || !out || (K % 64)) return GP_ERR_INVALID;
     try {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
         IGemmParams p{};
         p.in = (const h16_t*)a; p.wt = (const h16_t*)bt; p.bias = bias; p.res = (const h16_t*)residual; p.out = out; p.zero = zero_page();
         p.M = M; p.N = N; p.Cin = K; p.n_rows = n_rows_bt; p.ks = 1; p.stride = 1;
@@ -1591,13 +1671,11 @@ gp_status gp_gemm(const void* a, int lda, const void* bt, int ldb, const float* 
 gp_status gp_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int silu, void* stream) {
     if (!x || !y || !gamma || !beta || (C % 8) || (C % G)) return GP_ERR_INVALID;
     try {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
         const size_t need = (size_t)groupnorm_ws_floats(B, HW, C, G) + 2 * (size_t)B * C;
-        if (need > g_gn_ws_floats) {
-            if (g_gn_ws) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(g_gn_ws)); }
-            HIPCHK(hipMalloc((void**)&g_gn_ws, need * 4));
-            g_gn_ws_floats = need;
-        }
-        launch_groupnorm((const h16_t*)x, (h16_t*)y, gamma, beta, B, HW, C, G, eps, silu, g_gn_ws, (hipStream_t)stream);
+        float* g_gn_ws = scratch_floats(0, need);
+        if (groupnorm_small_applicable(B, HW, C, G)) launch_groupnorm_small((const h16_t*)x, (h16_t*)y, gamma, beta, B, HW, C, G, eps, silu, (hipStream_t)stream);
+        else launch_groupnorm((const h16_t*)x, (h16_t*)y, gamma, beta, B, HW, C, G, eps, silu, g_gn_ws, (hipStream_t)stream);
         HIPCHK(hipGetLastError());
         return GP_OK;
     } catch (...) { return GP_ERR_HIP; }
@@ -1613,6 +1691,7 @@ gp_status gp_flash_attention(const void* q, const void* k, const void* vt, void*
                              void* stream) {
     if (!q || !k || !vt || !out || (Tpad % 64) || Tpad < T) return GP_ERR_INVALID;
     try {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
         launch_flash_attn64((const h16_t*)q, (const h16_t*)k, (const h16_t*)vt, (h16_t*)out, zero_page(), B, T, heads, ldq, ldk, Tpad, ldo,
                             (hipStream_t)stream);
         HIPCHK(hipGetLastError());
@@ -1628,9 +1707,14 @@ gp_status gp_cross_attention(const void* q, const float* kc, const float* vc, vo
 
 gp_status gp_cross_attention_fold(const void* y, void* y_out, void* n3_out, const float* U, const float* u0, const float* G, const float* c0,
                                   const float* g3, const float* b3, int rows, int C, int heads, float eps, void* stream) {
-    if (!y || !y_out || !U || !u0 || !G || !c0 || (C % 8) || C > 1536 || heads < 1 || (n3_out && (!g3 || !b3))) return GP_ERR_INVALID;
+    if (!y || !y_out || !U || !u0 || !G || !c0 || !cross_attn_fold_supported(C, heads) || (n3_out && (!g3 || !b3))) return GP_ERR_INVALID;
     launch_cross_attn_fold((const h16_t*)y, (h16_t*)y_out, (h16_t*)n3_out, U, u0, G, c0, g3, b3, rows, C, heads, eps, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
+}
+
+double gp_mfma_peak_tflops(int device, void* stream) {
+    if (hipSetDevice(device) != hipSuccess) return -1.0;
+    return mfma_peak_tflops(20, (hipStream_t)stream);
 }
 
 gp_status gp_softmax_rows(const float* in, void* out, int rows, int T, int ld, float scale, void* stream) {

@@ -23,6 +23,17 @@
 #include "epilogue.h"
 #include "kernels.h"
 
+#include <atomic>
+
+// true exactly once per (mask, current device): callers guard their one-time per-device setup with it (thread-safe, lock-free)
+bool gp_first_use_on_device(unsigned long long* mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    const unsigned long long bit = 1ull << dev;
+    auto* a = reinterpret_cast<std::atomic<unsigned long long>*>(mask);
+    return !(a->fetch_or(bit, std::memory_order_acq_rel) & bit);
+}
+
 constexpr bool PRIO = true;   // s_setprio around the MFMA cluster made hipcc wait lgkmcnt(0) before the first MFMA
 template <int N>
 GP_DEV void wait_vm_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -291,11 +302,9 @@ int igemm_ksplit(const IGemmParams& p, int tile_hint) {
 template <int BM, int BN, int WM, int WN, int KS, int NSTAGE>
 static void launch_one(const IGemmParams& p, dim3 grid, hipStream_t s) {
     constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr_mask = 0;  // per device: every GPU of the process needs its own attribute
+    if (gp_first_use_on_device(&attr_mask))
         (void)hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, KS, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, KS, NSTAGE>), grid, dim3(64 * WM * WN), lds, s, p);
 }
 
@@ -378,14 +387,9 @@ void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s) {
     }
     const int S = igemm_ksplit(p, tile_hint);
     if (S > 1) {
-        static float* ws = nullptr;
-        static size_t ws_floats = 0;
+        // the partial sums live in a workspace the CALLER owns (an engine takes it from its pool): no process-global state here
         const size_t slice = (size_t)p.M * p.n_store, need = slice * S;
-        if (need > ws_floats) {
-            if (ws) { (void)hipDeviceSynchronize(); (void)hipFree(ws); }
-            if (hipMalloc((void**)&ws, need * sizeof(float)) != hipSuccess) { ws = nullptr; ws_floats = 0; }
-            else ws_floats = need;
-        }
+        float* ws = (p.splitk_ws && (size_t)p.splitk_ws_floats >= need) ? p.splitk_ws : nullptr;
         if (ws) {
             IGemmParams q = p;
             q.out = ws; q.out_fp32 = 1; q.ldo = p.n_store; q.bias = nullptr; q.bias_mode = GP_BIAS_NONE; q.res = nullptr; q.act = GP_ACT_NONE;

@@ -40,6 +40,8 @@ struct IGemmParams {
     int out_fp32;         // 1: fp32 output, 2: fp16 output (direct epilogue path)
     int act, bias_mode;
     int dbg;              // ablation bits for profiling only (1: no DMA in the loop, 2: no MFMA work, 4: no waits/barriers)
+    float* splitk_ws;     // caller-owned fp32 workspace for split-K partial sums (>= igemm_ksplit() * M * n_store floats) or nullptr: no split-K
+    long long splitk_ws_floats;
     int batch;            // grid.y batches with the strides below (elements)
     int ksplit;           // > 1: grid.z = ksplit slices of the K loop, slice z writes fp32 partials at out + z * split_bs (set by launch_igemm)
     long long split_bs;
@@ -49,6 +51,9 @@ struct IGemmParams {
 // tile_hint: 0 auto (halo conv / persistent GEMM / split-K / generic tile by heuristic), 1 = 128x128, 2 = 64x64, 3 = 256x32, 4 = 256x128,
 //            5 = conv_halo.hip, 6 = 128x64, 7 = pgemm.hip
 void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s);
+int igemm_ksplit(const IGemmParams& p, int tile_hint);   // K slices launch_igemm would like to use (1: none); needs p.splitk_ws to do so
+// >64 KiB of dynamic LDS needs hipFuncSetAttribute once per (kernel, device): true the first time it is asked for this device
+bool gp_first_use_on_device(unsigned long long* mask);
 // pgemm.hip: persistent GEMM for plain-row problems (ks == 1, bf16 out, column bias); tile_hint 7 forces it, 0 prefers it
 bool pgemm_applicable(const IGemmParams& p);
 int pgemm_bm(const IGemmParams& p);                 // rows per tile (256 or 128) launch_pgemm will use
@@ -76,6 +81,10 @@ void launch_groupnorm_apply(const h16_t* x, h16_t* y, const float* scale, const 
 void launch_groupnorm(const h16_t* x, h16_t* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps,
                       int silu, float* ws, hipStream_t s);
 int groupnorm_ws_floats(int B, int HW, int C, int G);
+// small maps (a group's HW x C/G block fits one workgroup's loop; (C / G) % 8 == 0): statistics + apply in one launch
+bool groupnorm_small_applicable(int B, int HW, int C, int G);
+void launch_groupnorm_small(const h16_t* x, h16_t* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int silu,
+                            hipStream_t s);
 
 // LayerNorm over the last dim of [rows][C] bf16.
 void launch_layernorm(const h16_t* x, h16_t* y, const float* gamma, const float* beta, int rows, int C, float eps, hipStream_t s);
@@ -90,6 +99,7 @@ void launch_cross_attn_small(const h16_t* q, const float* kc, const float* vc, h
 
 // Cross-attention against a 2-token constant context folded into per-head vectors (norm.hip): y_out = y + c0 + sum_h sigmoid(LNhat(y) . U[h]
 // + u0[h]) G[h]; optionally n3_out = LayerNorm(y_out; g3, b3).  U, G: [heads][C] fp32; u0 [heads]; c0, g3, b3 [C].  C <= 1536.
+bool cross_attn_fold_supported(int C, int heads);  // C == 64 * heads, heads in {1, 2, 4, 5, 10, 20} (the instantiated head counts)
 void launch_cross_attn_fold(const h16_t* y, h16_t* y_out, h16_t* n3_out, const float* U, const float* u0, const float* G, const float* c0,
                             const float* g3, const float* b3, int rows, int C, int heads, float eps, hipStream_t s);
 
@@ -118,3 +128,6 @@ void launch_add(const h16_t* a, const h16_t* b, h16_t* out, long long n, hipStre
 void launch_bilinear(const h16_t* in, h16_t* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, hipStream_t s);
 void launch_dpt_final(const h16_t* in, const float* w, float bias, float* out, int B, int HW, int Cin, hipStream_t s);  // ReLU'd 32ch -> 1
 void launch_minmax_norm(float* x, int B, long long n, float* ws, hipStream_t s);  // per-image (x-min)/(max-min)
+
+// microbench.hip: sustained TFLOP/s of back-to-back v_mfma_f32_32x32x16 on this chip (register operands, all CUs), or < 0 on error
+double mfma_peak_tflops(int ms_target, hipStream_t s);

@@ -155,6 +155,71 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const h16_t* __restrict__
     }
 }
 
+// ---- small maps: statistics + apply in ONE launch ---------------------------------------------------------------------------------------
+// One workgroup per (group, image) owns the group's HW x cpg block (cpg % 8 == 0): read it for the statistics (exact two-pass: sum, then
+// squared deviations), read it again -- L2-hot -- to normalise and write.  The three-launch path (partials, finalize, apply) cost ~27 us on
+// the UNet's 12x12 maps, 17 times per pass, for 1.5 MB of data.
+__global__ __launch_bounds__(256) void gn_small_kernel(const h16_t* __restrict__ x, h16_t* __restrict__ y, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int HW, int C, int G, float eps, int silu) {
+    __shared__ float red[8];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / G, vpg = cpg >> 3, items = HW * vpg;
+    const h16_t* xb = x + (long long)b * HW * C + g * cpg;
+    h16_t* yb = y + (long long)b * HW * C + g * cpg;
+    auto block_sum = [&](float v, int slot) -> float {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((tid & 63) == 0) red[slot * 4 + (tid >> 6)] = v;
+        __syncthreads();
+        return (red[slot * 4] + red[slot * 4 + 1]) + (red[slot * 4 + 2] + red[slot * 4 + 3]);
+    };
+    float s = 0.f;
+    for (int i = tid; i < items; i += 256) {
+        const int p = i / vpg, v = i - p * vpg;
+        const uint4 raw = *(const uint4*)(xb + (long long)p * C + v * 8);
+        s += (h16_lo(raw.x) + h16_hi(raw.x)) + (h16_lo(raw.y) + h16_hi(raw.y)) + (h16_lo(raw.z) + h16_hi(raw.z)) + (h16_lo(raw.w) + h16_hi(raw.w));
+    }
+    const float n_all = (float)HW * (float)cpg;
+    const float mean = block_sum(s, 0) / n_all;
+    float q = 0.f;
+    for (int i = tid; i < items; i += 256) {
+        const int p = i / vpg, v = i - p * vpg;
+        const uint4 raw = *(const uint4*)(xb + (long long)p * C + v * 8);
+        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float a = h16_lo(w[k]) - mean, c = h16_hi(w[k]) - mean; q += a * a + c * c; }
+    }
+    const float rstd = rsqrtf(block_sum(q, 1) / n_all + eps);
+    for (int i = tid; i < items; i += 256) {
+        const int p = i / vpg, v = i - p * vpg;
+        const uint4 raw = *(const uint4*)(xb + (long long)p * C + v * 8);
+        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+        const float* gm = gamma + g * cpg + v * 8;
+        const float* bt = beta + g * cpg + v * 8;
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[2 * k] = (h16_lo(w[k]) - mean) * rstd * gm[2 * k] + bt[2 * k];
+            o[2 * k + 1] = (h16_hi(w[k]) - mean) * rstd * gm[2 * k + 1] + bt[2 * k + 1];
+        }
+        if (silu) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = silu_f(o[k]);
+        }
+        uint4 r;
+        r.x = pack_h16x2(o[0], o[1]); r.y = pack_h16x2(o[2], o[3]); r.z = pack_h16x2(o[4], o[5]); r.w = pack_h16x2(o[6], o[7]);
+        *(uint4*)(yb + (long long)p * C + v * 8) = r;
+    }
+}
+bool groupnorm_small_applicable(int B, int HW, int C, int G) {
+    const int cpg = C / G;
+    return (cpg & 7) == 0 && cpg * G == C && (long long)HW * (cpg >> 3) <= 8192 && B * G >= 64;
+}
+void launch_groupnorm_small(const h16_t* x, h16_t* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int silu,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(gn_small_kernel, dim3(G, B), dim3(256), 0, s, x, y, gamma, beta, HW, C, G, eps, silu);
+}
+
 void launch_groupnorm_stats(const h16_t* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, float* ws,
                             float* scale, float* shift, hipStream_t s) {
     const int nchunk = gn_nchunk(HW);
@@ -319,11 +384,14 @@ void launch_layernorm(const h16_t* x, h16_t* y, const float* gamma, const float*
 // (custom_unet.py / BasicTransformerBlock attn2, genpercept_pipeline.py:425-429) -- exactly, in fp32, with the row in registers.  The
 // kernel also emits LN3 of the row it just stored (the input of the feed-forward GEMM), saving that pass too.  HBM-bound: 6 B / element.
 // One wave handles R rows at a time (the U / G rows it streams from L2 are reused R times); lane owns 8-channel vectors lane + 64 u.
-template <int VPT, int R>
+// HEADS is a template parameter so that both head loops unroll: the U / G loads of all heads are independent and issue together, and the
+// HEADS x R logit reductions interleave -- as a run-time loop every head paid an L2 round trip plus a 6-step shuffle chain in sequence
+// (78 us for 576 rows of 1280 channels, pure latency).
+template <int VPT, int R, int HEADS>
 __global__ __launch_bounds__(256) void cross_fold_kernel(const h16_t* __restrict__ y, h16_t* __restrict__ y_out, h16_t* __restrict__ n3_out,
                                                           const float* __restrict__ U, const float* __restrict__ u0, const float* __restrict__ G,
                                                           const float* __restrict__ c0, const float* __restrict__ g3, const float* __restrict__ b3,
-                                                          int rows, int C, int heads, float eps) {
+                                                          int rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= rows) return;
@@ -364,54 +432,58 @@ __global__ __launch_bounds__(256) void cross_fold_kernel(const h16_t* __restrict
         for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
         rstd[r] = rsqrtf(q * invC + eps);
     }
-    // ---- out accumulators start as y + c0; the per-head logits use yhat = (y - mean) rstd on the fly
-    float acc[R][VPT][8];
+    // ---- per-head logits d[r][h] = yhat . U[h]: partial sums over this lane's channels for every head, then one batch of reductions
+    float d[R][HEADS];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) d[r][h] = 0.f;
 #pragma unroll
     for (int u = 0; u < VPT; ++u) {
         const int vi = lane + u * 64;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        if (vi < nvec) { a = *(const float4*)(c0 + vi * 8); b = *(const float4*)(c0 + vi * 8 + 4); }
-        const float cc[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        if (vi < nvec) {
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc[r][u][k] = v[r][u][k] + cc[k];
-    }
-    for (int h = 0; h < heads; ++h) {
-        float d[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) d[r] = 0.f;
-#pragma unroll
-        for (int u = 0; u < VPT; ++u) {
-            const int vi = lane + u * 64;
-            if (vi < nvec) {
+            for (int h = 0; h < HEADS; ++h) {
                 const float4 a = *(const float4*)(U + (long long)h * C + vi * 8), b = *(const float4*)(U + (long long)h * C + vi * 8 + 4);
                 const float uu[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) d[r] += (v[r][u][k] - mean[r]) * uu[k];
+                    for (int k = 0; k < 8; ++k) d[r][h] += (v[r][u][k] - mean[r]) * uu[k];
             }
         }
-        float p[R];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int h = 0; h < HEADS; ++h) d[r][h] += __shfl_xor(d[r][h], o);
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) {
         const float uh = u0[h];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float t = d[r];
+        for (int r = 0; r < R; ++r) d[r][h] = __builtin_amdgcn_rcpf(1.f + __expf(-(d[r][h] * rstd[r] + uh)));  // softmax over 2 keys
+    }
+    // ---- y + c0 + sum_h p_h G[h]
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-            p[r] = __builtin_amdgcn_rcpf(1.f + __expf(-(t * rstd[r] + uh)));
-        }
+    for (int u = 0; u < VPT; ++u) {
+        const int vi = lane + u * 64;
+        if (vi < nvec) {
+            const float4 a0 = *(const float4*)(c0 + vi * 8), b0 = *(const float4*)(c0 + vi * 8 + 4);
+            const float cc[8] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w};
 #pragma unroll
-        for (int u = 0; u < VPT; ++u) {
-            const int vi = lane + u * 64;
-            if (vi < nvec) {
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[r][u][k] += cc[k];
+#pragma unroll
+            for (int h = 0; h < HEADS; ++h) {
                 const float4 a = *(const float4*)(G + (long long)h * C + vi * 8), b = *(const float4*)(G + (long long)h * C + vi * 8 + 4);
                 const float gg[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[r][u][k] += p[r] * gg[k];
+                    for (int k = 0; k < 8; ++k) v[r][u][k] += d[r][h] * gg[k];
             }
         }
     }
@@ -423,15 +495,15 @@ __global__ __launch_bounds__(256) void cross_fold_kernel(const h16_t* __restrict
         for (int u = 0; u < VPT; ++u) {
             const int vi = lane + u * 64;
             uint4 pk;
-            pk.x = pack_h16x2(acc[r][u][0], acc[r][u][1]); pk.y = pack_h16x2(acc[r][u][2], acc[r][u][3]);
-            pk.z = pack_h16x2(acc[r][u][4], acc[r][u][5]); pk.w = pack_h16x2(acc[r][u][6], acc[r][u][7]);
+            pk.x = pack_h16x2(v[r][u][0], v[r][u][1]); pk.y = pack_h16x2(v[r][u][2], v[r][u][3]);
+            pk.z = pack_h16x2(v[r][u][4], v[r][u][5]); pk.w = pack_h16x2(v[r][u][6], v[r][u][7]);
             if (vi < nvec && row0 + r < rows) *(uint4*)(y_out + (long long)(row0 + r) * C + vi * 8) = pk;
             const unsigned w[4] = {pk.x, pk.y, pk.z, pk.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { acc[r][u][2 * k] = h16_lo(w[k]); acc[r][u][2 * k + 1] = h16_hi(w[k]); }
+            for (int k = 0; k < 4; ++k) { v[r][u][2 * k] = h16_lo(w[k]); v[r][u][2 * k + 1] = h16_hi(w[k]); }
             if (vi < nvec) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) s += acc[r][u][k];
+                for (int k = 0; k < 8; ++k) s += v[r][u][k];
             }
         }
         if (!n3_out) continue;
@@ -443,7 +515,7 @@ __global__ __launch_bounds__(256) void cross_fold_kernel(const h16_t* __restrict
         for (int u = 0; u < VPT; ++u)
             if (lane + u * 64 < nvec) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { const float d = acc[r][u][k] - m3; q += d * d; }
+                for (int k = 0; k < 8; ++k) { const float dd = v[r][u][k] - m3; q += dd * dd; }
             }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
@@ -457,7 +529,7 @@ __global__ __launch_bounds__(256) void cross_fold_kernel(const h16_t* __restrict
                 const float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w}, bt[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
                 float o8[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) o8[k] = (acc[r][u][k] - m3) * r3 * gg[k] + bt[k];
+                for (int k = 0; k < 8; ++k) o8[k] = (v[r][u][k] - m3) * r3 * gg[k] + bt[k];
                 uint4 pk;
                 pk.x = pack_h16x2(o8[0], o8[1]); pk.y = pack_h16x2(o8[2], o8[3]); pk.z = pack_h16x2(o8[4], o8[5]); pk.w = pack_h16x2(o8[6], o8[7]);
                 *(uint4*)(n3_out + (long long)(row0 + r) * C + vi * 8) = pk;
@@ -467,12 +539,35 @@ __global__ __launch_bounds__(256) void cross_fold_kernel(const h16_t* __restrict
 }
 
 // y_out may alias y (a wave reads its rows completely before it writes them); n3_out optional.  C % 8 == 0, C <= 1536.
+bool cross_attn_fold_supported(int C, int heads) {
+    return (C % 8) == 0 && C <= 1536 && C == 64 * heads && (heads == 1 || heads == 2 || heads == 4 || heads == 5 || heads == 10 || heads == 20);
+}
+template <int VPT, int R, int HEADS>
+static void launch_cross_fold_one(const h16_t* y, h16_t* y_out, h16_t* n3_out, const float* U, const float* u0, const float* G, const float* c0,
+                                  const float* g3, const float* b3, int rows, int C, float eps, hipStream_t s) {
+    dim3 grid((rows + 4 * R - 1) / (4 * R));
+    hipLaunchKernelGGL((cross_fold_kernel<VPT, R, HEADS>), grid, dim3(256), 0, s, y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, eps);
+}
+template <int VPT, int HEADS>
+static void launch_cross_fold_r(const h16_t* y, h16_t* y_out, h16_t* n3_out, const float* U, const float* u0, const float* G, const float* c0,
+                                const float* g3, const float* b3, int rows, int C, float eps, hipStream_t s) {
+    // rows per wave: 4 (the U / G rows a wave streams are reused four times) once that still leaves >= 2 waves per SIMD on the chip
+    if (rows >= 16384 && VPT * HEADS <= 20) launch_cross_fold_one<VPT, 4, HEADS>(y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, eps, s);
+    else if (rows >= 4096) launch_cross_fold_one<VPT, 2, HEADS>(y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, eps, s);
+    else launch_cross_fold_one<VPT, 1, HEADS>(y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, eps, s);
+}
 void launch_cross_attn_fold(const h16_t* y, h16_t* y_out, h16_t* n3_out, const float* U, const float* u0, const float* G, const float* c0,
                             const float* g3, const float* b3, int rows, int C, int heads, float eps, hipStream_t s) {
     const int vpt = (C / 8 + 63) / 64;
-    constexpr int R = 4;
-    dim3 grid((rows + 4 * R - 1) / (4 * R));
-    if (vpt <= 1) hipLaunchKernelGGL((cross_fold_kernel<1, R>), grid, dim3(256), 0, s, y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, heads, eps);
-    else if (vpt <= 2) hipLaunchKernelGGL((cross_fold_kernel<2, R>), grid, dim3(256), 0, s, y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, heads, eps);
-    else hipLaunchKernelGGL((cross_fold_kernel<3, R>), grid, dim3(256), 0, s, y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, heads, eps);
+#define GP_CF(V, H) launch_cross_fold_r<V, H>(y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, eps, s)
+    (void)vpt;  // C == 64 * heads: 8 * heads channel vectors per row
+    switch (heads) {
+        case 1: GP_CF(1, 1); break;
+        case 2: GP_CF(1, 2); break;
+        case 4: GP_CF(1, 4); break;
+        case 5: GP_CF(1, 5); break;     // SD2.1: 320 / 640 / 1280 channels
+        case 10: GP_CF(2, 10); break;
+        default: GP_CF(3, 20); break;
+    }
+#undef GP_CF
 }

@@ -417,11 +417,8 @@ int pgemm_bm(const IGemmParams& p) {
 template <int BM, int ABL>
 static void launch_pgemm_one(const IGemmParams& p, int ncu, hipStream_t s) {
     using G = PGemmGeom<BM>;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)pgemm_kernel<BM, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-        attr = true;
-    }
+    static unsigned long long attr_mask = 0;
+    if (gp_first_use_on_device(&attr_mask)) (void)hipFuncSetAttribute((const void*)pgemm_kernel<BM, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
     const int tiles_n = (ncols + PG_BN - 1) / PG_BN, tiles_m = (p.M + BM - 1) / BM;
     int groups = ncu / tiles_n;

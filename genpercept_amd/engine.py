@@ -66,6 +66,7 @@ class GpTimings(C.Structure):
         ("flops_igemm", C.c_double), ("flops_attn", C.c_double),
         ("ms_igemm", C.c_float), ("ms_attn", C.c_float),
         ("n_igemm", C.c_int), ("n_attn", C.c_int), ("n_launches", C.c_int),
+        ("flops_halo", C.c_double), ("ms_halo", C.c_float), ("n_halo", C.c_int),
     ]
 
 
@@ -107,6 +108,7 @@ SYMBOLS = {
     "gp_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "gp_flash_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "gp_cross_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "gp_mfma_peak_tflops": (C.c_double, [_i, _vp]),
     "gp_cross_attention_fold": (_i, [_vp] * 9 + [_i, _i, _i, _f, _vp]),
     "gp_softmax_rows": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "gp_softmax_rows_f16": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
@@ -134,8 +136,10 @@ def load_library(precision: Optional[str] = None, path: Optional[str] = None):
     return lib
 
 
-def _stream_ptr() -> int:
-    return int(torch.cuda.current_stream().cuda_stream)
+def _stream_ptr(device=None) -> int:
+    """HIP stream handle of torch's current stream on `device` (an engine passes ITS device: with several GPUs in one process the
+    calling thread's current device may be another one)."""
+    return int(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -244,7 +248,7 @@ class Engine:
         lh, lw = self.lib.gp_latent_size(h), self.lib.gp_latent_size(w)
         oh, ow = (self.lib.gp_dpt_out_size(lh), self.lib.gp_dpt_out_size(lw)) if self.cfg.dpt_enabled else (8 * lh, 8 * lw)
         out = torch.empty((b, c, oh, ow), dtype=torch.float32, device=rgb.device)
-        self._check(self.lib.gp_infer(self._h, rgb.data_ptr(), int(is_u8), b, h, w, MODES[mode], out.data_ptr(), _stream_ptr()))
+        self._check(self.lib.gp_infer(self._h, rgb.data_ptr(), int(is_u8), b, h, w, MODES[mode], out.data_ptr(), _stream_ptr(self.device)))
         return out
 
     def vae_encode(self, rgb: torch.Tensor) -> torch.Tensor:
@@ -253,7 +257,7 @@ class Engine:
         b, _, h, w = rgb.shape
         out = torch.empty((b, self.cfg.vae_latent_channels, self.lib.gp_latent_size(h), self.lib.gp_latent_size(w)), dtype=torch.float32,
                           device=rgb.device)
-        self._check(self.lib.gp_vae_encode(self._h, rgb.data_ptr(), int(is_u8), b, h, w, out.data_ptr(), _stream_ptr()))
+        self._check(self.lib.gp_vae_encode(self._h, rgb.data_ptr(), int(is_u8), b, h, w, out.data_ptr(), _stream_ptr(self.device)))
         return out
 
     def _feat_shapes(self, b, h, w):
@@ -270,21 +274,21 @@ class Engine:
         if want_feats:
             feats = [torch.empty(s, dtype=torch.float32, device=latent.device) for s in self._feat_shapes(b, h, w)]
             fp = (C.c_void_p * 4)(*[f.data_ptr() for f in feats])
-        self._check(self.lib.gp_unet(self._h, latent.data_ptr(), b, h, w, _ptr(sample), fp, _stream_ptr()))
+        self._check(self.lib.gp_unet(self._h, latent.data_ptr(), b, h, w, _ptr(sample), fp, _stream_ptr(self.device)))
         return sample, feats
 
     def vae_decode(self, pred_latent: torch.Tensor, mean3: bool) -> torch.Tensor:
         z = pred_latent.float().contiguous()
         b, _, h, w = z.shape
         out = torch.empty((b, 1 if mean3 else 3, h * 8, w * 8), dtype=torch.float32, device=z.device)
-        self._check(self.lib.gp_vae_decode(self._h, z.data_ptr(), b, h, w, int(mean3), out.data_ptr(), _stream_ptr()))
+        self._check(self.lib.gp_vae_decode(self._h, z.data_ptr(), b, h, w, int(mean3), out.data_ptr(), _stream_ptr(self.device)))
         return out
 
     def vae_mid_attention(self, x: torch.Tensor, decoder: bool) -> torch.Tensor:
         x = x.float().contiguous()
         b, _, h, w = x.shape
         out = torch.empty_like(x)
-        self._check(self.lib.gp_vae_mid_attention(self._h, int(decoder), x.data_ptr(), b, h, w, out.data_ptr(), _stream_ptr()))
+        self._check(self.lib.gp_vae_mid_attention(self._h, int(decoder), x.data_ptr(), b, h, w, out.data_ptr(), _stream_ptr(self.device)))
         return out
 
     def dpt_head(self, feats: Sequence[torch.Tensor]) -> torch.Tensor:
@@ -292,7 +296,7 @@ class Engine:
         b, _, h, w = feats[0].shape
         out = torch.empty((b, self.lib.gp_dpt_out_size(h), self.lib.gp_dpt_out_size(w)), dtype=torch.float32, device=feats[0].device)
         fp = (C.c_void_p * 4)(*[f.data_ptr() for f in feats])
-        self._check(self.lib.gp_dpt_head(self._h, fp, b, h, w, out.data_ptr(), _stream_ptr()))
+        self._check(self.lib.gp_dpt_head(self._h, fp, b, h, w, out.data_ptr(), _stream_ptr(self.device)))
         return out
 
     # -- profiling -----------------------------------------------------------------------------------------------------
@@ -476,6 +480,11 @@ def cross_attention(q: torch.Tensor, kc: torch.Tensor, vc: torch.Tensor) -> torc
     if st != GP_OK:
         raise RuntimeError(f"gp_cross_attention failed ({st})")
     return out
+
+
+def mfma_peak_tflops(device: int = 0, precision: Optional[str] = None) -> float:
+    """Measured MFMA peak of this chip (TFLOP/s, dense, the library's 16-bit element type)."""
+    return float(load_library(precision).gp_mfma_peak_tflops(device, _stream_ptr()))
 
 
 def cross_attention_fold(y: torch.Tensor, U: torch.Tensor, u0: torch.Tensor, G: torch.Tensor, c0: torch.Tensor, g3: torch.Tensor, b3: torch.Tensor,

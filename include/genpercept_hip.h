@@ -19,7 +19,12 @@
  * Ownership: the engine owns weights, folded constants and its activation pool.  The caller owns every in/out DEVICE
  * buffer (e.g. PyTorch-ROCm tensors passed by data_ptr()) and keeps them alive until the stream has been synchronised.
  * Errors: every call returns gp_status; gp_last_error() gives the message.  Nothing throws across the ABI.
- * Threading: one engine per GPU; an engine is not re-entrant; different engines may run on different host threads.
+ * Threading: one engine per GPU; an engine is not re-entrant; different engines (same or different GPUs) may run on different host
+ *   threads concurrently: every workspace an engine call touches (activation pool, split-K partial sums, GroupNorm statistics, min-max
+ *   partials) belongs to that engine, and per-device kernel attributes are set per device.  An engine recycles activation buffers in
+ *   stream order; if consecutive calls pass different streams, the engine synchronises the previous stream first.  A call that fails
+ *   returns every buffer it had taken to the engine's pool.  The per-kernel entry points (parity-test interface) share one scratch
+ *   set per device and serialise on a process-wide mutex while they enqueue.
  */
 #ifndef GENPERCEPT_HIP_H
 #define GENPERCEPT_HIP_H
@@ -66,6 +71,9 @@ typedef struct gp_timings {
     double flops_igemm, flops_attn;                /* algorithmic flops issued since gp_reset_timings */
     float ms_igemm, ms_attn;                       /* summed kernel time of those launches (profiling level 2) */
     int n_igemm, n_attn, n_launches;
+    double flops_halo;                             /* the dominant kernel alone: conv3x3_halo3_kernel (a subset of the igemm figures) */
+    float ms_halo;
+    int n_halo;
 } gp_timings;
 
 void gp_default_config(gp_config* cfg);                                  /* SD2.1 values */
@@ -112,6 +120,10 @@ gp_status gp_reset_timings(gp_engine* e);
 /* Profiling level 3: text log of the last gp_infer, one line "ms<TAB>algorithmic flops<TAB>description" per kernel launch
  * (ms = start-to-next-start on the stream: kernel time plus the gap behind it).  Returns the bytes needed (incl. NUL). */
 int gp_get_launch_log(gp_engine* e, char* buf, int cap);
+
+/* Sustained TFLOP/s of back-to-back v_mfma_f32_32x32x16 (this library's element type) on every CU of `device`: the chip's own MFMA
+ * peak under load, reported by bench.py beside the nominal 2.5 PFLOP/s.  < 0 on error. */
+double gp_mfma_peak_tflops(int device, void* stream);
 
 /* ---- per-kernel entry points (DEVICE pointers, bf16 NHWC activations) -------------------------------------------- */
 /* Pack an OIHW fp32 HOST weight into the device layout [n_rows][taps][cin_pad] bf16 (n_rows = gp_packed_rows(cout)). */

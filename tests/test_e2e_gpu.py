@@ -464,3 +464,116 @@ def test_full_size_768_properties_dpt_head(metric_log):
         metric_log("full768_dpt_properties", out_std=a.std().item(), batch1_vs_batch4_mean_abs=dsz.mean().item(), max_abs=dsz.max().item())
     finally:
         eng.close()
+
+
+def _two_engine_job(dev_index, tw, ctx, rgb_u8, out, key, rounds=3):
+    """Worker of the threading tests: build an engine, run `rounds` inferences, keep the last result."""
+    try:
+        torch.cuda.set_device(dev_index)
+        from genpercept_amd.engine import Engine
+        eng = Engine(dev_index, tw["uc"], tw["vc"], None)
+        eng.load_state_dict("vae", tw["vsd"])
+        eng.load_state_dict("unet", tw["usd"])
+        eng.set_context(torch.as_tensor(ctx))
+        eng.finalize()
+        d = torch.device("cuda", dev_index)
+        x = torch.as_tensor(rgb_u8).to(d)
+        for _ in range(rounds):
+            y = eng.infer(x, "depth")
+        torch.cuda.synchronize(d)
+        out[key] = y.cpu()
+        eng.close()
+    except Exception as ex:  # surfaced by the caller
+        out[key] = ex
+
+
+def test_two_engines_on_two_threads_one_gpu(tiny_weights, golden, metric_log):
+    """The C-ABI's threading sentence (include/genpercept_hip.h): different engines may be driven from different host threads.  Two
+    engines on the SAME GPU, each on its own thread and torch stream, through shapes that take the split-K path (12x12 .. 2x2 maps,
+    long K) and the GroupNorm workspaces: results must equal the single-threaded result bit for bit."""
+    import threading
+    ref = {}
+    _two_engine_job(0, tiny_weights, golden["sq_ctx"], golden["sq_rgb_u8"], ref, "ref", rounds=1)
+    assert torch.is_tensor(ref["ref"]), ref["ref"]
+    out = {}
+
+    def run(key):
+        with torch.cuda.stream(torch.cuda.Stream(device=0)):
+            _two_engine_job(0, tiny_weights, golden["sq_ctx"], golden["sq_rgb_u8"], out, key, rounds=4)
+
+    ths = [threading.Thread(target=run, args=(k,)) for k in ("a", "b")]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for k in ("a", "b"):
+        assert torch.is_tensor(out[k]), out[k]
+        assert torch.equal(out[k], ref["ref"]), f"engine {k} differs from the single-threaded run"
+    metric_log("two_engines_two_threads_one_gpu", bitwise=1.0)
+
+
+def test_two_engines_alternating_streams(tiny_weights, golden, metric_log):
+    """Two engines on one GPU driven alternately, and one engine driven from two different streams in turn (the pool's stream fence)."""
+    from genpercept_amd.engine import Engine
+    d = torch.device("cuda", 0)
+    engs = []
+    for _ in range(2):
+        e = Engine(0, tiny_weights["uc"], tiny_weights["vc"], None)
+        e.load_state_dict("vae", tiny_weights["vsd"])
+        e.load_state_dict("unet", tiny_weights["usd"])
+        e.set_context(torch.as_tensor(golden["sq_ctx"]))
+        e.finalize()
+        engs.append(e)
+    try:
+        x = torch.as_tensor(golden["sq_rgb_u8"]).to(d)
+        ref = engs[0].infer(x, "depth").clone()
+        s1, s2 = torch.cuda.Stream(device=d), torch.cuda.Stream(device=d)
+        torch.cuda.synchronize()
+        outs = []
+        for i in range(6):
+            with torch.cuda.stream(s1 if i % 2 else s2):
+                outs.append(engs[i % 2].infer(x, "depth"))        # engines alternate, each always on its own stream
+                outs.append(engs[0].infer(x, "depth"))            # ... and engine 0 additionally hops between the two streams
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, ref)
+        metric_log("two_engines_alternating_streams", bitwise=1.0)
+    finally:
+        for e in engs:
+            e.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process")
+def test_two_engines_two_gpus_two_threads(tiny_weights, golden, metric_log):
+    """One engine per GPU, one host thread each (what an in-process 8-GPU driver does): per-device kernel attributes and workspaces."""
+    import threading
+    out = {}
+    ths = [threading.Thread(target=_two_engine_job, args=(i, tiny_weights, golden["sq_ctx"], golden["sq_rgb_u8"], out, i)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert torch.is_tensor(out[0]) and torch.is_tensor(out[1]), out
+    assert torch.equal(out[0], out[1])
+
+
+def test_failed_call_returns_buffers(tiny_weights, golden):
+    """A stage that throws mid-way (here: a UNet without context) must hand its activations back to the pool: the next calls work and the
+    pool does not grow."""
+    from genpercept_amd.engine import Engine
+    d = torch.device("cuda", 0)
+    e = Engine(0, tiny_weights["uc"], tiny_weights["vc"], None)
+    try:
+        e.load_state_dict("vae", tiny_weights["vsd"])
+        e.load_state_dict("unet", tiny_weights["usd"])
+        e.finalize()  # no set_context: the first transformer block raises after the encoder and several UNet layers have run
+        x = torch.as_tensor(golden["sq_rgb_u8"]).to(d)
+        for _ in range(3):
+            with pytest.raises(RuntimeError):
+                e.infer(x, "depth")
+        e.set_context(torch.as_tensor(golden["sq_ctx"]))
+        y = e.infer(x, "depth")
+        assert torch.isfinite(y).all()
+        assert float(np.abs(y.cpu().numpy() - golden["sq_depth"]).mean()) <= TOL_MAP_MEAN
+    finally:
+        e.close()

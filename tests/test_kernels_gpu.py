@@ -343,7 +343,9 @@ def test_gemm_geglu(mc, metric_log):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 64, True), (1, 128, 4096, True), (2, 320, 300, False), (1, 960, 144, True), (3, 2560, 36, True),
-                                  (1, 512, 1, True), (1, 128, 70000, True)])
+                                  (1, 512, 1, True), (1, 128, 70000, True),
+                                  # the one-launch small-map kernel (a group's block per workgroup; B * 32 >= 64 workgroups, (C / 32) % 8 == 0)
+                                  (4, 1280, 144, True), (4, 2560, 144, True), (2, 1280, 576, False), (4, 256, 37, True)])
 def test_groupnorm(case, metric_log):
     e = _eng()
     b, c, hw, silu = case
@@ -503,7 +505,7 @@ def test_heaviest_layers_batch4_vs_fp32(case, metric_log):
     check(f"heavy_b4{case}", yc, ref, metric_log)
 
 
-@pytest.mark.parametrize("case", [(150, 320, 5), (37, 640, 10), (64, 1280, 20), (5, 192, 3)])
+@pytest.mark.parametrize("case", [(150, 320, 5), (37, 640, 10), (64, 1280, 20), (5, 256, 4), (20000, 320, 5), (5000, 128, 2)])
 def test_cross_attention_two_token_fold(case, metric_log):
     """attn2 of the BasicTransformerBlock against a 2-token context (GenPercept's empty prompt, genpercept_pipeline.py:425-429) folded into
     per-head vectors: the kernel must equal LayerNorm -> to_q -> softmax(q k^T / 8) v -> to_out -> + residual, then norm3, computed
