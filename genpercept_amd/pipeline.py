@@ -38,6 +38,13 @@ class GenPerceptOutput:
     pred_colored: Union[None, Image.Image]
 
 
+def _load_file(f: str) -> Dict[str, torch.Tensor]:
+    if f.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(f)
+    return torch.load(f, map_location="cpu", weights_only=True)
+
+
 def _load_checkpoint_dir(path: str) -> Dict[str, torch.Tensor]:
     """diffusers on-disk layouts consumed by run.py:296-333."""
     cands = ["diffusion_pytorch_model.safetensors", "model.safetensors", "diffusion_pytorch_model.bin", "pytorch_model.bin"]
@@ -49,11 +56,54 @@ def _load_checkpoint_dir(path: str) -> Dict[str, torch.Tensor]:
             return _load_checkpoint_dir(os.path.join(path, "unet"))
     if not files:
         raise FileNotFoundError(f"no diffusers checkpoint under {path}")
-    f = files[0]
-    if f.endswith(".safetensors"):
-        from safetensors.torch import load_file
-        return load_file(f)
-    return torch.load(f, map_location="cpu", weights_only=True)
+    return _load_file(files[0])
+
+
+def compose_finetuned_vae(base_vae, ckpt_dir: str) -> Dict[str, torch.Tensor]:
+    """run.py:308-312: a fine-tuned decoder is saved RELATIVE to its sub-module -- `<ckpt>/vae_decoder/model.safetensors` holds
+    `conv_in.weight` ... (no `decoder.` prefix), `<ckpt>/vae_post_quant_conv/model.safetensors` holds `weight`, `bias` -- and is loaded
+    over the base VAE's decoder / post_quant_conv.  Returns the full VAE state dict (encoder and quant_conv from `base_vae`)."""
+    sd = dict(_state_dict_of(base_vae))
+    dec = _load_checkpoint_dir(os.path.join(ckpt_dir, "vae_decoder"))
+    pq = _load_checkpoint_dir(os.path.join(ckpt_dir, "vae_post_quant_conv"))
+    missing = [k for k in sd if k.startswith("decoder.") and k[len("decoder."):] not in dec]
+    extra = [k for k in dec if "decoder." + k not in sd]
+    if missing or extra:
+        raise KeyError(f"vae_decoder checkpoint does not match the base VAE's decoder (missing {missing[:3]}, unexpected {extra[:3]})")
+    for k, v in dec.items():
+        sd["decoder." + k] = v
+    for k, v in pq.items():
+        if "post_quant_conv." + k not in sd:
+            raise KeyError(f"unexpected key {k} in vae_post_quant_conv")
+        sd["post_quant_conv." + k] = v
+    return sd
+
+
+# class names of the reference's two DPT heads (genpercept/models/dpt_head.py:391, 585): identical parameter sets, but only the
+# ...Identity one is accepted by single_infer (genpercept_pipeline.py:474, 483-484); the other ends in a ReLU (dpt_head.py:69-76)
+_HEAD_IDENTITY = "DPTNeckHeadForUnetAfterUpsampleIdentity"
+_HEAD_RELU = "DPTNeckHeadForUnetAfterUpsample"
+
+
+def _head_kind(obj, declared: Optional[str]) -> Optional[str]:
+    """'identity' / 'relu' / None (unknown) for a customized_head argument: explicit `head_type`, else the module's class name, else the
+    checkpoint directory name (run.py:296-307 loads `dpt_head_identity/` into the Identity class and `dpt_head/` into the other)."""
+    if declared is not None:
+        if declared not in ("identity", "relu"):
+            raise ValueError(f"head_type must be 'identity' or 'relu', got {declared!r}")
+        return declared
+    name = type(obj).__name__
+    if name == _HEAD_IDENTITY:
+        return "identity"
+    if name == _HEAD_RELU:
+        return "relu"
+    if isinstance(obj, (str, os.PathLike)):
+        parts = [p for p in os.path.normpath(str(obj)).split(os.sep) if p]
+        if "dpt_head_identity" in parts:
+            return "identity"
+        if "dpt_head" in parts:
+            return "relu"
+    return None
 
 
 def _state_dict_of(obj) -> Optional[Dict[str, torch.Tensor]]:
@@ -87,7 +137,7 @@ class GenPerceptPipeline:
 
     def __init__(self, unet, vae, scheduler=None, text_encoder=None, tokenizer=None, default_denoising_steps: Optional[int] = 10,
                  default_processing_resolution: Optional[int] = 768, rgb_blending=False, customized_head=None, genpercept_pipeline=True,
-                 device: Union[str, int, torch.device, None] = None, torch_dtype: Optional[torch.dtype] = None):
+                 device: Union[str, int, torch.device, None] = None, torch_dtype: Optional[torch.dtype] = None, head_type: Optional[str] = None):
         self.genpercept_pipeline = genpercept_pipeline
         if not genpercept_pipeline:
             raise NotImplementedError("only the one-step archs=genpercept path is implemented (multi-step marigold/rgb_blending are out of scope)")
@@ -100,6 +150,10 @@ class GenPerceptPipeline:
             if bs != 1 or be != 1 or pt != "v_prediction":
                 raise NotImplementedError(f"one-step GenPercept needs the beta=1/1 v_prediction scheduler (got beta {bs}/{be}, {pt})")
         self._unet_src, self._vae_src, self._head_src = unet, vae, customized_head
+        self._head_kind = _head_kind(customized_head, head_type) if customized_head is not None else None
+        if self._head_kind == "relu":  # genpercept_pipeline.py:474,483-484: only the ...Identity head is a valid customized_head
+            raise ValueError("unsupported customized_head: DPTNeckHeadForUnetAfterUpsample (ReLU-terminated); "
+                             "single_infer accepts DPTNeckHeadForUnetAfterUpsampleIdentity only (genpercept_pipeline.py:483-484)")
         self.text_encoder, self.tokenizer = text_encoder, tokenizer
         self.default_denoising_steps = default_denoising_steps
         self.default_processing_resolution = default_processing_resolution
@@ -127,6 +181,17 @@ class GenPerceptPipeline:
         """run.py:370-376 call shape: sub-folders unet/, vae/ (+ text_encoder/, tokenizer/) unless passed as kwargs."""
         kw = dict(kwargs)
         kw.setdefault("torch_dtype", torch_dtype)
+        # run.py:296-312 (`--load_decoder_ckpt`): a fine-tuned head lives next to the UNet checkpoint as dpt_head_identity/ (DPT head),
+        # dpt_head/ (the ReLU-terminated head single_infer rejects) or vae_decoder/ + vae_post_quant_conv/ (fine-tuned VAE decoder)
+        dec_dir = kw.pop("load_decoder_ckpt", None)
+        if dec_dir:
+            have = set(os.listdir(dec_dir))
+            if "dpt_head_identity" in have:
+                kw.setdefault("customized_head", os.path.join(dec_dir, "dpt_head_identity"))
+            elif "dpt_head" in have:
+                kw.setdefault("customized_head", os.path.join(dec_dir, "dpt_head"))
+            elif "vae_decoder" in have and "vae_post_quant_conv" in have and kw.get("vae") is None:
+                kw["vae"] = compose_finetuned_vae(os.path.join(checkpoint, "vae"), dec_dir)
         for name in ("unet", "vae"):
             if kw.get(name) is None:
                 kw[name] = os.path.join(checkpoint, name)
@@ -180,6 +245,9 @@ class GenPerceptPipeline:
         if head_sd is not None:
             if not any(k.startswith("neck.fusion_stage") for k in head_sd):
                 raise ValueError("unsupported customized_head (genpercept_pipeline.py:483-484)")
+            if self._head_kind is None:  # a bare state dict: the two reference classes have identical keys, so it cannot be told apart
+                logging.warning("customized_head given as a plain state dict: assuming DPTNeckHeadForUnetAfterUpsampleIdentity "
+                                "(pass head_type='identity' to silence, 'relu' raises like the reference)")
             ucfg = gcfg.UNetConfig(**{**ucfg.__dict__, "has_out": False})
         eng = Engine(self._device.index or 0, ucfg, vcfg, dcfg, precision=self._precision)
         eng.load_state_dict("vae", vae_sd)

@@ -315,3 +315,96 @@ def test_image_util_matches_reference():
         except ValueError:
             got = "!ValueError"
         assert got == str(want), (name, got, want)
+
+
+def test_genpercept_import_path_shim():
+    """`from genpercept import GenPerceptPipeline` (run.py:33, infer.py:30) resolves to this engine's pipeline."""
+    import genpercept
+    import genpercept.genpercept_pipeline as gpp
+    from genpercept_amd.pipeline import GenPerceptOutput, GenPerceptPipeline
+    assert genpercept.GenPerceptPipeline is GenPerceptPipeline and genpercept.GenPerceptOutput is GenPerceptOutput
+    assert gpp.GenPerceptPipeline is GenPerceptPipeline
+    assert GenPerceptPipeline.latent_scale_factor == 0.18215
+
+
+def test_customized_head_kind_like_the_reference():
+    """genpercept_pipeline.py:474,483-484: only DPTNeckHeadForUnetAfterUpsampleIdentity is a valid customized_head; the ReLU-terminated
+    DPTNeckHeadForUnetAfterUpsample (same keys! run.py:303-307 loads it from `dpt_head/`) raises ValueError."""
+    from genpercept_amd.pipeline import GenPerceptPipeline
+
+    class DPTNeckHeadForUnetAfterUpsample:  # stands in for the reference module: only the class name and state_dict() matter
+        def state_dict(self):
+            return {"neck.fusion_stage.layers.0.projection.weight": torch.zeros(1)}
+
+    class DPTNeckHeadForUnetAfterUpsampleIdentity(DPTNeckHeadForUnetAfterUpsample):
+        pass
+
+    sched = dict(beta_start=1.0, beta_end=1.0, prediction_type="v_prediction")
+    with pytest.raises(ValueError):
+        GenPerceptPipeline(unet={}, vae={}, scheduler=sched, customized_head=DPTNeckHeadForUnetAfterUpsample())
+    with pytest.raises(ValueError):
+        GenPerceptPipeline(unet={}, vae={}, scheduler=sched, customized_head="/ckpt/run1/dpt_head")
+    with pytest.raises(ValueError):
+        GenPerceptPipeline(unet={}, vae={}, scheduler=sched, customized_head={"neck.x": torch.zeros(1)}, head_type="relu")
+    for head, kw in ((DPTNeckHeadForUnetAfterUpsampleIdentity(), {}), ("/ckpt/run1/dpt_head_identity", {}), ({"neck.x": torch.zeros(1)}, {"head_type": "identity"})):
+        p = GenPerceptPipeline(unet={}, vae={}, scheduler=sched, customized_head=head, **kw)
+        assert p._head_kind == "identity"
+    assert GenPerceptPipeline(unet={}, vae={}, scheduler=sched, customized_head={"neck.x": torch.zeros(1)})._head_kind is None
+
+
+def test_finetuned_vae_decoder_directories(tmp_path):
+    """run.py:308-312: vae_decoder/model.safetensors (keys without the `decoder.` prefix) + vae_post_quant_conv/model.safetensors are
+    composed over the base VAE; from_pretrained(load_decoder_ckpt=...) does it by path."""
+    from safetensors.torch import save_file
+    from genpercept_amd import config as gc
+    from genpercept_amd import weights as gw
+    from genpercept_amd.pipeline import GenPerceptPipeline, compose_finetuned_vae
+    vc = gc.VAEConfig(block_out_channels=(64, 64, 64, 64))
+    base = gw.synth_state_dict(gw.vae_manifest(vc), seed=4)
+    tuned = gw.synth_state_dict(gw.vae_manifest(vc), seed=5)
+    (tmp_path / "sd" / "vae").mkdir(parents=True)
+    (tmp_path / "ft" / "vae_decoder").mkdir(parents=True)
+    (tmp_path / "ft" / "vae_post_quant_conv").mkdir(parents=True)
+    save_file(dict(base), str(tmp_path / "sd" / "vae" / "diffusion_pytorch_model.safetensors"))
+    save_file({k[len("decoder."):]: v for k, v in tuned.items() if k.startswith("decoder.")}, str(tmp_path / "ft" / "vae_decoder" / "model.safetensors"))
+    save_file({k[len("post_quant_conv."):]: v for k, v in tuned.items() if k.startswith("post_quant_conv.")},
+              str(tmp_path / "ft" / "vae_post_quant_conv" / "model.safetensors"))
+    sd = compose_finetuned_vae(str(tmp_path / "sd" / "vae"), str(tmp_path / "ft"))
+    assert set(sd) == set(base)
+    for k in sd:
+        src = tuned if k.startswith(("decoder.", "post_quant_conv.")) else base
+        assert torch.equal(sd[k], src[k]), k
+    pipe = GenPerceptPipeline.from_pretrained(str(tmp_path / "sd"), unet={}, load_decoder_ckpt=str(tmp_path / "ft"),
+                                              scheduler=dict(beta_start=1.0, beta_end=1.0, prediction_type="v_prediction"))
+    assert torch.equal(pipe._vae_src["decoder.conv_in.weight"], tuned["decoder.conv_in.weight"])
+    bad = {k: v for k, v in tuned.items() if k.startswith("decoder.") and "conv_out" not in k}
+    save_file({k[len("decoder."):]: v for k, v in bad.items()}, str(tmp_path / "ft" / "vae_decoder" / "model.safetensors"))
+    with pytest.raises(KeyError):
+        compose_finetuned_vae(str(tmp_path / "sd" / "vae"), str(tmp_path / "ft"))
+
+
+def test_encode_text_hf_clip_branch(tmp_path):
+    """genpercept_pipeline.py:360-372 with REAL HF objects (a randomly initialised small CLIPTextModel and a CLIPTokenizer built from an
+    on-the-fly vocabulary; no checkpoint exists offline): padding='do_not_pad' gives the BOS, EOS pair for the empty prompt, the embedding
+    is cached, and -- CLIP's causal mask -- it equals rows [0:2] of the 77-token padded encoding the v1 pipeline stores as
+    empty_text_embed.npy, which is why the engine accepts either."""
+    import json
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTokenizer
+    from genpercept_amd.pipeline import GenPerceptPipeline
+    json.dump({"<|startoftext|>": 0, "<|endoftext|>": 1, "a</w>": 2, "b</w>": 3, "a": 4, "b": 5}, open(tmp_path / "vocab.json", "w"))
+    open(tmp_path / "merges.txt", "w").write("#version: 0.2\n")
+    tok = CLIPTokenizer(str(tmp_path / "vocab.json"), str(tmp_path / "merges.txt"), model_max_length=77)
+    torch.manual_seed(0)
+    enc = CLIPTextModel(CLIPTextConfig(vocab_size=8, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                                       max_position_embeddings=77, bos_token_id=0, eos_token_id=1)).eval()
+    pipe = GenPerceptPipeline(unet={}, vae={}, scheduler=dict(beta_start=1.0, beta_end=1.0, prediction_type="v_prediction"),
+                              text_encoder=enc, tokenizer=tok)
+    assert pipe.text_embed is None
+    pipe.encode_text("")
+    assert tuple(pipe.text_embed.shape) == (1, 2, 64) and pipe.text_embed.dtype == torch.float32
+    with torch.no_grad():
+        e77 = enc(tok("", padding="max_length", max_length=77, return_tensors="pt").input_ids)[0]
+    assert torch.allclose(pipe.text_embed, e77[:, :2], atol=1e-5)
+    first = pipe.text_embed
+    pipe.encode_text("a b")  # a non-empty prompt (infer.py --prompt): more tokens, new embedding
+    assert pipe.text_embed.shape[1] == 4 and pipe.text_embed is not first
