@@ -1712,6 +1712,35 @@ gp_status gp_cross_attention_fold(const void* y, void* y_out, void* n3_out, cons
     return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
 }
 
+void gp_resize_max_res_size(int H0, int W0, int max_edge, int* h, int* w) {
+    // image_util.py:95-101: downscale_factor = min(max / W, max / H) in double, new size by int() truncation
+    const double f = std::min((double)max_edge / (double)W0, (double)max_edge / (double)H0);
+    if (h) *h = (int)((double)H0 * f);
+    if (w) *w = (int)((double)W0 * f);
+}
+
+gp_status gp_preprocess(const void* rgb_u8, int B, int H0, int W0, void* out_u8, int h, int w, int resample, float* tmp, void* stream) {
+    if (!rgb_u8 || !out_u8 || B < 1 || H0 < 1 || W0 < 1 || h < 1 || w < 1 || (resample != 0 && resample != 1) || (resample == 0 && !tmp)) return GP_ERR_INVALID;
+    launch_resize(rgb_u8, out_u8, tmp, (long long)B * 3, H0, W0, h, w, resample, 1, 0, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
+}
+
+gp_status gp_postprocess(const float* pred, int B, int C, int h, int w, float* pred_out, int Ho, int Wo, int resample, float* tmp,
+                         const unsigned char* lut_dev, void* colored_out, void* q_out, int q_bits, void* stream) {
+    if (!pred || !pred_out || B < 1 || C < 1 || h < 1 || w < 1 || Ho < 1 || Wo < 1 || (resample != 0 && resample != 1)) return GP_ERR_INVALID;
+    if (colored_out && (!lut_dev || C != 1)) return GP_ERR_INVALID;
+    if (q_out && q_bits != 16 && q_bits != 8) return GP_ERR_INVALID;
+    const bool same = h == Ho && w == Wo;
+    if (!same && resample == 0 && !tmp) return GP_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const long long n = (long long)B * C * Ho * Wo;
+    if (same) launch_clip01(pred, pred_out, n, s);
+    else launch_resize(pred, pred_out, tmp, (long long)B * C, h, w, Ho, Wo, resample, 0, 1, s);
+    if (colored_out) launch_colorize_lut(pred_out, lut_dev, (unsigned char*)colored_out, n, s);
+    if (q_out) launch_quantize(pred_out, q_out, n, q_bits, s);
+    return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
+}
+
 double gp_mfma_peak_tflops(int device, void* stream) {
     if (hipSetDevice(device) != hipSuccess) return -1.0;
     return mfma_peak_tflops(20, (hipStream_t)stream);

@@ -129,5 +129,11 @@ void launch_bilinear(const h16_t* in, h16_t* out, int B, int Hi, int Wi, int Ho,
 void launch_dpt_final(const h16_t* in, const float* w, float bias, float* out, int B, int HW, int Cin, hipStream_t s);  // ReLU'd 32ch -> 1
 void launch_minmax_norm(float* x, int B, long long n, float* ws, hipStream_t s);  // per-image (x-min)/(max-min)
 
+// prepost.hip: device-side pre / post processing of GenPerceptPipeline.__call__ (resize with torchvision semantics, colour map, quantisation)
+void launch_resize(const void* in, void* out, float* tmp, long long planes, int Hi, int Wi, int Ho, int Wo, int mode, int u8, int clip01, hipStream_t s);
+void launch_clip01(const float* in, float* out, long long n, hipStream_t s);
+void launch_colorize_lut(const float* x, const unsigned char* lut, unsigned char* rgb, long long n, hipStream_t s);
+void launch_quantize(const float* x, void* q, long long n, int bits, hipStream_t s);
+
 // microbench.hip: sustained TFLOP/s of back-to-back v_mfma_f32_32x32x16 on this chip (register operands, all CUs), or < 0 on error
 double mfma_peak_tflops(int ms_target, hipStream_t s);

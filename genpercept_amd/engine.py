@@ -108,6 +108,9 @@ SYMBOLS = {
     "gp_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "gp_flash_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "gp_cross_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "gp_resize_max_res_size": (None, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "gp_preprocess": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "gp_postprocess": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "gp_mfma_peak_tflops": (C.c_double, [_i, _vp]),
     "gp_cross_attention_fold": (_i, [_vp] * 9 + [_i, _i, _i, _f, _vp]),
     "gp_softmax_rows": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
@@ -480,6 +483,67 @@ def cross_attention(q: torch.Tensor, kc: torch.Tensor, vc: torch.Tensor) -> torc
     if st != GP_OK:
         raise RuntimeError(f"gp_cross_attention failed ({st})")
     return out
+
+
+RESAMPLE_CODE = {"bilinear": 0, "nearest-exact": 1}  # what the device resize implements (bicubic stays on the host path)
+
+
+def resize_max_res_size(h0: int, w0: int, max_edge: int):
+    lib = load_library()
+    h, w = C.c_int(), C.c_int()
+    lib.gp_resize_max_res_size(h0, w0, max_edge, C.byref(h), C.byref(w))
+    return h.value, w.value
+
+
+def preprocess(rgb_u8: torch.Tensor, size, resample: str = "bilinear") -> torch.Tensor:
+    """resize_max_res of a uint8 [B,3,H0,W0] image ON THE DEVICE to size = (h, w) (image_util.py:75-105; uint8 in, uint8 out)."""
+    lib = load_library()
+    assert rgb_u8.is_cuda and rgb_u8.dtype == torch.uint8 and rgb_u8.dim() == 4 and rgb_u8.shape[1] == 3
+    rgb_u8 = rgb_u8.contiguous()
+    b, _, h0, w0 = rgb_u8.shape
+    h, w = int(size[0]), int(size[1])
+    if (h, w) == (h0, w0):
+        return rgb_u8
+    out = torch.empty((b, 3, h, w), dtype=torch.uint8, device=rgb_u8.device)
+    tmp = torch.empty((b * 3 * h0 * w,), dtype=torch.float32, device=rgb_u8.device) if resample == "bilinear" else None
+    st = lib.gp_preprocess(rgb_u8.data_ptr(), b, h0, w0, out.data_ptr(), h, w, RESAMPLE_CODE[resample], _ptr(tmp), _stream_ptr(rgb_u8.device))
+    if st != GP_OK:
+        raise RuntimeError(f"gp_preprocess failed ({st})")
+    return out
+
+
+_lut_cache: Dict[tuple, torch.Tensor] = {}
+
+
+def colormap_lut(cmap: str, device) -> torch.Tensor:
+    """256 x 3 uint8 table of a matplotlib colour map, exactly the bytes (cm(i / 256...)[:3] * 255).astype(uint8) gives for LUT entry i."""
+    key = (cmap, str(device))
+    if key not in _lut_cache:
+        import matplotlib
+        import numpy as np
+        cm = matplotlib.colormaps[cmap]
+        table = cm(np.arange(256, dtype=np.int64), bytes=False)[:, :3]  # integer input: direct LUT lookup
+        _lut_cache[key] = torch.from_numpy((table * 255).astype(np.uint8)).contiguous().to(device)
+    return _lut_cache[key]
+
+
+def postprocess(pred: torch.Tensor, size, resample: str = "bilinear", cmap: Optional[str] = None, q_bits: int = 0):
+    """pred fp32 [B,C,h,w] on the device -> (pred_out [B,C,H,W] clipped to [0,1], colored uint8 [B,H,W,3] or None, quantised or None)."""
+    lib = load_library()
+    assert pred.is_cuda and pred.dtype == torch.float32 and pred.dim() == 4
+    pred = pred.contiguous()
+    b, c, h, w = pred.shape
+    ho, wo = int(size[0]), int(size[1])
+    out = torch.empty((b, c, ho, wo), dtype=torch.float32, device=pred.device)
+    tmp = torch.empty((b * c * h * wo,), dtype=torch.float32, device=pred.device) if (resample == "bilinear" and (h, w) != (ho, wo)) else None
+    lut = colormap_lut(cmap, pred.device) if cmap is not None else None
+    col = torch.empty((b, ho, wo, 3), dtype=torch.uint8, device=pred.device) if cmap is not None else None
+    q = torch.empty((b, c, ho, wo), dtype=torch.uint16 if q_bits == 16 else torch.uint8, device=pred.device) if q_bits else None
+    st = lib.gp_postprocess(pred.data_ptr(), b, c, h, w, out.data_ptr(), ho, wo, RESAMPLE_CODE[resample], _ptr(tmp), _ptr(lut), _ptr(col), _ptr(q), q_bits,
+                            _stream_ptr(pred.device))
+    if st != GP_OK:
+        raise RuntimeError(f"gp_postprocess failed ({st})")
+    return out, col, q
 
 
 def mfma_peak_tflops(device: int = 0, precision: Optional[str] = None) -> float:

@@ -353,6 +353,45 @@ class GenPerceptPipeline:
         return self._run(images, processing_res, match_input_res, get_resample_method(resample_method), color_map, fix_timesteps, prompt)
 
     def _run(self, rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt) -> List[GenPerceptOutput]:
+        from .engine import RESAMPLE_CODE
+        if rgb.dtype == torch.uint8 and resample in RESAMPLE_CODE and not os.environ.get("GENPERCEPT_HOST_PREPOST"):
+            return self._run_device(rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt)
+        return self._run_host(rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt)
+
+    def _run_device(self, rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt) -> List[GenPerceptOutput]:
+        """Pre / post processing on the GPU (gp_preprocess / gp_postprocess): the uint8 image goes up once, resize_max_res, the model, the
+        resize back to the input size, clip, colour map and the 8-bit image all run on the device; pred_np and the coloured bytes come down."""
+        from . import engine as ge
+        input_size = rgb.shape
+        if color_map is not None:
+            assert self.mode in ["depth", "disparity"]
+        x = rgb.to(self._device, non_blocking=True)
+        if processing_res > 0:
+            x = ge.preprocess(x, ge.resize_max_res_size(int(input_size[-2]), int(input_size[-1]), int(processing_res)), resample)
+        pred = self.single_infer(x, 1, None, False, fix_timesteps, prompt)
+        size = tuple(int(v) for v in input_size[-2:]) if match_input_res else tuple(pred.shape[-2:])
+        one_ch = pred.shape[1] == 1
+        pred_out, col, q8 = ge.postprocess(pred, size, resample, cmap=color_map if one_ch else None, q_bits=0 if color_map is not None else 8)
+        pred_np = pred_out.cpu().numpy()
+        col_np = col.cpu().numpy() if col is not None else None
+        q8_np = q8.cpu().numpy() if q8 is not None else None
+        outs = []
+        for i in range(pred_np.shape[0]):
+            p = pred_np[i].squeeze()
+            if color_map is not None:
+                col_img = Image.fromarray(col_np[i])
+            else:
+                c8 = q8_np[i].squeeze()
+                if c8.ndim == 3 and c8.shape[0] == 3:
+                    c8 = np.transpose(c8, (1, 2, 0))
+                col_img = Image.fromarray(np.ascontiguousarray(c8))
+            if p.ndim == 3 and p.shape[0] == 3:
+                p = np.transpose(p, (1, 2, 0))
+            outs.append(GenPerceptOutput(pred_np=p, pred_colored=col_img))
+        return outs
+
+    def _run_host(self, rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt) -> List[GenPerceptOutput]:
+        """The same steps with the resizes / colour map on the host (torch CPU + matplotlib): float inputs and bicubic resampling."""
         input_size = rgb.shape
         if processing_res > 0:
             rgb = resize_max_res(rgb, max_edge_resolution=processing_res, resample_method=resample)

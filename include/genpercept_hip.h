@@ -121,6 +121,19 @@ gp_status gp_reset_timings(gp_engine* e);
  * (ms = start-to-next-start on the stream: kernel time plus the gap behind it).  Returns the bytes needed (incl. NUL). */
 int gp_get_launch_log(gp_engine* e, char* buf, int cap);
 
+/* ---- pre / post processing of GenPerceptPipeline.__call__ on the device (DEVICE pointers, NCHW) ---------------------------------
+ * resample: 0 = bilinear with antialias (torchvision resize(..., antialias=True): ATen's separable triangle filter), 1 = nearest-exact.
+ * tmp: DEVICE fp32 scratch for the separable bilinear pass, >= B * C * H_in * W_out floats (unused for nearest-exact). */
+/* new size of resize_max_res (genpercept/util/image_util.py:75-105): longest edge -> max_edge, int() truncation */
+void gp_resize_max_res_size(int H0, int W0, int max_edge, int* h, int* w);
+/* resize_max_res on the uint8 RGB [B][3][H0][W0] -> [B][3][h][w] uint8 (fp32 interpolation, round half to even; genpercept_pipeline.py:236-242) */
+gp_status gp_preprocess(const void* rgb_u8, int B, int H0, int W0, void* out_u8, int h, int w, int resample, float* tmp, void* stream);
+/* genpercept_pipeline.py:301-329 + run.py:449-455: pred fp32 [B][C][h][w] -> resize to (Ho, Wo) (skipped when equal) -> clip to [0, 1]
+ * -> pred_out fp32 [B][C][Ho][Wo]; optionally colored_out uint8 [B][Ho][Wo][3] through the 256 x 3 byte colour LUT lut_dev (C == 1), and
+ * q_out = (pred_out * 65535).astype(uint16) (q_bits 16) or (pred_out * 255).astype(uint8) (q_bits 8), [B][C][Ho][Wo]. */
+gp_status gp_postprocess(const float* pred, int B, int C, int h, int w, float* pred_out, int Ho, int Wo, int resample, float* tmp,
+                         const unsigned char* lut_dev, void* colored_out, void* q_out, int q_bits, void* stream);
+
 /* Sustained TFLOP/s of back-to-back v_mfma_f32_32x32x16 (this library's element type) on every CU of `device`: the chip's own MFMA
  * peak under load, reported by bench.py beside the nominal 2.5 PFLOP/s.  < 0 on error. */
 double gp_mfma_peak_tflops(int device, void* stream);

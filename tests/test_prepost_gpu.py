@@ -1,0 +1,87 @@
+"""Device-side pre / post processing (gp_preprocess / gp_postprocess, csrc/prepost.hip) against the host path
+(genpercept_amd/image_util.py = the reference's torchvision / matplotlib recipe, pinned to the reference's outputs in test_host.py).
+
+Tolerances: uint8 resize -- the kernel repeats ATen's separable anti-aliased filter in fp32, accumulation order included, but fused
+multiply-adds differ between the two machines, so a value that lands within ~1e-6 of x.5 may round the other way: at most 1 LSB on at most
+0.1 % of the pixels; fp32 resize: 2e-6 absolute on [0,1] maps; colour LUT and quantisation: bit-exact given the same fp32 input."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("hw", [(480, 640), (1200, 1600), (3024, 4032), (500, 333), (768, 768), (97, 1031)])
+@pytest.mark.parametrize("mode", ["bilinear", "nearest-exact"])
+def test_preprocess_resize_max_res_u8(hw, mode, metric_log):
+    from genpercept_amd import engine as ge
+    from genpercept_amd import image_util as iu
+    g = torch.Generator().manual_seed(hw[0] + hw[1])
+    img = torch.randint(0, 256, (2, 3, hw[0], hw[1]), generator=g, dtype=torch.uint8)
+    img[0, :, : hw[0] // 2] = (torch.arange(hw[1]) % 256).to(torch.uint8)  # smooth part next to the noise
+    ref = iu.resize_max_res(img, 768, mode)
+    size = ge.resize_max_res_size(hw[0], hw[1], 768)
+    assert tuple(ref.shape[-2:]) == size
+    out = ge.preprocess(img.cuda(), size, mode).cpu()
+    assert out.dtype == torch.uint8 and out.shape == ref.shape
+    d = (out.int() - ref.int()).abs()
+    frac = float((d > 0).float().mean())
+    metric_log(f"preprocess_u8{hw}{mode}", max_lsb=int(d.max()), frac_diff=frac)
+    assert int(d.max()) <= (1 if mode == "bilinear" else 0) and frac <= 1e-3
+
+
+@pytest.mark.parametrize("case", [(1, 576, 768, 3024, 4032), (3, 768, 768, 500, 500), (1, 384, 512, 384, 512), (1, 768, 576, 60, 45), (2, 96, 128, 97, 131)])
+@pytest.mark.parametrize("mode", ["bilinear", "nearest-exact"])
+def test_postprocess_resize_clip_colorize_quantize(case, mode, metric_log):
+    from genpercept_amd import engine as ge
+    from genpercept_amd import image_util as iu
+    c, h, w, ho, wo = case
+    g = torch.Generator().manual_seed(h + w + ho)
+    yy, xx = torch.meshgrid(torch.linspace(-0.1, 1.1, h), torch.linspace(0, 1, w), indexing="ij")
+    pred = (0.7 * (yy * xx)[None, None] + 0.3 * torch.rand(2, c, h, w, generator=g)).float()  # leaves [0, 1] so that the clip matters
+    ref = iu.resize_to(pred, (ho, wo), mode).numpy().clip(0, 1)
+    out, col, q = ge.postprocess(pred.cuda(), (ho, wo), mode, cmap="Spectral" if c == 1 else None, q_bits=16)
+    out_np = out.cpu().numpy()
+    err = float(np.abs(out_np - ref).max())
+    metric_log(f"postprocess{case}{mode}", max_abs=err)
+    assert out_np.shape == ref.shape and out_np.min() >= 0.0 and out_np.max() <= 1.0
+    assert err <= (2e-6 if mode == "bilinear" else 0.0)
+    # quantisation and colour map are exact functions of the fp32 map the device produced
+    assert np.array_equal(q.cpu().numpy(), (out_np * 65535.0).astype(np.uint16))
+    if c == 1:
+        for i in range(out_np.shape[0]):
+            want = iu.chw2hwc((iu.colorize_depth_maps(out_np[i, 0], 0, 1, cmap="Spectral").squeeze() * 255).astype(np.uint8))
+            assert np.array_equal(col[i].cpu().numpy(), want)
+    else:
+        assert col is None
+    q8 = ge.postprocess(pred.cuda(), (ho, wo), mode, q_bits=8)[2].cpu().numpy()
+    assert np.array_equal(q8, (out_np * 255.0).astype(np.uint8))
+
+
+def test_pipeline_device_prepost_matches_host_path(monkeypatch, metric_log):
+    """GenPerceptPipeline.__call__ end to end: the device pre / post path against the host path (GENPERCEPT_HOST_PREPOST=1) on the same engine."""
+    import os
+    from PIL import Image
+    from genpercept_amd import GenPerceptPipeline
+    from oracle import sd21 as osd
+    uc, vc = osd.UNetCfg.tiny(), osd.VAECfg.tiny()
+    g = torch.Generator().manual_seed(9)
+    pipe = GenPerceptPipeline(unet=osd.synth_state_dict(osd.unet_manifest(uc), 1), vae=osd.synth_state_dict(osd.vae_manifest(vc), 2),
+                              scheduler=dict(beta_start=1.0, beta_end=1.0, prediction_type="v_prediction"), text_encoder=torch.randn(2, 64, generator=g), tokenizer=None)
+    pipe.to("cuda")
+    arr = torch.randint(0, 256, (150, 200, 3), generator=g, dtype=torch.uint8).numpy()
+    arr[:, :100] = np.linspace(0, 255, 100, dtype=np.uint8)[None, :, None]
+    img = Image.fromarray(arr)
+    for kw in (dict(processing_res=0, mode="depth"), dict(processing_res=96, mode="depth"), dict(processing_res=96, mode="normal", color_map=None),
+               dict(processing_res=64, mode="depth", match_input_res=False, resample_method="nearest")):
+        dev = pipe(img, **kw)
+        monkeypatch.setenv("GENPERCEPT_HOST_PREPOST", "1")
+        host = pipe(img, **kw)
+        monkeypatch.delenv("GENPERCEPT_HOST_PREPOST")
+        assert dev.pred_np.shape == host.pred_np.shape and dev.pred_np.dtype == host.pred_np.dtype == np.float32
+        assert dev.pred_colored.size == host.pred_colored.size and dev.pred_colored.mode == host.pred_colored.mode
+        dm = float(np.abs(dev.pred_np - host.pred_np).mean())
+        dc = float((np.abs(np.asarray(dev.pred_colored).astype(int) - np.asarray(host.pred_colored).astype(int)) > 2).mean())
+        metric_log(f"pipeline_prepost{sorted(kw.items())}", mean_abs=dm, frac_colored_diff=dc)
+        # without a resize of the INPUT the two paths feed the engine the same bytes; with one, a uint8 pixel may differ by 1 LSB on <0.1 %
+        assert dm <= (1e-6 if kw["processing_res"] == 0 else 2e-3) and dc <= (1e-4 if kw["processing_res"] == 0 else 2e-2)
