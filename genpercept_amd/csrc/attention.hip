@@ -21,7 +21,10 @@ GP_DEV int attn_off128(int row, int slot) { return row * 128 + ((slot ^ ((row >>
 
 // NKB: 32-key blocks per KV tile (2: 64 keys, 4: 128 keys -- one online-softmax update, one barrier and one DMA wait per 128 keys,
 // longer independent MFMA runs)
-template <int NKB>
+// NST: depth of the K / V ring in LDS (16 KiB per stage at NKB = 2).  2 = one tile ahead, a full vmcnt(0) + barrier per tile; 3 = two tiles
+// ahead with COUNTED waits and one raw s_barrier per tile -- the DMA of tile t+2 is issued before tile t computes and is only waited for at
+// the top of tile t+2, so an L2 / MALL round trip no longer has to fit inside one tile's compute.
+template <int NKB, int NST>
 __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __restrict__ Q, const h16_t* __restrict__ K,
                                                             const h16_t* __restrict__ Vt, h16_t* __restrict__ O,
                                                             const h16_t* __restrict__ zero, int T, int heads, int ldq, int ldk, int Tpad,
@@ -31,8 +34,14 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // 1-D grid, XCD-aware: workgroup id b runs on XCD b % 8 (observed), so give each XCD a contiguous run of (image, head, query block):
+    // the ~96 workgroups resident on an XCD then share the K / V of one or two (image, head) pairs (2.4 MB each at T = 9216) in their
+    // 4 MiB L2 instead of all twenty pairs streaming through every L2 (speed only, never correctness)
+    const int nqb = (T + 127) >> 7;
+    const int sid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = sid % nqb, bh = sid / nqb;
+    const int h = bh % heads, b = bh / heads;
+    const int q0 = qb * 128 + wave * 32;
     const int l31 = lane & 31, hh = lane >> 5;
 
     const h16_t* Qb = Q + (long long)b * T * ldq + h * 64;
@@ -85,6 +94,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
     int cur = 0;
+    const unsigned smem_base = (unsigned)(unsigned long long)smem;  // integer-addressed LDS reads: see common.h (no compiler vmcnt(0) before them)
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(3))) u32x2_t* lds_u2_ptr;
 
     // One KV tile.  The softmax is the bound of this kernel (head_dim 64: 16 MFMAs of 32 cycles against ~32 scores per lane), so it is
     // kept to the minimum: raw v_exp_f32 (the libm exp2f wrapper added a compare, two selects and a v_ldexp per score), the 1/sqrt(d)
@@ -93,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
     // (Row sums through an extra all-ones MFMA block were tried: no gain, 16 more VGPRs.)
     auto tile = [&](int kt, auto maskc) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(maskc)::value != 0;
-        const char* sb = smem + cur * STAGE;
+        const unsigned sb = smem_base + cur * STAGE;
         // ---- S^T = K Q^T: two 32-key blocks, 4 k-steps of 16 over d
         f32x16_t s_acc[NKB];
 #pragma unroll
@@ -101,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
             const int row = kb * 32 + l31;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const h16x8_t kf = *(const h16x8_t*)(sb + attn_off128(row, ks * 2 + hh));
+                const h16x8_t kf = lds_frag(sb + attn_off128(row, ks * 2 + hh), 0);
                 s_acc[kb] = mfma_32x32x16(kf, qf[ks], ks == 0 ? zero16 : s_acc[kb]);  // C = 0: inline constant
             }
         }
@@ -151,25 +163,32 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
                     const int row = d * 32 + l31;
-                    const char* vr = sb + KBYTES + (kb >> 1) * 8192 + row * 128;
+                    const unsigned vr = sb + KBYTES + (kb >> 1) * 8192 + row * 128;
                     const int sw = (row >> 1) & 7;
-                    union { h16x8_t v; uint2 h2[2]; } vf;
-                    vf.h2[0] = *(const uint2*)(vr + ((((ko >> 3)) ^ sw) << 4) + (ko & 7) * 2);
-                    vf.h2[1] = *(const uint2*)(vr + ((((ko >> 3) + 1) ^ sw) << 4) + (ko & 7) * 2);
+                    union { h16x8_t v; u32x2_t h2[2]; } vf;
+                    vf.h2[0] = *(lds_u2_ptr)(vr + ((((ko >> 3)) ^ sw) << 4) + (ko & 7) * 2);
+                    vf.h2[1] = *(lds_u2_ptr)(vr + ((((ko >> 3) + 1) ^ sw) << 4) + (ko & 7) * 2);
                     o_acc[d] = mfma_32x32x16(vf.v, pf.v, o_acc[d]);
                 }
             }
     };
 
-    stage(0, 0);
-    wait_vm0();
-    __syncthreads();
+    constexpr int LPS = NKB + 2 * NH;  // LDS-DMA instructions per wave and stage
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)
+        if (s0 < nt) stage(s0, s0);
+    int nxt = NST - 1;
     for (int kt = 0; kt < nt; ++kt) {
-        if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
+        // my DMAs of tile kt have landed (NST - 2 younger stages may stay in flight) ...
+        const int ahead = min(NST - 2, nt - 1 - kt);
+        if (ahead >= 1) wait_vm<LPS>(); else wait_vm<0>();
+        static_assert(NST == 2 || NST == 3, "ring depth");
+        // ... and after the barrier everybody's have, and everybody is done reading the slot of tile kt - 1, which tile kt + NST - 1 refills
+        __builtin_amdgcn_s_barrier();
+        if (kt + NST - 1 < nt) stage(nxt, kt + NST - 1);
         if (kt * KEYS + KEYS > T) tile(kt, IC<1>{}); else tile(kt, IC<0>{});
-        if (kt + 1 < nt) wait_vm0();
-        __syncthreads();
-        cur ^= 1;
+        cur = cur + 1 == NST ? 0 : cur + 1;
+        nxt = nxt + 1 == NST ? 0 : nxt + 1;
     }
     // ---- normalise and store O[q][d] (this lane: q = l31, d = 32*blk + 8*(r>>2) + 4*hh + (r&3))
     l_run += __shfl_xor(l_run, 32);
@@ -189,10 +208,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
 
 void launch_flash_attn64(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t* out, const h16_t* zero, int B, int T, int heads,
                          int ldq, int ldk, int Tpad, int ldo, hipStream_t s) {
-    dim3 grid((T + 127) / 128, heads, B);
+    dim3 grid(((T + 127) / 128) * heads * B);
     // 64-key tiles: 156 VGPRs, three waves per SIMD.  (128-key tiles -- one softmax update, barrier and DMA wait per 128 keys -- need 256
     // VGPRs, two waves per SIMD, and measured 8 % slower: this kernel lives on latency hiding across waves.)
-    hipLaunchKernelGGL(flash_attn64_kernel<2>, grid, dim3(256), 32768, s, q, k, vt, out, zero, T, heads, ldq, ldk, Tpad, ldo);
+    static const bool ring2 = getenv("GENPERCEPT_FLASH_RING2") != nullptr;  // A/B switch: the two-stage ring
+    if (ring2) hipLaunchKernelGGL((flash_attn64_kernel<2, 2>), grid, dim3(256), 2 * 16384, s, q, k, vt, out, zero, T, heads, ldq, ldk, Tpad, ldo);
+    else hipLaunchKernelGGL((flash_attn64_kernel<2, 3>), grid, dim3(256), 3 * 16384, s, q, k, vt, out, zero, T, heads, ldq, ldk, Tpad, ldo);
 }
 
 // ---- cross-attention with a tiny constant context -------------------------------------------------------------------

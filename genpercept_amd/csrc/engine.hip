@@ -713,7 +713,8 @@ struct gp_engine {
         p.lda = wv.cin_pad; p.ldw = x.C; p.ldo = Tpad; p.n_store = Tpad;
         p.bias_mode = wv.bias ? GP_BIAS_ROW : GP_BIAS_NONE;
         p.batch = x.B; p.in_bs = 0; p.wt_bs = (long long)T * x.C; p.out_bs = (long long)C * Tpad; p.bias_bs = 0;
-        run_igemm(p);
+        // rows = channels: 320 / 640 of them leave the last 256-row tile of the large-problem configuration 25 / 50 % full -> 128-row tiles
+        run_igemm(p, (C % 256) ? 1 : 0);
         return vt;
     }
     // statistics -> per-(image, channel) scale / shift in the GN workspace; from the producer's tile partials when it left some

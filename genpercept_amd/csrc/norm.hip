@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const h16_t* __restrict__
 }
 bool groupnorm_small_applicable(int B, int HW, int C, int G) {
     const int cpg = C / G;
-    return (cpg & 7) == 0 && cpg * G == C && (long long)HW * (cpg >> 3) <= 8192 && B * G >= 64;
+    (void)B;  // must not depend on the batch size: an image's bits may not change with its batch mates (test_batch_equals_single)
+    return (cpg & 7) == 0 && cpg * G == C && (long long)HW * (cpg >> 3) <= 8192;
 }
 void launch_groupnorm_small(const h16_t* x, h16_t* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int silu,
                             hipStream_t s) {

@@ -344,7 +344,7 @@ def test_gemm_geglu(mc, metric_log):
 
 @pytest.mark.parametrize("case", [(2, 64, 64, True), (1, 128, 4096, True), (2, 320, 300, False), (1, 960, 144, True), (3, 2560, 36, True),
                                   (1, 512, 1, True), (1, 128, 70000, True),
-                                  # the one-launch small-map kernel (a group's block per workgroup; B * 32 >= 64 workgroups, (C / 32) % 8 == 0)
+                                  # the one-launch small-map kernel (a group's HW x C/32 block per workgroup, (C / 32) % 8 == 0)
                                   (4, 1280, 144, True), (4, 2560, 144, True), (2, 1280, 576, False), (4, 256, 37, True)])
 def test_groupnorm(case, metric_log):
     e = _eng()
