@@ -211,7 +211,9 @@ void launch_flash_attn64(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t*
     dim3 grid(((T + 127) / 128) * heads * B);
     // 64-key tiles: 156 VGPRs, three waves per SIMD.  (128-key tiles -- one softmax update, barrier and DMA wait per 128 keys -- need 256
     // VGPRs, two waves per SIMD, and measured 8 % slower: this kernel lives on latency hiding across waves.)
-    static const bool ring2 = getenv("GENPERCEPT_FLASH_RING2") != nullptr;  // A/B switch: the two-stage ring
+    // (in-box A/B at the four UNet levels: the three-stage ring is 2 % SLOWER -- 614 vs 629 us at T = 9216 -- so K / V latency is not what
+    //  this kernel waits for; it stays as a switch, GENPERCEPT_FLASH_RING3)
+    static const bool ring2 = getenv("GENPERCEPT_FLASH_RING3") == nullptr;
     if (ring2) hipLaunchKernelGGL((flash_attn64_kernel<2, 2>), grid, dim3(256), 2 * 16384, s, q, k, vt, out, zero, T, heads, ldq, ldk, Tpad, ldo);
     else hipLaunchKernelGGL((flash_attn64_kernel<2, 3>), grid, dim3(256), 3 * 16384, s, q, k, vt, out, zero, T, heads, ldq, ldk, Tpad, ldo);
 }

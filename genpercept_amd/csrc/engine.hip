@@ -180,7 +180,8 @@ struct gp_engine {
     h16_t* conv_in_w27 = nullptr;  // VAE encoder conv_in as a [Cout][32] (K = 27) matrix for rgb_conv_in_kernel
     bool fuse_gn = true;   // GENPERCEPT_NO_GN_FUSION=1 keeps the separate apply pass (A/B measurements)
     int gn_fuse_max_slices = 1;        // GENPERCEPT_GN_FUSE_MAX_SLICES: on large maps fuse the apply only into convs with at most this many 128-channel output slices
-    int gn_fuse_always_below_px = 16384;  // maps with fewer pixels per image always fuse
+    int gn_fuse_always_below_px = 0;   // GENPERCEPT_GN_FUSE_BELOW_PX: maps with fewer pixels per image fuse whatever the slice count (r1: 16384; r2 in-box
+                                       // A/B with the faster apply / one-launch small-map GroupNorm: 0 is 1.3 ms per pass faster)
     bool fuse_stats = true;  // GENPERCEPT_NO_STATS_FUSION=1 keeps the separate statistics pass
 
     std::unordered_map<std::string, PackedW> convs;
@@ -447,6 +448,7 @@ struct gp_engine {
         HIPCHK(hipSetDevice(cfg.device));
         fuse_gn = getenv("GENPERCEPT_NO_GN_FUSION") == nullptr;
         if (const char* ms = getenv("GENPERCEPT_GN_FUSE_MAX_SLICES")) gn_fuse_max_slices = atoi(ms);
+        if (const char* px = getenv("GENPERCEPT_GN_FUSE_BELOW_PX")) gn_fuse_always_below_px = atoi(px);
         fuse_stats = getenv("GENPERCEPT_NO_STATS_FUSION") == nullptr;
         {
             std::vector<h16_t> z(2048, 0);
@@ -776,9 +778,9 @@ struct gp_engine {
         IGemmParams p = conv_params(x, w, o, nullptr);
         p.in_scale = scale; p.in_shift = shift; p.in_silu = silu ? 1 : 0;
         // The fused transform is redone by every 128-channel slice of the output (each slice's workgroup stages its own halo) and it is
-        // VALU-issue bound inside the conv.  On the large VAE maps (> 96x96) one separate apply pass -- 2 x tensor bytes of HBM traffic --
-        // is cheaper than that redundant arithmetic as soon as there are two slices (measured: decoder -0.6 ms, encoder -0.4 ms); on the
-        // UNet's small maps the extra launch costs more than it saves (+0.9 ms when unfused), so those always fuse.
+        // bound by the two quarter-rate transcendentals per element inside the conv.  One separate apply pass -- 2 x tensor bytes of HBM
+        // traffic -- is cheaper than that redundant arithmetic as soon as there are two slices (measured r1: decoder -0.6 ms, encoder
+        // -0.4 ms on the large VAE maps; r2: also on the 96x96 .. 24x24 maps, another -1.3 ms per pass), so only single-slice convs fuse.
         const int slices = (w.cout + 127) / 128;
         const bool fuse_here = slices <= gn_fuse_max_slices || x.H * x.W < gn_fuse_always_below_px;
         if (fuse_gn && fuse_here && conv_uses_halo(p, 0)) return conv(x, w, o, scale, shift, silu);
