@@ -135,3 +135,32 @@ def evaluate_depth(pred: np.ndarray, gt: np.ndarray, valid_mask: np.ndarray, min
     a, g, m = (np.asarray(x, dtype=np.float64)[None] for x in (aligned.squeeze(), gt_a.squeeze(), vm.squeeze()))
     m = m.astype(bool)
     return {k: f(a, g, m) for k, f in METRICS.items()}
+
+
+# ---- surface normals ---------------------------------------------------------------------------------------------------------------------
+# The reference has no normal EVALUATION script; the only definition of "angular error" in its tree is angular_loss
+# (genpercept/losses/geometry_losses.py:550-590): cosine similarity along the channel axis, clamped to [-1 + eps, 1 - eps] (eps 1e-4),
+# acos, mean over the valid pixels.  The evaluator below is that quantity (radians -> degrees) plus the summary statistics normal
+# benchmarks report; pinned to the reference function by tests/golden/datasets_ref.npz.
+def normal_angular_error(pred: np.ndarray, gt: np.ndarray, valid_mask: Optional[np.ndarray] = None, eps: float = 1e-4) -> Dict[str, float]:
+    """pred, gt: [..., 3, H, W] normal maps (any scale: only directions matter); valid_mask: [..., 1 | absent, H, W] or None.
+    pred may be the pipeline's [0, 1] encoding: pass decode_normals(pred_np) first."""
+    p, g = np.asarray(pred, dtype=np.float64), np.asarray(gt, dtype=np.float64)
+    num = (p * g).sum(axis=-3)
+    den = np.maximum(np.linalg.norm(p, axis=-3), 1e-8) * np.maximum(np.linalg.norm(g, axis=-3), 1e-8)  # torch.cosine_similarity's eps
+    ang = np.arccos(np.clip(num / den, -1.0 + eps, 1.0 - eps))
+    if valid_mask is not None:
+        m = np.asarray(valid_mask).astype(bool)
+        if m.ndim == ang.ndim + 1:
+            m = m[..., 0, :, :]
+        ang = ang[m]
+    else:
+        ang = ang.reshape(-1)
+    deg = np.degrees(ang)
+    return {"mean_rad": float(ang.mean()), "mean_deg": float(deg.mean()), "median_deg": float(np.median(deg)), "rmse_deg": float(np.sqrt((deg ** 2).mean())),
+            "within_11.25": float((deg < 11.25).mean()), "within_22.5": float((deg < 22.5).mean()), "within_30": float((deg < 30.0).mean())}
+
+
+def decode_normals(pred_np: np.ndarray) -> np.ndarray:
+    """GenPerceptOutput.pred_np of mode='normal' is [H, W, 3] in [0, 1] = (n + 1) / 2 (genpercept_pipeline.py:469-472): back to [3, H, W] in [-1, 1]."""
+    return np.moveaxis(np.asarray(pred_np, dtype=np.float64) * 2.0 - 1.0, -1, -3)

@@ -49,14 +49,75 @@ def read_filename_list(path: str) -> List[List[str]]:
         return [ln.split() for ln in f.read().splitlines() if ln.strip()]
 
 
-# dataset conventions the evaluation needs (nyu_dataset.py:28-58): depth range, naming mode, decode scale, Eigen evaluation crop
+# Dataset conventions the evaluation needs (config/dataset/eval/*.yaml + src/dataset/{nyu,kitti,eth3d,scannet,diode}_dataset.py): depth
+# range, naming mode, how the ground truth is stored, evaluation crop / mask.  Pinned to the reference classes by tests/golden/datasets_ref.npz.
+#   gt: ("png", divisor) | ("eth3d_bin", (H, W)) | ("npy", None)
 DATASETS: Dict[str, dict] = {
-    "nyu": dict(min_depth=1e-3, max_depth=10.0, name_mode=FileNameMode.rgb_id, depth_scale=1.0 / 1000.0, eval_crop=(45, 471, 41, 601)),
+    "nyu": dict(min_depth=1e-3, max_depth=10.0, name_mode=FileNameMode.rgb_id, gt=("png", 1000.0), eval_crop=(45, 471, 41, 601)),
+    "kitti": dict(min_depth=1e-5, max_depth=80.0, name_mode=FileNameMode.id, gt=("png", 256.0), kitti_bm_crop=True, valid_mask_crop="eigen"),
+    "eth3d": dict(min_depth=1e-5, max_depth=float("inf"), name_mode=FileNameMode.id, gt=("eth3d_bin", (4032, 6048))),
+    "scannet": dict(min_depth=1e-3, max_depth=10.0, name_mode=FileNameMode.id, gt=("png", 1000.0)),
+    "diode": dict(min_depth=0.6, max_depth=350.0, name_mode=FileNameMode.id, gt=("npy", None), mask_from_file=True),
 }
+DATASETS["nyu_v2"] = DATASETS["nyu"]  # `name:` of config/dataset/eval/data_nyu_test.yaml
 
 
 def read_depth_png(path: str, depth_scale: float) -> np.ndarray:
     return np.asarray(Image.open(path)).astype(np.float32) * np.float32(depth_scale)
+
+
+def kitti_benchmark_crop(img: np.ndarray) -> np.ndarray:
+    """kitti_dataset.py:83-110: bottom-aligned, horizontally centred 352 x 1216 window of a [.., H, W] array (RGB and depth alike)."""
+    h, w = img.shape[-2:]
+    top, left = int(h - 352), int((w - 1216) / 2)
+    return img[..., top:top + 352, left:left + 1216]
+
+
+def kitti_eval_mask(h: int, w: int, kind: Optional[str]) -> np.ndarray:
+    """kitti_dataset.py:112-133: Garg (ECCV16) / Eigen (NIPS14) evaluation window as a boolean [h, w] mask (None: everything)."""
+    m = np.zeros((h, w), dtype=bool)
+    if kind is None:
+        m[:] = True
+    elif kind == "garg":
+        m[int(0.40810811 * h):int(0.99189189 * h), int(0.03594771 * w):int(0.96405229 * w)] = True
+    elif kind == "eigen":
+        m[int(0.3324324 * h):int(0.91351351 * h), int(0.0359477 * w):int(0.96405229 * w)] = True
+    else:
+        raise ValueError(f"Unknown crop type: {kind}")
+    return m
+
+
+def read_gt_depth(path: str, dataset: str) -> np.ndarray:
+    """Ground-truth depth [H, W] float32 in metres as the reference's dataset class decodes it (after the KITTI benchmark crop)."""
+    cfg = DATASETS[dataset]
+    kind, arg = cfg["gt"]
+    if kind == "png":          # kitti / 256 (kitti_dataset.py:60-68), scannet and nyu / 1000 (scannet_dataset.py:31-38, nyu_dataset.py:39-46)
+        d = np.asarray(Image.open(path)).astype(np.float32) / np.float32(arg)
+    elif kind == "eth3d_bin":  # eth3d_dataset.py:38-57: raw float32, inf = no measurement -> 0
+        d = np.fromfile(path, dtype=np.float32).copy()
+        d[d == np.inf] = 0.0
+        d = d.reshape(arg)
+    elif kind == "npy":        # diode_dataset.py:37-50
+        d = np.load(path).squeeze().astype(np.float32)
+    else:
+        raise ValueError(kind)
+    if cfg.get("kitti_bm_crop"):
+        d = kitti_benchmark_crop(d)
+    return d
+
+
+def dataset_valid_mask(depth: np.ndarray, dataset: str, mask_path: Optional[str] = None) -> np.ndarray:
+    """base_dataset.py:410-413 range test, then the dataset's evaluation crop (NYU Eigen crop, KITTI Garg / Eigen window) or, for DIODE,
+    the mask file that ships with the sample (diode_dataset.py:72-78)."""
+    cfg = DATASETS[dataset]
+    if cfg.get("mask_from_file"):
+        if mask_path is None:
+            raise ValueError("DIODE samples carry their validity mask as a third path")
+        return np.load(mask_path).squeeze().astype(bool)
+    m = valid_mask_of(depth, cfg["min_depth"], cfg["max_depth"], cfg.get("eval_crop"))
+    if "valid_mask_crop" in cfg:
+        m = m & kitti_eval_mask(depth.shape[-2], depth.shape[-1], cfg["valid_mask_crop"])
+    return m
 
 
 def valid_mask_of(depth: np.ndarray, min_depth: float, max_depth: float, eval_crop: Optional[Tuple[int, int, int, int]] = None) -> np.ndarray:
@@ -71,12 +132,15 @@ def valid_mask_of(depth: np.ndarray, min_depth: float, max_depth: float, eval_cr
 
 def run_inference(pipe, base_dir: str, samples: Sequence[Sequence[str]], output_dir: str, name_mode: FileNameMode, mode: str = "depth",
                   denoise_steps: int = 1, ensemble_size: int = 1, processing_res: int = 0, match_input_res: bool = True,
-                  resample_method: str = "bilinear", fix_timesteps=None, prompt: str = "") -> List[str]:
-    """infer.py:408-447.  Returns the paths written."""
+                  resample_method: str = "bilinear", fix_timesteps=None, prompt: str = "", rgb_crop: Optional[Callable[[np.ndarray], np.ndarray]] = None) -> List[str]:
+    """infer.py:408-447.  Returns the paths written.  rgb_crop: e.g. kitti_benchmark_crop (applied to the [3, H, W] image)."""
     written = []
+    samples = [s for s in samples if len(s) < 2 or s[1] != "None"]  # kitti_dataset.py:47: entries without ground truth are skipped
     for s in samples:
         rgb_rel = s[0]
         img = Image.open(os.path.join(base_dir, rgb_rel)).convert("RGB")
+        if rgb_crop is not None:  # KITTI: the benchmark crop is applied to the RGB as well (kitti_dataset.py:70-74)
+            img = Image.fromarray(np.ascontiguousarray(np.moveaxis(rgb_crop(np.moveaxis(np.asarray(img), -1, 0)), 0, -1)))
         out = pipe(img, denoising_steps=denoise_steps, ensemble_size=ensemble_size, processing_res=processing_res, match_input_res=match_input_res,
                    batch_size=0, color_map=None, show_progress_bar=False, resample_method=resample_method, mode=mode,
                    fix_timesteps=fix_timesteps, prompt=prompt)
@@ -99,8 +163,10 @@ def evaluate_predictions(prediction_dir: str, base_dir: str, samples: Sequence[S
     n = 0
     for s in samples:
         rgb_rel, depth_rel = s[0], s[1]
-        gt = read_gt(os.path.join(base_dir, depth_rel)) if read_gt else read_depth_png(os.path.join(base_dir, depth_rel), cfg["depth_scale"])
-        vm = valid_mask_of(gt, cfg["min_depth"], cfg["max_depth"], cfg.get("eval_crop"))
+        if depth_rel == "None":
+            continue
+        gt = read_gt(os.path.join(base_dir, depth_rel)) if read_gt else read_gt_depth(os.path.join(base_dir, depth_rel), dataset)
+        vm = dataset_valid_mask(gt, dataset, os.path.join(base_dir, s[2]) if cfg.get("mask_from_file") and len(s) > 2 else None)
         pred_name = os.path.join(os.path.dirname(rgb_rel), get_pred_name(os.path.basename(rgb_rel), cfg["name_mode"], suffix=pred_suffix))
         pred_path = os.path.join(prediction_dir, pred_name)
         if not os.path.exists(pred_path):

@@ -11,6 +11,7 @@ Fixtures are data (seeds, inputs, expected outputs) — never reference source.
   metrics_ref.npz    outputs of the REFERENCE's src/util/metric.py + src/util/alignment.py on seeded arrays.
   batchsize_ref.npz  the REFERENCE's find_batch_size (genpercept/util/batchsize.py) on a grid of cards / resolutions / ensembles.
   infer_eval_ref.npz the REFERENCE's get_pred_name (all naming modes) and alignment variants (max_resolution, disparity-space protocol).
+  datasets_ref.npz   the REFERENCE's dataset conventions beyond NYU (KITTI crop / masks / decode, ETH3D, ScanNet, DIODE) and angular_loss.
   image_util_ref.npz the REFERENCE's colorize_depth_maps / chw2hwc outputs, resize_max_res size rule, resample-method names.
   e2e_tiny.npz       end-to-end goldens of the fp32 oracle (oracle/) on the tiny configs: inputs + expected outputs
                      for every stage (latent, unet out, feats, decode, final) — what the HIP path is checked against
@@ -211,6 +212,90 @@ def make_infer_eval_golden():
     print("infer/eval golden:", len(names), "names")
 
 
+def make_datasets_golden():
+    """Evaluation-side conventions of the REFERENCE's dataset classes beyond NYU (src/dataset/{kitti,eth3d,scannet,diode,nyu}_dataset.py;
+    cv2 / torchvision stubbed, the code under test uses neither): depth ranges and naming modes, KITTI benchmark crop and Garg / Eigen
+    evaluation masks, depth decoding (KITTI / 256, ScanNet and NYU / 1000, ETH3D raw float32 with inf -> 0, DIODE .npy + mask), and the
+    angular error of genpercept/losses/geometry_losses.py:angular_loss, from which the normal evaluator is defined."""
+    import importlib.util
+    import tempfile
+    for name in ("cv2", "torchvision", "torchvision.transforms"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision.transforms"].InterpolationMode = types.SimpleNamespace(NEAREST=0, BILINEAR=1, BICUBIC=2, NEAREST_EXACT=3)
+    sys.modules["torchvision.transforms"].Resize = object
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.path.insert(0, REF)
+    from src.dataset import base_dataset as bd
+    from src.dataset.diode_dataset import DIODEDataset
+    from src.dataset.eth3d_dataset import ETH3DDataset
+    from src.dataset.kitti_dataset import KITTIDataset
+    from src.dataset.nyu_dataset import NYUDataset
+    from src.dataset.scannet_dataset import ScanNetDataset
+    real_init = bd.BaseDataset.__init__
+    bd.BaseDataset.__init__ = lambda self, **kw: self.__dict__.update(kw)  # keep only what the subclass passes up (ranges, naming mode)
+    out = {}
+    try:
+        files = [["a.png", "a_d.png"], ["b.png", "None"], ["c.png", "c_d.png"]]
+        insts = {"kitti": KITTIDataset(kitti_bm_crop=True, valid_mask_crop="eigen", filenames=[list(f) for f in files]),
+                 "eth3d": ETH3DDataset(), "scannet": ScanNetDataset(), "diode": DIODEDataset(), "nyu": NYUDataset(eigen_valid_mask=True)}
+        for k, d in insts.items():
+            out[f"{k}_range"] = np.array([float(d.min_depth), float(d.max_depth)], dtype=np.float64)
+            out[f"{k}_name_mode"] = np.array(d.name_mode.name)
+        out["kitti_filtered"] = np.array([f[0] for f in insts["kitti"].filenames])
+        # KITTI benchmark crop + evaluation masks on raw KITTI sizes
+        sizes = [(375, 1242), (370, 1226), (376, 1241), (374, 1238), (352, 1216)]
+        boxes, masks = [], {}
+        for h, w in sizes:
+            idx = torch.arange(h * w).reshape(h, w)
+            c = KITTIDataset.kitti_benchmark_crop(idx)
+            boxes.append([h, w, int(c[0, 0]) // w, int(c[0, 0]) % w, c.shape[0], c.shape[1]])
+            depth = torch.full((1, c.shape[0], c.shape[1]), 5.0)
+            depth[0, ::7, ::5] = 0.0      # invalid: below min_depth
+            depth[0, 1::11, 2::9] = 90.0  # invalid: beyond max_depth
+            for crop in ("eigen", "garg", None):
+                k = insts["kitti"]
+                k.valid_mask_crop = crop
+                masks[f"kitti_mask_{crop}_{h}x{w}"] = np.packbits(k._get_valid_mask(depth).numpy().astype(np.uint8))
+        out["kitti_crop_boxes"] = np.array(boxes)  # h, w, top, left, crop_h, crop_w
+        out.update(masks)
+        # decoders
+        raw = (np.arange(6 * 8, dtype=np.float32).reshape(6, 8) * 37.0 + 5.0)
+        for k in ("kitti", "scannet", "nyu"):
+            d = insts[k]
+            d.is_exr_data = False
+            d._read_image = lambda rel, raw=raw: raw.copy()
+            out[f"{k}_decoded"] = np.asarray(d._read_depth_file("x.png"), dtype=np.float64)
+        out["raw_png_values"] = raw
+        with tempfile.TemporaryDirectory() as td:
+            e = insts["eth3d"]
+            e.is_tar, e.tar_obj, e.dataset_dir, e.HEIGHT, e.WIDTH = False, None, td, 6, 8
+            buf = raw.copy()
+            buf[2, 3] = np.inf
+            buf.tofile(os.path.join(td, "d.bin"))
+            out["eth3d_decoded"] = e._read_depth_file("d.bin")
+            di = insts["diode"]
+            di.is_tar, di.tar_obj, di.dataset_dir = False, None, td
+            np.save(os.path.join(td, "d.npy"), raw[:, :, None])
+            out["diode_decoded"] = di._read_depth_file("d.npy")
+    finally:
+        bd.BaseDataset.__init__ = real_init
+    # angular error (radians) of the reference's angular_loss on seeded normals
+    spec = importlib.util.spec_from_file_location("ref_geometry_losses", os.path.join(REF, "genpercept/losses/geometry_losses.py"))
+    gl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gl)
+    g = torch.Generator().manual_seed(21)
+    gt = torch.nn.functional.normalize(torch.randn(2, 3, 24, 32, generator=g), dim=1)
+    pred = torch.nn.functional.normalize(gt + 0.3 * torch.randn(2, 3, 24, 32, generator=g), dim=1)
+    pred[0, :, 0, :4] = gt[0, :, 0, :4]          # exact agreement: exercises the clamp at 1 - eps
+    pred[1, :, 1, :4] = -gt[1, :, 1, :4]         # opposite normals: clamp at -1 + eps
+    mask = (torch.rand(2, 1, 24, 32, generator=g) > 0.25)
+    out.update(normal_gt=gt.numpy(), normal_pred=pred.numpy(), normal_mask=mask.numpy(),
+               angular_loss_mean_rad=np.array(float(gl.angular_loss(pred, gt, mask.float()))))
+    np.savez_compressed(os.path.join(HERE, "datasets_ref.npz"), **out)
+    print("datasets_ref.npz", len(out), "entries,", os.path.getsize(os.path.join(HERE, "datasets_ref.npz")) // 1024, "KiB")
+
+
 def make_image_util_golden():
     """The REFERENCE's genpercept/util/image_util.py: colorize_depth_maps (matplotlib Spectral), chw2hwc, the output-size rule of
     resize_max_res (int() truncation; torchvision's `resize` is replaced by a stub that records the requested size -- the resampling
@@ -303,7 +388,7 @@ def make_e2e_tiny():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dpt", "metrics", "e2e", "batchsize", "infer_eval", "image_util"]
+    which = sys.argv[1:] or ["dpt", "metrics", "e2e", "batchsize", "infer_eval", "image_util", "datasets"]
     if "dpt" in which:
         make_dpt_golden()
     if "dpt" in which or "dpt_odd" in which:
@@ -318,3 +403,5 @@ if __name__ == "__main__":
         make_infer_eval_golden()
     if "image_util" in which:
         make_image_util_golden()
+    if "datasets" in which:
+        make_datasets_golden()

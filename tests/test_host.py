@@ -408,3 +408,65 @@ def test_encode_text_hf_clip_branch(tmp_path):
     first = pipe.text_embed
     pipe.encode_text("a b")  # a non-empty prompt (infer.py --prompt): more tokens, new embedding
     assert pipe.text_embed.shape[1] == 4 and pipe.text_embed is not first
+
+
+def test_dataset_conventions_match_reference_classes(tmp_path):
+    """tests/golden/datasets_ref.npz: KITTI / ETH3D / ScanNet / DIODE / NYU conventions read off the reference's dataset classes
+    (depth ranges, naming mode, KITTI benchmark crop + Garg / Eigen masks, ground-truth decoding)."""
+    from PIL import Image
+    from genpercept_amd import infer_eval as ie
+    g = np.load(os.path.join(ROOT, "tests", "golden", "datasets_ref.npz"))
+    for name in ("kitti", "eth3d", "scannet", "diode", "nyu"):
+        cfg = ie.DATASETS[name]
+        assert [cfg["min_depth"], cfg["max_depth"]] == list(g[f"{name}_range"]), name
+        assert cfg["name_mode"].name == str(g[f"{name}_name_mode"]), name
+    for h, w, top, left, ch, cw in g["kitti_crop_boxes"]:
+        idx = np.arange(h * w).reshape(h, w)
+        c = ie.kitti_benchmark_crop(idx)
+        assert c.shape == (ch, cw) and c[0, 0] == top * w + left
+        depth = np.full((ch, cw), 5.0, dtype=np.float32)
+        depth[::7, ::5] = 0.0
+        depth[1::11, 2::9] = 90.0
+        for crop in ("eigen", "garg", None):
+            want = np.unpackbits(g[f"kitti_mask_{crop}_{h}x{w}"])[: ch * cw].reshape(ch, cw).astype(bool)
+            got = ie.valid_mask_of(depth, 1e-5, 80.0) & ie.kitti_eval_mask(ch, cw, crop)
+            assert np.array_equal(got, want), (h, w, crop)
+    raw = g["raw_png_values"]
+    Image.fromarray(raw.astype(np.uint16)).save(tmp_path / "d.png")
+    for name in ("scannet", "nyu"):
+        assert np.array_equal(ie.read_gt_depth(str(tmp_path / "d.png"), name), g[f"{name}_decoded"].astype(np.float32))
+    big = np.zeros((375, 1242), dtype=np.uint16)
+    big[23:, 13:1229] = 7
+    big[40, 100] = 12345
+    Image.fromarray(big).save(tmp_path / "k.png")
+    kd = ie.read_gt_depth(str(tmp_path / "k.png"), "kitti")
+    assert kd.shape == (352, 1216) and kd[40 - 23, 100 - 13] == np.float32(12345 / 256.0) and np.all(kd[:, 0] == np.float32(7 / 256.0))
+    assert np.array_equal((raw / 256.0).astype(np.float32), g["kitti_decoded"].astype(np.float32))  # the decode rule itself
+    buf = raw.copy()
+    buf[2, 3] = np.inf
+    buf.tofile(tmp_path / "e.bin")
+    ie.DATASETS["_eth3d_small"] = dict(ie.DATASETS["eth3d"], gt=("eth3d_bin", (6, 8)))
+    try:
+        assert np.array_equal(ie.read_gt_depth(str(tmp_path / "e.bin"), "_eth3d_small"), g["eth3d_decoded"])
+    finally:
+        del ie.DATASETS["_eth3d_small"]
+    np.save(tmp_path / "d.npy", raw[:, :, None])
+    assert np.array_equal(ie.read_gt_depth(str(tmp_path / "d.npy"), "diode"), g["diode_decoded"][0])
+    m = (raw > 500)
+    np.save(tmp_path / "m.npy", m[:, :, None].astype(np.uint8))
+    assert np.array_equal(ie.dataset_valid_mask(raw, "diode", str(tmp_path / "m.npy")), m)
+    with pytest.raises(ValueError):
+        ie.dataset_valid_mask(raw, "diode")
+
+
+def test_normal_angular_error_matches_reference_angular_loss():
+    """The normal evaluator is DEFINED by the reference's angular_loss (geometry_losses.py:550-590); its mean (radians) must equal it."""
+    from genpercept_amd import eval_metrics as em
+    g = np.load(os.path.join(ROOT, "tests", "golden", "datasets_ref.npz"))
+    r = em.normal_angular_error(g["normal_pred"], g["normal_gt"], g["normal_mask"])
+    assert abs(r["mean_rad"] - float(g["angular_loss_mean_rad"])) <= 2e-6
+    assert abs(r["mean_deg"] - np.degrees(r["mean_rad"])) < 1e-9 and 0.0 <= r["within_11.25"] <= r["within_22.5"] <= r["within_30"] <= 1.0
+    same = em.normal_angular_error(g["normal_gt"], g["normal_gt"])
+    assert same["mean_deg"] < 1.0  # the clamp at 1 - 1e-4 leaves acos(0.9999) = 0.81 degrees, like the reference
+    enc = np.moveaxis((g["normal_gt"][0] + 1.0) / 2.0, 0, -1)  # what the pipeline returns for mode='normal'
+    assert np.allclose(em.decode_normals(enc), g["normal_gt"][0], atol=1e-6)
