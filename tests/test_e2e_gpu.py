@@ -624,3 +624,17 @@ def test_infer_eval_loop_with_the_engine(precision, tiny_weights, tmp_path, metr
         errs.append(em.normal_angular_error(em.decode_normals(out.pred_np), normals_ref[i] * 2.0 - 1.0)["mean_deg"])
     metric_log(f"infer_eval_loop_normal[{precision}]", mean_angular_error_deg=float(np.mean(errs)))
     assert float(np.mean(errs)) <= (10.0 if precision == "bf16" else 1.7)  # fp16 measured 0.82 degrees (the clamp alone leaves 0.81)
+
+
+def test_dpt_head_more_than_64_images(eng_dpt, golden):
+    """The per-image min-max workspace is sized from the batch (a fixed 64-image buffer was overrun by B > 64, reachable through
+    infer_batch at small resolutions).  70 images: every map normalised on its own, and image 69 equals the same image run alone."""
+    d = torch.device("cuda", 0)
+    eng_dpt.set_context(torch.as_tensor(golden["sq_ctx"]))
+    g = torch.Generator().manual_seed(70)
+    rgb = torch.randint(0, 256, (70, 3, 32, 32), generator=g, dtype=torch.uint8).to(d)
+    out = eng_dpt.infer(rgb, "disparity")
+    assert out.shape[0] == 70 and torch.isfinite(out).all()
+    mn, mx = out.amin(dim=(1, 2, 3)), out.amax(dim=(1, 2, 3))
+    assert float(mn.abs().max()) < 1e-6 and float((mx - 1).abs().max()) < 1e-6
+    assert torch.equal(eng_dpt.infer(rgb[69:70], "disparity"), out[69:70])
