@@ -209,10 +209,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
 void launch_flash_attn64(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t* out, const h16_t* zero, int B, int T, int heads,
                          int ldq, int ldk, int Tpad, int ldo, hipStream_t s) {
     dim3 grid(((T + 127) / 128) * heads * B);
-    // 64-key tiles: 156 VGPRs, three waves per SIMD.  (128-key tiles -- one softmax update, barrier and DMA wait per 128 keys -- need 256
-    // VGPRs, two waves per SIMD, and measured 8 % slower: this kernel lives on latency hiding across waves.)
-    // (in-box A/B at the four UNet levels: the three-stage ring is 2 % SLOWER -- 614 vs 629 us at T = 9216 -- so K / V latency is not what
-    //  this kernel waits for; it stays as a switch, GENPERCEPT_FLASH_RING3)
+    // 64-key tiles: 194 VGPRs as hipcc 7.2 allocates them, i.e. two waves per SIMD (forcing three, __launch_bounds__(256, 3), spills 38 registers).
+    // Measured alternatives, all slower at T = 9216 (610 us, kernel only): 128-key tiles -8 % (r1); a three-stage K / V ring with counted waits
+    // -2 % (stays as a switch, GENPERCEPT_FLASH_RING3: K / V latency is not what the kernel waits for); two 32-query blocks per wave so that each
+    // K / V^T fragment read feeds two MFMAs: 1100 us with 256 VGPRs + 42 spilled, 1050 us at one wave per SIMD; one online-softmax update per
+    // 32 keys instead of 64 (165 VGPRs): 644 us.  r2 ablations of the shipped shape: no softmax arithmetic 494 us, no P.V MFMAs 587 us, neither
+    // 442 us, additionally no K.Q^T MFMAs 249 us (the LDS fragment reads, DMA and loop alone), no waits / barriers 601 us.
     static const bool ring2 = getenv("GENPERCEPT_FLASH_RING3") == nullptr;
     if (ring2) hipLaunchKernelGGL((flash_attn64_kernel<2, 2>), grid, dim3(256), 2 * 16384, s, q, k, vt, out, zero, T, heads, ldq, ldk, Tpad, ldo);
     else hipLaunchKernelGGL((flash_attn64_kernel<2, 3>), grid, dim3(256), 3 * 16384, s, q, k, vt, out, zero, T, heads, ldq, ldk, Tpad, ldo);

@@ -623,12 +623,12 @@ def test_infer_eval_loop_with_the_engine(precision, tiny_weights, tmp_path, metr
         out = pipe(Image.open(base / s[0]), processing_res=0, mode="normal", color_map=None)
         errs.append(em.normal_angular_error(em.decode_normals(out.pred_np), normals_ref[i] * 2.0 - 1.0)["mean_deg"])
     metric_log(f"infer_eval_loop_normal[{precision}]", mean_angular_error_deg=float(np.mean(errs)))
-    assert float(np.mean(errs)) <= (10.0 if precision == "bf16" else 1.7)  # fp16 measured 0.82 degrees (the clamp alone leaves 0.81)
+    assert float(np.mean(errs)) <= (4.0 if precision == "bf16" else 1.7)  # measured 2.01 / 0.82 degrees (the evaluator's clamp alone leaves 0.81)
 
 
 def test_dpt_head_more_than_64_images(eng_dpt, golden):
     """The per-image min-max workspace is sized from the batch (a fixed 64-image buffer was overrun by B > 64, reachable through
-    infer_batch at small resolutions).  70 images: every map normalised on its own, and image 69 equals the same image run alone."""
+    infer_batch at small resolutions).  70 images: every map normalised on its own, and image 69 agrees with the same image run alone."""
     d = torch.device("cuda", 0)
     eng_dpt.set_context(torch.as_tensor(golden["sq_ctx"]))
     g = torch.Generator().manual_seed(70)
@@ -637,4 +637,6 @@ def test_dpt_head_more_than_64_images(eng_dpt, golden):
     assert out.shape[0] == 70 and torch.isfinite(out).all()
     mn, mx = out.amin(dim=(1, 2, 3)), out.amax(dim=(1, 2, 3))
     assert float(mn.abs().max()) < 1e-6 and float((mx - 1).abs().max()) < 1e-6
-    assert torch.equal(eng_dpt.infer(rgb[69:70], "disparity"), out[69:70])
+    # (70 images vs 1: the launchers pick other tiles / split-K factors for the other M, so the accumulation order -- not the math -- differs)
+    alone = eng_dpt.infer(rgb[69:70], "disparity")
+    assert float((alone - out[69:70]).abs().mean()) <= 2 * TOLS[eng_dpt.precision]["map_mean"]

@@ -1,9 +1,10 @@
 """Device-side pre / post processing (gp_preprocess / gp_postprocess, csrc/prepost.hip) against the host path
 (genpercept_amd/image_util.py = the reference's torchvision / matplotlib recipe, pinned to the reference's outputs in test_host.py).
 
-Tolerances: uint8 resize -- the kernel repeats ATen's separable anti-aliased filter in fp32, accumulation order included, but fused
-multiply-adds differ between the two machines, so a value that lands within ~1e-6 of x.5 may round the other way: at most 1 LSB on at most
-0.1 % of the pixels; fp32 resize: 2e-6 absolute on [0,1] maps; colour LUT and quantisation: bit-exact given the same fp32 input."""
+Measured on MI355X + EPYC 9575F host: the device resize is BIT-EXACT with ATen's CPU kernel on every shape below, uint8 and fp32 (the kernel
+repeats the separable anti-aliased filter in fp32, weight computation and accumulation order included).  The gates leave room only for a host
+whose ATen build contracts multiply-adds differently: uint8 at most 1 LSB on at most 0.01 % of the pixels, fp32 5e-7 absolute on [0,1] maps;
+colour LUT and quantisation: bit-exact given the same fp32 input."""
 import numpy as np
 import pytest
 import torch
@@ -27,7 +28,7 @@ def test_preprocess_resize_max_res_u8(hw, mode, metric_log):
     d = (out.int() - ref.int()).abs()
     frac = float((d > 0).float().mean())
     metric_log(f"preprocess_u8{hw}{mode}", max_lsb=int(d.max()), frac_diff=frac)
-    assert int(d.max()) <= (1 if mode == "bilinear" else 0) and frac <= 1e-3
+    assert int(d.max()) <= (1 if mode == "bilinear" else 0) and frac <= 1e-4
 
 
 @pytest.mark.parametrize("case", [(1, 576, 768, 3024, 4032), (3, 768, 768, 500, 500), (1, 384, 512, 384, 512), (1, 768, 576, 60, 45), (2, 96, 128, 97, 131)])
@@ -45,7 +46,7 @@ def test_postprocess_resize_clip_colorize_quantize(case, mode, metric_log):
     err = float(np.abs(out_np - ref).max())
     metric_log(f"postprocess{case}{mode}", max_abs=err)
     assert out_np.shape == ref.shape and out_np.min() >= 0.0 and out_np.max() <= 1.0
-    assert err <= (2e-6 if mode == "bilinear" else 0.0)
+    assert err <= (5e-7 if mode == "bilinear" else 0.0)
     # quantisation and colour map are exact functions of the fp32 map the device produced
     assert np.array_equal(q.cpu().numpy(), (out_np * 65535.0).astype(np.uint16))
     if c == 1:
