@@ -106,6 +106,49 @@ void launch_nchw_f32_to_nhwc(const float* in, h16_t* out, int B, int C, int H, i
                        (long long)H * W, Cpad);
 }
 
+// ---- multi-step archs (marigold / rgb_blending; genpercept_pipeline.py:413-422,447-465) ---------------------------------------------
+// The denoising state lives in fp32, pixel-major [B*h*w][L]; the UNet reads its 16-bit copy from channels [off, off+L) of the latent
+// tensor the encoder wrote (marigold: [rgb_latent, pred_latent] in channels 0..2L-1, "this order is important" :452; rgb_blending:
+// the state replaces the rgb latent in channels 0..L-1).
+__global__ __launch_bounds__(256) void ddim_init_kernel(const float* __restrict__ noise, h16_t* __restrict__ lat, float* __restrict__ sample,
+                                                         int B, long long HW, int L, int ld, int off) {
+    const long long n = (long long)B * HW * L;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % L);
+        const long long bp = i / L, b = bp / HW, p = bp - b * HW;
+        const float s = noise ? noise[(b * L + c) * HW + p] : h16_to_f(lat[bp * ld + c]);
+        sample[i] = s;
+        if (noise) lat[bp * ld + off + c] = f_to_h16(s);
+    }
+}
+void launch_ddim_init(const float* noise_nchw, h16_t* lat, float* sample, int B, int H, int W, int L, int ld, int off, hipStream_t s) {
+    hipLaunchKernelGGL(ddim_init_kernel, dim3(grid_for((long long)B * H * W * L)), dim3(256), 0, s, noise_nchw, lat, sample, B,
+                       (long long)H * W, L, ld, off);
+}
+// One scheduler step in its affine form (genpercept_amd/scheduler.py: step_coefficients):
+//   x0 = clip(x0_sample * s + x0_model * m), eps = eps_sample * s + eps_model * m, s' = prev_x0 * x0 + prev_eps * eps.
+__global__ __launch_bounds__(256) void ddim_step_kernel(const h16_t* __restrict__ model, int ldm, float* __restrict__ sample,
+                                                         h16_t* __restrict__ uin, int ldu, int off, h16_t* __restrict__ x0_out, int ldx,
+                                                         long long pixels, int L, DdimCoef k) {
+    const long long n = pixels * L;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % L);
+        const long long px = i / L;
+        const float m = h16_to_f(model[px * ldm + c]), s = sample[i];
+        float x0 = k.x0_sample * s + k.x0_model * m;
+        if (k.clip > 0.f) x0 = fminf(fmaxf(x0, -k.clip), k.clip);
+        const float eps = k.eps_sample * s + k.eps_model * m;
+        const float prev = k.prev_x0 * x0 + k.prev_eps * eps;
+        sample[i] = prev;
+        uin[px * ldu + off + c] = f_to_h16(prev);
+        if (x0_out) x0_out[px * ldx + c] = f_to_h16(x0);
+    }
+}
+void launch_ddim_step(const h16_t* model, int ldm, float* sample, h16_t* uin, int ldu, int off, h16_t* x0_out, int ldx, long long pixels, int L,
+                      const DdimCoef& k, hipStream_t s) {
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(pixels * L)), dim3(256), 0, s, model, ldm, sample, uin, ldu, off, x0_out, ldx, pixels, L, k);
+}
+
 // bf16 NHWC (row stride ld) -> fp32 NCHW
 __global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const h16_t* __restrict__ in, float* __restrict__ out, int B, int C,
                                                                 long long HW, int ld) {

@@ -144,6 +144,7 @@ struct ResW {
     // time-embedding fold (UNet only)
     bool has_temb = false;
     std::vector<float> c1_bias_h, tw_h, tb_h;  // conv1.bias, time_emb_proj.{weight,bias}
+    size_t temb_off = 0;                       // where c1.bias lives in the engine's time-embedding bias arena (floats)
 };
 struct TfW {
     NormW gn, ln1, ln2, ln3;
@@ -193,6 +194,9 @@ struct gp_engine {
     std::vector<float> ctx;                          // [L][D]
     int ctx_L = 0, ctx_D = 0;
     float timestep = 1.f;
+    float* temb_arena = nullptr;          // conv1 biases of all UNet resnets at the current timestep
+    size_t temb_total = 0;
+    std::map<float, float*> temb_cache;   // timestep -> device copy of the arena's contents
     std::vector<float> pq_w, pq_b;  // post_quant_conv
     float* pq_w_dev = nullptr;
     float* pq_b_dev = nullptr;
@@ -358,14 +362,18 @@ struct gp_engine {
         vattn[p] = std::move(a);
     }
 
-    void fold_timestep() {
-        if (te_w1.empty()) return;
+    // conv1 bias + time_emb_proj(SiLU(time_embedding(t))) of every UNet resnet at timestep t, concatenated in arena order; computed on
+    // the host in double once per distinct t and kept on the device, so a change of timestep is one stream-ordered D2D copy
+    // (the multi-step archs walk 10-50 timesteps per image; genpercept_pipeline.py:447-463).
+    const float* timestep_biases(float t) {
+        auto it = temb_cache.find(t);
+        if (it != temb_cache.end()) return it->second;
         const int c0 = cfg.unet_block_out[0], te = c0 * 4, half = c0 / 2;
         std::vector<double> temb(c0), e1(te), emb(te);
         for (int i = 0; i < half; ++i) {
             const double f = std::exp(-std::log(10000.0) * i / half);
-            temb[i] = std::cos((double)timestep * f);
-            temb[half + i] = std::sin((double)timestep * f);
+            temb[i] = std::cos((double)t * f);
+            temb[half + i] = std::sin((double)t * f);
         }
         for (int o = 0; o < te; ++o) {
             double a = te_b1[o];
@@ -377,18 +385,42 @@ struct gp_engine {
             for (int i = 0; i < te; ++i) a += (double)te_w2[(size_t)o * te + i] * e1[i];
             emb[o] = a / (1.0 + std::exp(-a));  // SiLU(emb), the input of every time_emb_proj
         }
+        std::vector<float> all(temb_total);
         for (auto& kv : resnets) {
-            ResW& r = kv.second;
+            const ResW& r = kv.second;
             if (!r.has_temb) continue;
             const int co = r.c1.cout;
-            std::vector<float> b(co);
             for (int o = 0; o < co; ++o) {
                 double a = (double)r.c1_bias_h[o] + r.tb_h[o];
-                for (int i = 0; i < te; ++i) a += (double)r.tw_h[(size_t)o * te + i] * emb[i];
-                b[o] = (float)a;
+                const float* wrow = &r.tw_h[(size_t)o * te];
+                for (int i = 0; i < te; ++i) a += (double)wrow[i] * emb[i];
+                all[r.temb_off + o] = (float)a;
             }
-            HIPCHK(hipMemcpy(r.c1.bias, b.data(), co * 4, hipMemcpyHostToDevice));
         }
+        float* d = nullptr;
+        HIPCHK(hipMalloc((void**)&d, temb_total * sizeof(float)));
+        weights_dev.push_back(d);
+        HIPCHK(hipMemcpy(d, all.data(), temb_total * sizeof(float), hipMemcpyHostToDevice));
+        temb_cache[t] = d;
+        return d;
+    }
+    void fold_timestep() {  // synchronous form (gp_finalize / gp_set_timestep)
+        if (te_w1.empty()) return;
+        if (!temb_arena) {  // every temb resnet's conv1 bias re-pointed into one arena
+            temb_total = 0;
+            for (auto& kv : resnets)
+                if (kv.second.has_temb) { kv.second.temb_off = temb_total; temb_total += (size_t)((kv.second.c1.cout + 63) / 64) * 64; }
+            HIPCHK(hipMalloc((void**)&temb_arena, temb_total * sizeof(float)));
+            weights_dev.push_back(temb_arena);
+            for (auto& kv : resnets)
+                if (kv.second.has_temb) kv.second.c1.bias = temb_arena + kv.second.temb_off;
+        }
+        HIPCHK(hipMemcpy(temb_arena, timestep_biases(timestep), temb_total * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    void set_timestep_on_stream(float t) {  // inside a pass: ordered after the launches that still read the previous biases
+        const float* src = timestep_biases(t);
+        timestep = t;
+        HIPCHK(hipMemcpyAsync(temb_arena, src, temb_total * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     void fold_context() {
         if (ctx.empty()) return;
@@ -1007,6 +1039,7 @@ struct gp_engine {
         m = resnet(m2, "unet.mid_block.resnets.1", cfg.unet_norm_eps);
         drop(m2);
         Act h = m;
+        bool h_is_feat = false;  // h is one of the caller's feature maps (multi_level_feats): the caller drops it, not this function
         for (int i = 0; i < 4; ++i) {
             const std::string bp = "unet.up_blocks." + std::to_string(i);
             const bool attn = cfg.unet_down_attn[3 - i];
@@ -1025,7 +1058,9 @@ struct gp_engine {
                 } else {
                     launch_concat(h.p, h.C, skip.p, skip.C, cat.p, h.pixels(), st);
                 }
-                drop(h);
+                if (!h_is_feat) drop(h);
+                else if (h.st) pool.release(h.st);
+                h_is_feat = false;
                 drop(skip);
                 Act y = resnet(cat, bp + ".resnets." + std::to_string(j), cfg.unet_norm_eps);
                 drop(cat);
@@ -1044,10 +1079,10 @@ struct gp_engine {
                 drop(h);
                 h = y;
             }
-            if (feats) {
-                feats[i] = new_act(h.B, h.H, h.W, h.C);
-                mark("feat_copy " + dims(h));
-                HIPCHK(hipMemcpyAsync(feats[i].p, h.p, (size_t)h.pixels() * h.C * 2, hipMemcpyDeviceToDevice, st));
+            if (feats) {  // custom_unet.py:365,400: the output of every up block; retained, not copied (the buffer outlives its use here)
+                feats[i] = h;
+                feats[i].st = nullptr;  // (its statistics partials stay with h and are released below / by the next concat)
+                h_is_feat = true;
             }
         }
         Act out;
@@ -1058,7 +1093,8 @@ struct gp_engine {
             out = conv(n, convs.at("unet.conv_out"), o);
             drop(n);
         }
-        drop(h);
+        if (!h_is_feat) drop(h);
+        else if (h.st) { pool.release(h.st); }
         return out;
     }
 
@@ -1458,6 +1494,63 @@ gp_status gp_infer(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, i
             launch_minmax_norm(out_dev, B, out_px, mm_ws, e->st);
             e->pool.release(mm_ws);
         }
+        e->mark("END", 0.0, 0);
+        if (stage_ev) {
+            HIPCHK(hipEventRecord(e->ev[3], e->st));
+            HIPCHK(hipEventSynchronize(e->ev[3]));
+            HIPCHK(hipEventElapsedTime(&e->tm.ms_encode, e->ev[0], e->ev[1]));
+            HIPCHK(hipEventElapsedTime(&e->tm.ms_unet, e->ev[1], e->ev[2]));
+            HIPCHK(hipEventElapsedTime(&e->tm.ms_head, e->ev[2], e->ev[3]));
+            HIPCHK(hipEventElapsedTime(&e->tm.ms_total, e->ev[0], e->ev[3]));
+        }
+        HIPCHK(hipGetLastError());
+    });
+}
+
+gp_status gp_infer_steps(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, int W, gp_mode mode, const gp_ddim_step* steps,
+                         int n_steps, const float* noise_dev, float* out_dev, void* stream) {
+    if (!e || !rgb_dev || !out_dev || !steps) return GP_ERR_INVALID;
+    return guard(e, [&] {
+        check_ready(e, stream);
+        if (B < 1 || H < 8 || W < 8 || n_steps < 1) throw std::invalid_argument("need B >= 1, H, W >= 8 and at least one step");
+        if (e->cfg.dpt_enabled || !e->cfg.unet_has_out) throw std::invalid_argument("the multi-step archs use the VAE-decoder head");
+        const int L = e->cfg.vae_latent_channels;
+        if (e->cfg.unet_in_channels != (noise_dev ? 2 * L : L))
+            throw std::invalid_argument(noise_dev ? "an initial noise sample needs a UNet with 2 x latent input channels (marigold, run.py:59-78)"
+                                                  : "without an initial noise sample the UNet takes the latent channels only (rgb_blending)");
+        const bool stage_ev = e->prof >= 1;
+        if (stage_ev) {
+            for (int i = 0; i < 4; ++i) if (!e->ev[i]) HIPCHK(hipEventCreate(&e->ev[i]));
+            HIPCHK(hipEventRecord(e->ev[0], e->st));
+        }
+        e->marks_used = 0;
+        const float t_before = e->timestep;
+        Act lat = e->vae_encode(rgb_dev, is_u8, B, H, W);  // channels 0..L-1 = rgb latent; the UNet input tensor from here on
+        if (stage_ev) HIPCHK(hipEventRecord(e->ev[1], e->st));
+        const int off = noise_dev ? L : 0;
+        float* sample = (float*)e->pool.alloc((size_t)lat.pixels() * L * sizeof(float));
+        e->mark("ddim_init");
+        launch_ddim_init(noise_dev, lat.p, sample, B, lat.H, lat.W, L, lat.C, off, e->st);
+        Act x0 = e->new_act(B, lat.H, lat.W, 64);
+        for (int i = 0; i < n_steps; ++i) {
+            const gp_ddim_step& s = steps[i];
+            if (s.timestep != e->timestep) e->set_timestep_on_stream(s.timestep);
+            Act v = e->unet(lat, nullptr, true);
+            const DdimCoef k{s.x0_sample, s.x0_model, s.eps_sample, s.eps_model, s.prev_x0, s.prev_eps, s.clip};
+            e->mark("ddim_step");
+            launch_ddim_step(v.p, v.C, sample, lat.p, lat.C, off, i == n_steps - 1 ? x0.p : nullptr, x0.C, lat.pixels(), L, k, e->st);
+            e->drop(v);
+        }
+        e->pool.release(sample);
+        e->drop(lat);
+        if (e->timestep != t_before) e->set_timestep_on_stream(t_before);
+        if (stage_ev) HIPCHK(hipEventRecord(e->ev[2], e->st));
+        Act dec = e->vae_decode(x0, 1.0f / e->cfg.vae_scaling_factor);
+        e->drop(x0);
+        const int mean3 = !(mode == GP_MODE_NORMAL || mode == GP_MODE_SEG);
+        e->mark("decode_epilogue");
+        launch_decode_epilogue(dec.p, out_dev, B, dec.H, dec.W, dec.C, mean3, 0, e->st);
+        e->drop(dec);
         e->mark("END", 0.0, 0);
         if (stage_ev) {
             HIPCHK(hipEventRecord(e->ev[3], e->st));

@@ -117,6 +117,10 @@ void launch_rgb_conv_in(const void* rgb, int is_u8, const h16_t* w27, const floa
 void launch_concat(const h16_t* a, int Ca, const h16_t* b, int Cb, h16_t* out, long long pixels, hipStream_t s);
 int concat_stats_bm(long long hw);  // pixels per statistics tile launch_concat_stats can use for an image of hw pixels (0: none)
 void launch_concat_stats(const h16_t* a, int Ca, const h16_t* b, int Cb, h16_t* out, long long pixels, int bm, float* part, hipStream_t s);
+struct DdimCoef { float x0_sample, x0_model, eps_sample, eps_model, prev_x0, prev_eps, clip; };
+void launch_ddim_init(const float* noise_nchw, h16_t* lat, float* sample, int B, int H, int W, int L, int ld, int off, hipStream_t s);
+void launch_ddim_step(const h16_t* model, int ldm, float* sample, h16_t* uin, int ldu, int off, h16_t* x0_out, int ldx, long long pixels, int L,
+                      const DdimCoef& k, hipStream_t s);
 void launch_nchw_f32_to_nhwc(const float* in, h16_t* out, int B, int C, int H, int W, int Cpad, hipStream_t s);
 void launch_nhwc_to_nchw_f32(const h16_t* in, float* out, int B, int C, int H, int W, int ld, hipStream_t s);
 void launch_decode_epilogue(const h16_t* in, float* out, int B, int H, int W, int ld, int mean3, int raw, hipStream_t s);  // mean, clip, (x+1)/2

@@ -74,6 +74,11 @@ _libs: Dict[str, C.CDLL] = {}
 
 # (name, restype, argtypes) for every symbol include/genpercept_hip.h declares
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+class GpDdimStep(C.Structure):
+    """`gp_ddim_step` (include/genpercept_hip.h)."""
+    _fields_ = [(n, C.c_float) for n in ("timestep", "x0_sample", "x0_model", "eps_sample", "eps_model", "prev_x0", "prev_eps", "clip")]
+
+
 SYMBOLS = {
     "gp_default_config": (None, [C.POINTER(GpConfig)]),
     "gp_create": (_i, [C.POINTER(GpConfig), C.POINTER(_vp)]),
@@ -86,6 +91,7 @@ SYMBOLS = {
     "gp_set_timestep": (_i, [_vp, _f]),
     "gp_finalize": (_i, [_vp]),
     "gp_infer": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "gp_infer_steps": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "gp_vae_encode": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gp_unet": (_i, [_vp, _vp, _i, _i, _i, _vp, C.POINTER(_vp), _vp]),
     "gp_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -252,6 +258,29 @@ class Engine:
         oh, ow = (self.lib.gp_dpt_out_size(lh), self.lib.gp_dpt_out_size(lw)) if self.cfg.dpt_enabled else (8 * lh, 8 * lw)
         out = torch.empty((b, c, oh, ow), dtype=torch.float32, device=rgb.device)
         self._check(self.lib.gp_infer(self._h, rgb.data_ptr(), int(is_u8), b, h, w, MODES[mode], out.data_ptr(), _stream_ptr(self.device)))
+        return out
+
+    def infer_steps(self, rgb: torch.Tensor, mode: str, steps, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The denoising loop of the multi-step archs (gp_infer_steps).  steps: the dicts of `DDIMSchedulerCustomized.plan()`;
+        noise: fp32 [B,L,h,w] on this device (marigold) or None (rgb_blending: the sample starts as the rgb latent)."""
+        assert rgb.is_cuda and rgb.dim() == 4 and rgb.shape[1] == 3
+        is_u8 = rgb.dtype == torch.uint8
+        rgb = (rgb if is_u8 else rgb.float()).contiguous()
+        b, _, h, w = rgb.shape
+        lh, lw = self.lib.gp_latent_size(h), self.lib.gp_latent_size(w)
+        arr = (GpDdimStep * len(steps))()
+        for a, s in zip(arr, steps):
+            if s.get("std", 0.0) or s.get("eps_from_x0", False):
+                raise ValueError("the engine's loop is the deterministic update (eta = 0, use_clipped_model_output = False)")
+            for f, _t in GpDdimStep._fields_:
+                setattr(a, f, float(s[f]))
+        if noise is not None:
+            if tuple(noise.shape) != (b, self.cfg.vae_latent_channels, lh, lw):
+                raise ValueError(f"noise must be [{b},{self.cfg.vae_latent_channels},{lh},{lw}], got {tuple(noise.shape)}")
+            noise = noise.to(device=rgb.device, dtype=torch.float32).contiguous()
+        out = torch.empty((b, 1 if mode in ONE_CHANNEL_MODES else 3, 8 * lh, 8 * lw), dtype=torch.float32, device=rgb.device)
+        self._check(self.lib.gp_infer_steps(self._h, rgb.data_ptr(), int(is_u8), b, h, w, MODES[mode], C.cast(arr, _vp), len(steps),
+                                            _ptr(noise), out.data_ptr(), _stream_ptr(self.device)))
         return out
 
     def vae_encode(self, rgb: torch.Tensor) -> torch.Tensor:

@@ -1,5 +1,6 @@
 """GenPerceptPipeline: host-side mirror of the reference's `genpercept.GenPerceptPipeline`
-(/root/reference/genpercept/genpercept_pipeline.py:64-526) for the one-step `archs=genpercept` path.
+(/root/reference/genpercept/genpercept_pipeline.py:64-526): the one-step `archs=genpercept` path and the multi-step
+`marigold` / `rgb_blending` archs (run.py:361-368).
 
 Same constructor keywords, same `__call__` keywords, same assertions and exceptions, same `GenPerceptOutput`
 (`pred_np`, `pred_colored`), so `run.py:420-432` / `infer.py:417-430` style drivers work unchanged.  Differences, all
@@ -7,9 +8,10 @@ behind the same surface:
   * `unet` / `vae` / `customized_head` may be anything exposing `state_dict()` (real diffusers modules included), a plain
     dict of tensors in the diffusers key layout, or a directory holding a diffusers safetensors/bin checkpoint — `diffusers`
     itself is never imported;
-  * `scheduler` is only inspected: beta_start == beta_end == 1 and v_prediction make DDIM's pred_original_sample equal
-    to -model_output at t = 1 (genpercept_pipeline.py:465; src/customized_modules/ddim.py:166-204), which the engine
-    implements directly; any other scheduler raises NotImplementedError (multi-step archs are out of this path);
+  * `scheduler` is reduced to scalars on the host (`genpercept_amd.scheduler.DDIMSchedulerCustomized`, built from any object / dict /
+    directory carrying a DDIM scheduler config).  beta_start == beta_end == 1 with v_prediction makes DDIM's pred_original_sample equal
+    to -model_output (genpercept_pipeline.py:465; src/customized_modules/ddim.py:166-204): that case is `gp_infer`; every other
+    scheduler, and the multi-step archs, run the denoising loop inside the engine (`gp_infer_steps`);
   * `text_encoder` may be a precomputed [L, D] embedding of the prompt (e.g. the v1 `empty_text_embed.npy`);
   * all tensor math runs in libgenpercept_hip.so on one MI355X; there is no PyTorch/CPU fallback.
 New: `infer_batch` for a list of images / a [B,3,H,W] tensor (the reference is one image per call).
@@ -132,6 +134,22 @@ def _sched_attr(s, name, default=None):
     return default
 
 
+def _as_scheduler(s):
+    """Anything carrying a DDIM scheduler config -> the host-side scheduler (None stays None)."""
+    from .scheduler import DDIMSchedulerCustomized, _DEFAULTS
+    if s is None or isinstance(s, DDIMSchedulerCustomized):
+        return s
+    if "LCM" in type(s).__name__ or "LCM" in str(_sched_attr(s, "_class_name", "")):
+        raise NotImplementedError("LCMScheduler checkpoints are not supported (the reference's run.py only builds DDIMSchedulerCustomized)")
+    if isinstance(s, (str, os.PathLike)):
+        d = str(s)
+        return DDIMSchedulerCustomized.from_pretrained(d, subfolder="scheduler" if os.path.isdir(os.path.join(d, "scheduler")) else None)
+    cfg = {k: _sched_attr(s, k) for k in _DEFAULTS if _sched_attr(s, k, None) is not None}
+    if "beta_start" not in cfg or "beta_end" not in cfg:
+        raise TypeError(f"cannot read a DDIM scheduler config from {type(s)}")
+    return DDIMSchedulerCustomized(**cfg)
+
+
 class GenPerceptPipeline:
     latent_scale_factor = 0.18215  # genpercept_pipeline.py:96
 
@@ -139,16 +157,19 @@ class GenPerceptPipeline:
                  default_processing_resolution: Optional[int] = 768, rgb_blending=False, customized_head=None, genpercept_pipeline=True,
                  device: Union[str, int, torch.device, None] = None, torch_dtype: Optional[torch.dtype] = None, head_type: Optional[str] = None):
         self.genpercept_pipeline = genpercept_pipeline
-        if not genpercept_pipeline:
-            raise NotImplementedError("only the one-step archs=genpercept path is implemented (multi-step marigold/rgb_blending are out of scope)")
-        default_denoising_steps = 1  # genpercept_pipeline.py:115-117
-        rgb_blending = True
-        self.scheduler = scheduler
-        if scheduler is not None:
-            bs, be = _sched_attr(scheduler, "beta_start"), _sched_attr(scheduler, "beta_end")
-            pt = _sched_attr(scheduler, "prediction_type", "v_prediction")
-            if bs != 1 or be != 1 or pt != "v_prediction":
-                raise NotImplementedError(f"one-step GenPercept needs the beta=1/1 v_prediction scheduler (got beta {bs}/{be}, {pt})")
+        if genpercept_pipeline:  # genpercept_pipeline.py:115-117
+            default_denoising_steps = 1
+            rgb_blending = True
+        self.scheduler = _as_scheduler(scheduler)
+        if self.scheduler is None and not genpercept_pipeline:
+            raise ValueError("the multi-step archs (genpercept_pipeline=False) need a scheduler")
+        # beta == 1 everywhere with v_prediction: alphas_cumprod == 0, so one step's pred_original_sample is -model_output for any t
+        c = self.scheduler.config if self.scheduler is not None else None
+        self._x0_is_neg_v = c is None or (c.beta_start == 1 and c.beta_end == 1 and c.prediction_type == "v_prediction"
+                                          and c.trained_betas is None and not c.rescale_betas_zero_snr and not c.clip_sample and not c.thresholding)
+        if customized_head is not None:  # genpercept_pipeline.py:141-143
+            assert rgb_blending and self.scheduler is not None and c.beta_start == 1 and c.beta_end == 1
+            assert genpercept_pipeline
         self._unet_src, self._vae_src, self._head_src = unet, vae, customized_head
         self._head_kind = _head_kind(customized_head, head_type) if customized_head is not None else None
         if self._head_kind == "relu":  # genpercept_pipeline.py:474,483-484: only the ...Identity head is a valid customized_head
@@ -240,6 +261,12 @@ class GenPerceptPipeline:
         unet_sd, vae_sd, head_sd = _state_dict_of(self._unet_src), _state_dict_of(self._vae_src), _state_dict_of(self._head_src)
         if unet_sd is None or vae_sd is None:
             raise ValueError("unet and vae weights are required")
+        if not (self.rgb_blending or self.genpercept_pipeline):
+            lat = int(vae_sd["post_quant_conv.weight"].shape[0]) if "post_quant_conv.weight" in vae_sd else 4
+            if int(unet_sd["conv_in.weight"].shape[1]) == lat:  # run.py:322-323: marigold on a 4-channel UNet checkpoint
+                from .weights import replace_unet_conv_in
+                unet_sd = replace_unet_conv_in(unet_sd)
+                logging.info("Unet conv_in layer is replaced")
         ucfg, vcfg = gcfg.infer_unet_config(unet_sd), gcfg.infer_vae_config(vae_sd)
         dcfg = gcfg.infer_dpt_config(head_sd) if head_sd is not None else None
         if head_sd is not None:
@@ -291,10 +318,22 @@ class GenPerceptPipeline:
     def single_infer(self, rgb_in: torch.Tensor, num_inference_steps: int = 1, generator=None, show_pbar: bool = False, fix_timesteps=None,
                      prompt="") -> torch.Tensor:
         """genpercept_pipeline.py:375-486.  rgb_in: [B,3,h,w] in [-1,1] (or uint8 0..255) -> [B,C,h',w'] in [0,1]."""
-        assert num_inference_steps == 1, "GenPercept only forward once."
-        eng = self._prepare(fix_timesteps, prompt)
+        if self.genpercept_pipeline:
+            assert num_inference_steps == 1, "GenPercept only forward once."
         rgb_in = rgb_in.to(self._device)
-        return eng.infer(rgb_in, self.mode or "depth")
+        mode = self.mode or "depth"
+        if self.genpercept_pipeline and self._x0_is_neg_v:
+            return self._prepare(fix_timesteps, prompt).infer(rgb_in, mode)
+        # the denoising loop (:447-465): the scheduler becomes one affine update per step, the loop itself runs in the engine
+        eng = self._prepare(None, prompt)
+        plan = self.scheduler.plan(int(num_inference_steps), fix_timesteps)
+        noise = None
+        if not (self.rgb_blending or self.genpercept_pipeline):  # marigold: the sample starts as noise (:413-420)
+            lh, lw = eng.lib.gp_latent_size(rgb_in.shape[-2]), eng.lib.gp_latent_size(rgb_in.shape[-1])
+            shape = (rgb_in.shape[0], self.vae_config.latent_channels, lh, lw)
+            gdev = generator.device if generator is not None else self._device
+            noise = torch.randn(shape, device=gdev, dtype=torch.float32, generator=generator).to(self._device)
+        return eng.infer_steps(rgb_in, mode, plan, noise)
 
     @torch.no_grad()
     def encode_rgb(self, rgb_in: torch.Tensor) -> torch.Tensor:
@@ -320,8 +359,11 @@ class GenPerceptPipeline:
             processing_res = self.default_processing_resolution
         assert processing_res >= 0
         assert ensemble_size >= 1
-        assert ensemble_size == 1  # genpercept_pipeline.py:211-213
-        assert denoising_steps == 1
+        if self.genpercept_pipeline:  # genpercept_pipeline.py:211-216
+            assert ensemble_size == 1
+            assert denoising_steps == 1
+        else:
+            self._check_inference_step(denoising_steps)
         resample = get_resample_method(resample_method)
         # genpercept_pipeline.py:264-270: batch size of the ensemble loader (always 1 on the one-step path: ensemble_size == 1)
         if batch_size <= 0:
@@ -337,12 +379,37 @@ class GenPerceptPipeline:
             raise TypeError(f"Unknown input type: {type(input_image) = }")
         input_size = rgb.shape
         assert 4 == rgb.dim() and 3 == input_size[-3], f"Wrong input shape {input_size}, expected [1, rgb, H, W]"
-        outs = self._run(rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt)
+        opts = dict(steps=int(denoising_steps), ensemble_size=int(ensemble_size), batch_size=int(batch_size), generator=generator,
+                    ensemble_kwargs=ensemble_kwargs)
+        outs = self._run(rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt, opts)
         return outs[0] if rgb.shape[0] == 1 else outs
+
+    def _check_inference_step(self, n_step: int) -> None:
+        """genpercept_pipeline.py:338-358 (DDIM branch; LCM schedulers are refused at construction)."""
+        assert n_step >= 1
+        if n_step < 10:
+            logging.warning(f"Too few denoising steps: {n_step}. Recommended to use the LCM checkpoint for few-step inference.")
+
+    def _predict(self, x: torch.Tensor, fix_timesteps, prompt, opts: Optional[dict]) -> torch.Tensor:
+        """The batched prediction + test-time ensembling of __call__ (genpercept_pipeline.py:250-297), per image of `x`."""
+        o = opts or {}
+        steps, e = o.get("steps", self.default_denoising_steps if not self.genpercept_pipeline else 1), o.get("ensemble_size", 1)
+        gen = o.get("generator")
+        if e == 1:
+            return self.single_infer(x, steps, gen, False, fix_timesteps, prompt)
+        from .ensemble import ensemble_depth
+        bs = max(1, o.get("batch_size", 1))
+        outs = []
+        for i in range(x.shape[0]):
+            dup = x[i:i + 1].expand(e, -1, -1, -1)
+            preds = torch.cat([self.single_infer(dup[j:j + bs], steps, gen, False, fix_timesteps, prompt) for j in range(0, e, bs)], dim=0)
+            pred, _ = ensemble_depth(preds, scale_invariant=True, shift_invariant=True, max_res=50, **(o.get("ensemble_kwargs") or {}))
+            outs.append(pred)
+        return torch.cat(outs, dim=0)
 
     def infer_batch(self, images: Union[Sequence[Image.Image], torch.Tensor], mode: str, processing_res: Optional[int] = None,
                     match_input_res: bool = True, resample_method: str = "bilinear", color_map: Optional[str] = "Spectral", fix_timesteps=None,
-                    prompt="") -> List[GenPerceptOutput]:
+                    prompt="", denoising_steps: Optional[int] = None, ensemble_size: int = 1, generator=None) -> List[GenPerceptOutput]:
         """Batch entry (new): images of one common size, one engine call; results are per image (DPT min-max per image)."""
         self.mode = mode
         if processing_res is None:
@@ -350,15 +417,19 @@ class GenPerceptPipeline:
         if not torch.is_tensor(images):
             images = torch.stack([torch.from_numpy(np.asarray(im.convert("RGB")).copy()).permute(2, 0, 1) for im in images])
         assert images.dim() == 4 and images.shape[1] == 3
-        return self._run(images, processing_res, match_input_res, get_resample_method(resample_method), color_map, fix_timesteps, prompt)
+        steps = self.default_denoising_steps if denoising_steps is None else int(denoising_steps)
+        if self.genpercept_pipeline:
+            assert steps == 1 and ensemble_size == 1
+        opts = dict(steps=steps, ensemble_size=int(ensemble_size), batch_size=max(1, int(ensemble_size)), generator=generator, ensemble_kwargs=None)
+        return self._run(images, processing_res, match_input_res, get_resample_method(resample_method), color_map, fix_timesteps, prompt, opts)
 
-    def _run(self, rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt) -> List[GenPerceptOutput]:
+    def _run(self, rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt, opts=None) -> List[GenPerceptOutput]:
         from .engine import RESAMPLE_CODE
         if rgb.dtype == torch.uint8 and resample in RESAMPLE_CODE and not os.environ.get("GENPERCEPT_HOST_PREPOST"):
-            return self._run_device(rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt)
-        return self._run_host(rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt)
+            return self._run_device(rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt, opts)
+        return self._run_host(rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt, opts)
 
-    def _run_device(self, rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt) -> List[GenPerceptOutput]:
+    def _run_device(self, rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt, opts=None) -> List[GenPerceptOutput]:
         """Pre / post processing on the GPU (gp_preprocess / gp_postprocess): the uint8 image goes up once, resize_max_res, the model, the
         resize back to the input size, clip, colour map and the 8-bit image all run on the device; pred_np and the coloured bytes come down."""
         from . import engine as ge
@@ -368,7 +439,7 @@ class GenPerceptPipeline:
         x = rgb.to(self._device, non_blocking=True)
         if processing_res > 0:
             x = ge.preprocess(x, ge.resize_max_res_size(int(input_size[-2]), int(input_size[-1]), int(processing_res)), resample)
-        pred = self.single_infer(x, 1, None, False, fix_timesteps, prompt)
+        pred = self._predict(x, fix_timesteps, prompt, opts)
         size = tuple(int(v) for v in input_size[-2:]) if match_input_res else tuple(pred.shape[-2:])
         one_ch = pred.shape[1] == 1
         pred_out, col, q8 = ge.postprocess(pred, size, resample, cmap=color_map if one_ch else None, q_bits=0 if color_map is not None else 8)
@@ -390,7 +461,7 @@ class GenPerceptPipeline:
             outs.append(GenPerceptOutput(pred_np=p, pred_colored=col_img))
         return outs
 
-    def _run_host(self, rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt) -> List[GenPerceptOutput]:
+    def _run_host(self, rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt, opts=None) -> List[GenPerceptOutput]:
         """The same steps with the resizes / colour map on the host (torch CPU + matplotlib): float inputs and bicubic resampling."""
         input_size = rgb.shape
         if processing_res > 0:
@@ -400,7 +471,7 @@ class GenPerceptPipeline:
         else:
             rgb_in = rgb.float() / 255.0 * 2.0 - 1.0
             assert rgb_in.min() >= -1.0 and rgb_in.max() <= 1.0
-        pred = self.single_infer(rgb_in, 1, None, False, fix_timesteps, prompt)
+        pred = self._predict(rgb_in, fix_timesteps, prompt, opts)
         if match_input_res:
             pred = resize_to(pred, input_size[-2:], resample)
         pred = pred.cpu().numpy().clip(0, 1)

@@ -213,3 +213,12 @@ def merge_lora_state_dict(sd: Dict[str, torch.Tensor], scale: Optional[float] = 
         else:
             out[k] = v
     return out
+
+
+def replace_unet_conv_in(unet_sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """run.py:59-78 (`_replace_unet_conv_in`): the marigold arch feeds [rgb_latent, pred_latent]; a UNet saved with the plain latent
+    input gets its conv_in weight repeated along the input axis and halved ("half the activation magnitude"), bias unchanged."""
+    sd = dict(unet_sd)
+    w = sd["conv_in.weight"]
+    sd["conv_in.weight"] = (w.repeat(1, 2, 1, 1) * 0.5).contiguous()
+    return sd

@@ -13,6 +13,8 @@
  *   gp_load_tensor    from_pretrained / load_state_dict of the diffusers-layout checkpoints   run.py:296-357
  *   gp_set_context    encode_text + text_embed cache                genpercept_pipeline.py:360-372,425-429
  *   gp_set_timestep   scheduler.set_timesteps / fix_timesteps       genpercept_pipeline.py:403-408
+ *   gp_infer_steps    single_infer for archs marigold / rgb_blending: the denoising loop with the DDIM update
+ *                                                                   genpercept_pipeline.py:413-422,447-465; ddim.py:144-217; run.py:361-368
  * The per-kernel entry points (gp_conv2d ... gp_bilinear) exist for the parity tests; they are the same launchers the
  * engine uses.
  *
@@ -101,6 +103,22 @@ gp_status gp_finalize(gp_engine* e);
 int gp_latent_size(int pixels);   /* three VAE downsamples: x -> (x - 2) / 2 + 1 */
 int gp_dpt_out_size(int latent);  /* DPT head output edge: 32 * (two UNet downsamples of the latent edge) == 8 * latent when latent % 4 == 0 */
 gp_status gp_infer(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, int W, gp_mode mode, float* out_dev, void* stream);
+
+/* The multi-step archs (VAE-decoder head only).  One scheduler step in affine form (what diffusers' DDIMScheduler.step computes for
+ * epsilon / sample / v_prediction with eta = 0; the host derives the numbers, genpercept_amd/scheduler.py):
+ *   x0 = clip(x0_sample * s + x0_model * m, +-clip)   (clip <= 0: none),   eps = eps_sample * s + eps_model * m,
+ *   s' = prev_x0 * x0 + prev_eps * eps,               m = UNet(input_t, timestep), s = current sample.
+ * noise_dev != NULL (marigold): DEVICE fp32 [B][L][h][w] initial sample; the UNet reads [rgb_latent, sample] (unet_in_channels == 2L).
+ * noise_dev == NULL (rgb_blending): the sample starts as the rgb latent and is itself the UNet input (unet_in_channels == L).
+ * The result is the LAST step's x0 (pred_original_sample, :465), decoded / clipped / shifted exactly like gp_infer.  The engine's
+ * timestep (gp_set_timestep) is restored on return; the first use of a new timestep value folds its time embedding on the host (tens
+ * of ms, once per engine and value), later uses are one device copy. */
+typedef struct gp_ddim_step {
+    float timestep;
+    float x0_sample, x0_model, eps_sample, eps_model, prev_x0, prev_eps, clip;
+} gp_ddim_step;
+gp_status gp_infer_steps(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, int W, gp_mode mode, const gp_ddim_step* steps,
+                         int n_steps, const float* noise_dev, float* out_dev, void* stream);
 
 /* Stage-level entry points (DEVICE fp32 NCHW in/out). */
 gp_status gp_vae_encode(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, int W, float* latent_out, void* stream);

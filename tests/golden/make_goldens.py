@@ -13,6 +13,12 @@ Fixtures are data (seeds, inputs, expected outputs) — never reference source.
   infer_eval_ref.npz the REFERENCE's get_pred_name (all naming modes) and alignment variants (max_resolution, disparity-space protocol).
   datasets_ref.npz   the REFERENCE's dataset conventions beyond NYU (KITTI crop / masks / decode, ETH3D, ScanNet, DIODE) and angular_loss.
   image_util_ref.npz the REFERENCE's colorize_depth_maps / chw2hwc outputs, resize_max_res size rule, resample-method names.
+  scheduler_ref.npz  the REFERENCE's DDIMSchedulerCustomized (src/customized_modules/ddim.py:144-217): betas / alphas_cumprod /
+                     final_alpha_cumprod of every hf_configs/scheduler_* config (+ the scaled_linear_power schedule) and _get_variance;
+                     its diffusers base class is a stub (the class's own __init__ and _get_variance never call into it).
+  ensemble_ref.npz   the REFERENCE's ensemble_depth (genpercept/util/ensemble.py) on seeded affine-distorted maps (inputs below
+                     max_res, so torchvision -- stubbed -- is never reached).
+  e2e_multistep.npz  oracle goldens of the multi-step archs (marigold: noise + 8-channel conv_in; rgb_blending) on the tiny configs.
   e2e_tiny.npz       end-to-end goldens of the fp32 oracle (oracle/) on the tiny configs: inputs + expected outputs
                      for every stage (latent, unet out, feats, decode, final) — what the HIP path is checked against
                      on the GPU box where neither /root/reference nor large weights exist.
@@ -352,6 +358,133 @@ def make_image_util_golden():
     print("image_util golden:", len(sizes), "size cases;", dict(names))
 
 
+def _load_ref_module(name, rel):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def make_scheduler_golden():
+    import glob
+    import json
+    d, dc = types.ModuleType("diffusers"), types.ModuleType("diffusers.configuration_utils")
+
+    class _Base:  # DDIMScheduler / DDPMScheduler stand-ins: the customised classes override __init__ and never call super()
+        pass
+    d.DDIMScheduler, d.DDPMScheduler = _Base, type("DDPMScheduler", (), {})
+    dc.ConfigMixin, dc.register_to_config = object, (lambda f: f)
+    d.configuration_utils = dc
+    saved = {k: sys.modules.get(k) for k in ("diffusers", "diffusers.configuration_utils")}
+    sys.modules.update({"diffusers": d, "diffusers.configuration_utils": dc})
+    try:
+        ddim = _load_ref_module("ref_ddim", "src/customized_modules/ddim.py")
+        out, names = {}, []
+        keys = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "trained_betas", "clip_sample", "set_alpha_to_one",
+                "steps_offset", "prediction_type", "thresholding", "dynamic_thresholding_ratio", "clip_sample_range", "sample_max_value",
+                "timestep_spacing", "rescale_betas_zero_snr")
+        cfgs = {}
+        for f in sorted(glob.glob(os.path.join(REF, "hf_configs/scheduler_*/scheduler_config.json"))):
+            cfgs[os.path.basename(os.path.dirname(f))] = {k: v for k, v in json.load(open(f)).items() if k in keys}
+        cfgs["power_2.0"] = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear_power", power_beta_curve=2.0,
+                                 set_alpha_to_one=False, prediction_type="v_prediction", clip_sample=False, steps_offset=1)
+        cfgs["power_3.0_zero_snr"] = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear_power", power_beta_curve=3.0,
+                                          rescale_betas_zero_snr=True, set_alpha_to_one=True)
+        pairs = [(999, 899), (501, 451), (51, 1), (1, -49), (20, 19), (981, 961)]
+        for name, cfg in cfgs.items():
+            s = ddim.DDIMSchedulerCustomized(**cfg)
+            names.append(name)
+            out[name + "/cfg"] = np.array(json.dumps(cfg))
+            out[name + "/betas"] = s.betas.numpy()
+            out[name + "/alphas_cumprod"] = s.alphas_cumprod.numpy()
+            out[name + "/final_alpha_cumprod"] = np.float32(s.final_alpha_cumprod)
+            out[name + "/variance"] = np.array([float(s._get_variance(t, p)) for t, p in pairs], dtype=np.float64)
+        out["names"] = np.array(names)
+        out["variance_pairs"] = np.array(pairs, dtype=np.int64)
+    finally:
+        for k, v in saved.items():
+            sys.modules.pop(k, None) if v is None else sys.modules.__setitem__(k, v)
+    np.savez_compressed(os.path.join(HERE, "scheduler_ref.npz"), **out)
+    print("scheduler_ref.npz", names, os.path.getsize(os.path.join(HERE, "scheduler_ref.npz")) // 1024, "KiB")
+
+
+def make_ensemble_golden():
+    tv, tvt, tvf = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms"), types.ModuleType("torchvision.transforms.functional")
+
+    class IM:
+        BILINEAR, BICUBIC, NEAREST, NEAREST_EXACT = "bilinear", "bicubic", "nearest", "nearest-exact"
+
+    def no_resize(*a, **k):
+        raise AssertionError("the ensemble fixtures stay below max_res: torchvision must not be reached")
+    tvt.InterpolationMode, tvf.resize = IM, no_resize
+    tv.transforms, tvt.functional = tvt, tvf
+    pk, pu = types.ModuleType("ref_gp"), types.ModuleType("ref_gp.util")
+    pk.__path__, pu.__path__ = [os.path.join(REF, "genpercept")], [os.path.join(REF, "genpercept/util")]
+    names = ("torchvision", "torchvision.transforms", "torchvision.transforms.functional", "ref_gp", "ref_gp.util")
+    saved = {k: sys.modules.get(k) for k in names}
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.transforms.functional": tvf, "ref_gp": pk, "ref_gp.util": pu})
+    try:
+        import importlib
+        ens = importlib.import_module("ref_gp.util.ensemble")
+        rng = np.random.RandomState(11)
+        out, cases = {}, []
+        yy, xx = np.mgrid[0:40, 0:48].astype(np.float32)
+        base = 0.5 + 0.35 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + 0.1 * (yy / 40.0)
+        for tag, e, kw in (("affine_med5", 5, {}), ("affine_med4", 4, {}), ("affine_mean3", 3, dict(reduction="mean")),
+                           ("scale_med6", 6, dict(shift_invariant=False)), ("affine_unc7", 7, dict(output_uncertainty=True)),
+                           ("affine_iter8", 5, dict(max_iter=8, tol=1e-5, regularizer_strength=0.05)), ("single", 1, {})):
+            s = rng.uniform(0.6, 1.6, size=(e, 1, 1, 1)).astype(np.float32)
+            t = rng.uniform(-0.2, 0.3, size=(e, 1, 1, 1)).astype(np.float32) * (0 if kw.get("shift_invariant") is False else 1)
+            d = (base[None, None] * s + t + rng.normal(0, 0.02, size=(e, 1, 40, 48))).astype(np.float32)
+            if kw.get("shift_invariant") is False:
+                d = np.abs(d)
+            pred, unc = ens.ensemble_depth(torch.from_numpy(d), scale_invariant=True, max_res=50, **{"shift_invariant": True, **kw})
+            out[tag + "/in"], out[tag + "/pred"] = d, pred.numpy()
+            if unc is not None:
+                out[tag + "/unc"] = unc.numpy()
+            import json
+            out[tag + "/kw"] = np.array(json.dumps(kw))
+            cases.append(tag)
+        out["cases"] = np.array(cases)
+    finally:
+        for k, v in saved.items():
+            sys.modules.pop(k, None) if v is None else sys.modules.__setitem__(k, v)
+    np.savez_compressed(os.path.join(HERE, "ensemble_ref.npz"), **out)
+    print("ensemble_ref.npz", cases, os.path.getsize(os.path.join(HERE, "ensemble_ref.npz")) // 1024, "KiB")
+
+
+MULTISTEP_SCHED = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False,
+                       steps_offset=1, prediction_type="v_prediction", timestep_spacing="leading")  # hf_configs/scheduler_beta_0.00085_0.012
+
+
+def make_e2e_multistep():
+    vc = osd.VAECfg.tiny()
+    uc4 = osd.UNetCfg.tiny()
+    uc8 = osd.UNetCfg(in_channels=8, block_out_channels=uc4.block_out_channels, num_heads=uc4.num_heads, cross_attention_dim=uc4.cross_attention_dim)
+    vae_sd = osd.synth_state_dict(osd.vae_manifest(vc), seed=2)
+    unet4 = osd.synth_state_dict(osd.unet_manifest(uc4), seed=1)
+    unet8 = opipe.replace_unet_conv_in(unet4)  # run.py:59-78 on the same seeded 4-channel UNet
+    g = torch.Generator().manual_seed(77)
+    ctx = torch.randn(2, uc4.cross_attention_dim, generator=g)
+    out = {"ctx": ctx.numpy()}
+    with torch.no_grad():
+        for tag, (h, w) in (("sq", (64, 64)), ("odd", (72, 88))):
+            rgb = torch.randint(0, 256, (2, 3, h, w), generator=g, dtype=torch.uint8)
+            noise = torch.randn(2, 4, h // 8, w // 8, generator=g)
+            out[f"{tag}_rgb"], out[f"{tag}_noise"] = rgb.numpy(), noise.numpy()
+            x = opipe.normalize_rgb(rgb)
+            for steps in (1, 4, 10):
+                out[f"{tag}_marigold_{steps}"] = opipe.multi_step_infer(vae_sd, vc, unet8, uc8, x, ctx, "depth", opipe.DDIM(**MULTISTEP_SCHED), steps, noise).numpy()
+                out[f"{tag}_blend_{steps}"] = opipe.multi_step_infer(vae_sd, vc, unet4, uc4, x, ctx, "depth", opipe.DDIM(**MULTISTEP_SCHED), steps).numpy()
+            out[f"{tag}_blend_normal_4"] = opipe.multi_step_infer(vae_sd, vc, unet4, uc4, x, ctx, "normal", opipe.DDIM(**MULTISTEP_SCHED), 4).numpy()
+            out[f"{tag}_blend_fix_3"] = opipe.multi_step_infer(vae_sd, vc, unet4, uc4, x, ctx, "depth", opipe.DDIM(**MULTISTEP_SCHED), 3, fix_timesteps=400).numpy()
+            eps_cfg = dict(MULTISTEP_SCHED, prediction_type="epsilon", clip_sample=True, set_alpha_to_one=True, steps_offset=0, timestep_spacing="trailing")
+            out[f"{tag}_marigold_eps_4"] = opipe.multi_step_infer(vae_sd, vc, unet8, uc8, x, ctx, "depth", opipe.DDIM(**eps_cfg), 4, noise).numpy()
+    np.savez_compressed(os.path.join(HERE, "e2e_multistep.npz"), **out)
+    print("e2e_multistep.npz", os.path.getsize(os.path.join(HERE, "e2e_multistep.npz")) // 1024, "KiB")
+
+
 def make_e2e_tiny():
     uc, vc, dc = osd.UNetCfg.tiny(), osd.VAECfg.tiny(), odpt.DPTCfg.tiny()
     usd = osd.synth_state_dict(osd.unet_manifest(uc), 1)
@@ -388,7 +521,13 @@ def make_e2e_tiny():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dpt", "metrics", "e2e", "batchsize", "infer_eval", "image_util", "datasets"]
+    which = sys.argv[1:] or ["dpt", "metrics", "e2e", "batchsize", "infer_eval", "image_util", "datasets", "scheduler", "ensemble", "multistep"]
+    if "scheduler" in which:
+        make_scheduler_golden()
+    if "ensemble" in which:
+        make_ensemble_golden()
+    if "multistep" in which:
+        make_e2e_multistep()
     if "dpt" in which:
         make_dpt_golden()
     if "dpt" in which or "dpt_odd" in which:

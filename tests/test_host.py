@@ -97,11 +97,20 @@ def test_pipeline_validation_without_gpu():
     class BadSched:
         beta_start, beta_end, prediction_type = 0.00085, 0.012, "v_prediction"
 
+    # any DDIM config is accepted (one step with a beta != 1 scheduler runs the engine's denoising loop); only beta == 1 + v_prediction
+    # without clipping is the closed form x0 = -v
+    assert not GenPerceptPipeline(unet={}, vae={}, scheduler=BadSched())._x0_is_neg_v
+    with pytest.raises(ValueError):
+        GenPerceptPipeline(unet={}, vae={}, genpercept_pipeline=False)  # the multi-step archs need their scheduler
+    multi = GenPerceptPipeline(unet={}, vae={}, scheduler=BadSched(), genpercept_pipeline=False, rgb_blending=True)
+    assert multi.default_denoising_steps == 10 and multi.rgb_blending and not multi.genpercept_pipeline
+    with pytest.raises(AssertionError):  # genpercept_pipeline.py:141-143: a customised head needs the one-step beta == 1 pipeline
+        GenPerceptPipeline(unet={}, vae={}, scheduler=BadSched(), customized_head={"neck.x": torch.zeros(1)}, head_type="identity")
+    class Lcm:
+        _class_name, beta_start, beta_end = "LCMScheduler", 0.00085, 0.012
     with pytest.raises(NotImplementedError):
-        GenPerceptPipeline(unet={}, vae={}, scheduler=BadSched())
-    with pytest.raises(NotImplementedError):
-        GenPerceptPipeline(unet={}, vae={}, genpercept_pipeline=False)
-    pipe = GenPerceptPipeline(unet={}, vae={}, scheduler={"beta_start": 1.0, "beta_end": 1.0, "prediction_type": "v_prediction"},
+        GenPerceptPipeline(unet={}, vae={}, scheduler=Lcm())
+    pipe = GenPerceptPipeline(unet={}, vae={}, scheduler={"beta_start": 1.0, "beta_end": 1.0, "prediction_type": "v_prediction", "clip_sample": False},
                               text_encoder=np.zeros((2, 1024), np.float32), default_denoising_steps=10)
     assert pipe.default_denoising_steps == 1 and pipe.rgb_blending and pipe.latent_scale_factor == 0.18215
     assert pipe.text_embed.shape == (1, 2, 1024) and pipe.dtype == torch.bfloat16
@@ -339,7 +348,7 @@ def test_customized_head_kind_like_the_reference():
     class DPTNeckHeadForUnetAfterUpsampleIdentity(DPTNeckHeadForUnetAfterUpsample):
         pass
 
-    sched = dict(beta_start=1.0, beta_end=1.0, prediction_type="v_prediction")
+    sched = dict(beta_start=1.0, beta_end=1.0, prediction_type="v_prediction", clip_sample=False)
     with pytest.raises(ValueError):
         GenPerceptPipeline(unet={}, vae={}, scheduler=sched, customized_head=DPTNeckHeadForUnetAfterUpsample())
     with pytest.raises(ValueError):
@@ -375,7 +384,7 @@ def test_finetuned_vae_decoder_directories(tmp_path):
         src = tuned if k.startswith(("decoder.", "post_quant_conv.")) else base
         assert torch.equal(sd[k], src[k]), k
     pipe = GenPerceptPipeline.from_pretrained(str(tmp_path / "sd"), unet={}, load_decoder_ckpt=str(tmp_path / "ft"),
-                                              scheduler=dict(beta_start=1.0, beta_end=1.0, prediction_type="v_prediction"))
+                                              scheduler=dict(beta_start=1.0, beta_end=1.0, prediction_type="v_prediction", clip_sample=False))
     assert torch.equal(pipe._vae_src["decoder.conv_in.weight"], tuned["decoder.conv_in.weight"])
     bad = {k: v for k, v in tuned.items() if k.startswith("decoder.") and "conv_out" not in k}
     save_file({k[len("decoder."):]: v for k, v in bad.items()}, str(tmp_path / "ft" / "vae_decoder" / "model.safetensors"))
@@ -397,7 +406,7 @@ def test_encode_text_hf_clip_branch(tmp_path):
     torch.manual_seed(0)
     enc = CLIPTextModel(CLIPTextConfig(vocab_size=8, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
                                        max_position_embeddings=77, bos_token_id=0, eos_token_id=1)).eval()
-    pipe = GenPerceptPipeline(unet={}, vae={}, scheduler=dict(beta_start=1.0, beta_end=1.0, prediction_type="v_prediction"),
+    pipe = GenPerceptPipeline(unet={}, vae={}, scheduler=dict(beta_start=1.0, beta_end=1.0, prediction_type="v_prediction", clip_sample=False),
                               text_encoder=enc, tokenizer=tok)
     assert pipe.text_embed is None
     pipe.encode_text("")

@@ -1,0 +1,173 @@
+"""CPU tests of the multi-step archs' host logic (marigold / rgb_blending): the scheduler against the REFERENCE's
+DDIMSchedulerCustomized (tests/golden/scheduler_ref.npz) and against the oracle's independent restatement of diffusers' step, the
+ensembling against the REFERENCE's ensemble_depth (tests/golden/ensemble_ref.npz), the oracle's loop against its committed goldens."""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from genpercept_amd.ensemble import ensemble_depth
+from genpercept_amd.scheduler import DDIMSchedulerCustomized
+from oracle import pipeline as opipe
+from oracle import sd21 as osd
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _ref_cfgs():
+    g = np.load(os.path.join(GOLD, "scheduler_ref.npz"))
+    return g, [(str(n), json.loads(str(g[str(n) + "/cfg"]))) for n in g["names"]]
+
+
+def test_scheduler_tables_equal_the_reference_class():
+    """betas / alphas_cumprod / final_alpha_cumprod / _get_variance of every hf_configs scheduler (+ scaled_linear_power, zero-SNR rescale):
+    product scheduler and oracle restatement both equal the reference's own class bit for bit (same torch ops on the same build)."""
+    g, cfgs = _ref_cfgs()
+    assert len(cfgs) == 9
+    pairs = g["variance_pairs"]
+    for name, cfg in cfgs:
+        s = DDIMSchedulerCustomized(**cfg)
+        assert np.array_equal(s.betas.numpy(), g[name + "/betas"]), name
+        assert np.array_equal(s.alphas_cumprod.numpy(), g[name + "/alphas_cumprod"]), name
+        assert np.float32(s.final_alpha_cumprod) == g[name + "/final_alpha_cumprod"], name
+        var = np.array([float(s._get_variance(int(t), int(p))) for t, p in pairs])
+        assert np.array_equal(np.isnan(var), np.isnan(g[name + "/variance"])), name
+        ok = ~np.isnan(var)
+        assert np.array_equal(var[ok], g[name + "/variance"][ok]), name
+        if not cfg.get("rescale_betas_zero_snr"):
+            o = opipe.DDIM(**cfg)
+            assert np.array_equal(o.alphas_cumprod.numpy(), g[name + "/alphas_cumprod"]), name
+            assert np.float32(o.final_alpha_cumprod) == g[name + "/final_alpha_cumprod"], name
+            v2 = np.array([float(o.get_variance(int(t), int(p))) for t, p in pairs])
+            assert np.array_equal(v2[ok], g[name + "/variance"][ok]), name
+
+
+def test_scheduler_from_pretrained_and_timesteps(tmp_path):
+    cfg = dict(_class_name="DDIMScheduler", _diffusers_version="0.29.2", beta_end=0.012, beta_schedule="scaled_linear", beta_start=0.00085,
+               clip_sample=False, num_train_timesteps=1000, prediction_type="v_prediction", set_alpha_to_one=False, skip_prk_steps=True,
+               steps_offset=1, timestep_spacing="leading", trained_betas=None)
+    os.makedirs(tmp_path / "ckpt" / "scheduler")
+    (tmp_path / "ckpt" / "scheduler" / "scheduler_config.json").write_text(json.dumps(cfg))
+    s = DDIMSchedulerCustomized.from_pretrained(str(tmp_path / "ckpt"), subfolder="scheduler")
+    assert s.config.beta_end == 0.012 and s.config.steps_offset == 1 and not s.config.clip_sample
+    with pytest.raises(FileNotFoundError):
+        DDIMSchedulerCustomized.from_pretrained(str(tmp_path / "ckpt"))
+    s.set_timesteps(1)
+    assert s.timesteps.tolist() == [1]                                   # the one-step GenPercept case
+    s.set_timesteps(10)
+    assert s.timesteps.tolist() == [901, 801, 701, 601, 501, 401, 301, 201, 101, 1]
+    s.set_timesteps(50)
+    assert s.timesteps[0] == 981 and s.timesteps[-1] == 1 and len(s.timesteps) == 50
+    for sp, first, last in (("trailing", 999, 99), ("linspace", 999, 0)):
+        t = DDIMSchedulerCustomized(**{**{k: v for k, v in cfg.items() if not k.startswith("_") and k != "skip_prk_steps"}, "timestep_spacing": sp})
+        t.set_timesteps(10)
+        assert t.timesteps[0] == first and t.timesteps[-1] == last and len(t.timesteps) == 10
+        o = opipe.DDIM(**{**cfg, "timestep_spacing": sp})
+        assert o.set_timesteps(10).tolist() == t.timesteps.tolist()
+    with pytest.raises(ValueError):
+        s.set_timesteps(1001)
+    with pytest.raises(TypeError):
+        DDIMSchedulerCustomized(beta_start=1.0, not_a_field=3)
+    with pytest.raises(NotImplementedError):
+        DDIMSchedulerCustomized(beta_schedule="sigmoid")
+    plan = s.plan(4, fix_timesteps=400)
+    assert [p["timestep"] for p in plan] == [400.0] * 4                  # genpercept_pipeline.py:405-406
+
+
+@pytest.mark.parametrize("kind,clip,alpha_one", [("v_prediction", False, False), ("epsilon", True, True), ("sample", False, True)])
+def test_scheduler_step_equals_the_oracle_restatement(kind, clip, alpha_one):
+    """The affine form handed to the engine == diffusers' step as the oracle restates it (different grouping of the same fp32 numbers)."""
+    cfg = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=clip, set_alpha_to_one=alpha_one, steps_offset=1,
+               prediction_type=kind)
+    s, o = DDIMSchedulerCustomized(**cfg), opipe.DDIM(**cfg)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 9, 11, generator=g)
+    s.set_timesteps(5)
+    o.set_timesteps(5)
+    xs, xo = x.clone(), x.clone()
+    for t in s.timesteps:
+        m = torch.randn(2, 4, 9, 11, generator=g)
+        out = s.step(m, t, xs)
+        prev_o, x0_o = o.step(m, int(t), xo)
+        assert torch.allclose(out.pred_original_sample, x0_o, rtol=1e-5, atol=2e-5)
+        assert torch.allclose(out.prev_sample, prev_o, rtol=1e-5, atol=2e-5)
+        if clip:
+            assert out.pred_original_sample.abs().max() <= 1.0
+        xs, xo = out.prev_sample, prev_o
+    # beta == 1: x0 = -v at any timestep (the closed form gp_infer uses)
+    b1 = DDIMSchedulerCustomized(beta_start=1.0, beta_end=1.0, beta_schedule="scaled_linear", prediction_type="v_prediction", clip_sample=False,
+                                 set_alpha_to_one=False, steps_offset=1)
+    c = b1.plan(1)[0]
+    assert (c["x0_sample"], c["x0_model"], c["timestep"]) == (0.0, -1.0, 1.0)
+    # eta > 0 uses the reference's customised variance and a generator
+    s.set_timesteps(5)
+    t0 = int(s.timesteps[1])
+    a = s.step(x, t0, x, eta=1.0, generator=torch.Generator().manual_seed(1)).prev_sample
+    b = s.step(x, t0, x, eta=1.0, generator=torch.Generator().manual_seed(1)).prev_sample
+    assert torch.equal(a, b) and not torch.equal(a, s.step(x, t0, x).prev_sample)
+    std = float(s._get_variance(t0, t0 - 200) ** 0.5)
+    assert abs(s.step_coefficients(t0, eta=1.0)["std"] - std) < 1e-7
+
+
+def test_ensemble_depth_equals_the_reference():
+    g = np.load(os.path.join(GOLD, "ensemble_ref.npz"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # scipy's finite differences on the fp32 parameter vector the reference hands it
+        for c in g["cases"]:
+            c = str(c)
+            kw = {"shift_invariant": True, **json.loads(str(g[c + "/kw"]))}
+            pred, unc = ensemble_depth(torch.from_numpy(g[c + "/in"]), scale_invariant=True, max_res=50, **kw)
+            assert pred.shape == (1, 1, 40, 48)
+            assert np.abs(pred.numpy() - g[c + "/pred"]).max() <= 1e-6, c
+            if c + "/unc" in g.files:
+                assert np.abs(unc.numpy() - g[c + "/unc"]).max() <= 1e-6, c
+        # above max_res the alignment runs on a nearest-exact reduction; the result still spans [0,1] and undoes the distortions
+        yy, xx = np.mgrid[0:96, 0:128].astype(np.float32)
+        base = torch.from_numpy(0.5 + 0.4 * np.sin(xx / 17.0) * np.cos(yy / 13.0))
+        d = torch.stack([base * s + t for s, t in ((1.0, 0.0), (1.7, -0.3), (0.6, 0.2), (1.2, 0.1))])[:, None]
+        pred, _ = ensemble_depth(d, max_res=50)
+        ref = (base - base.min()) / (base.max() - base.min())
+        assert pred.min() == 0 and pred.max() == 1 and (pred[0, 0] - ref).abs().max() < 2e-2
+    with pytest.raises(ValueError):
+        ensemble_depth(torch.zeros(3, 2, 4, 4))
+    with pytest.raises(ValueError):
+        ensemble_depth(torch.zeros(3, 1, 4, 4), reduction="mode")
+    with pytest.raises(ValueError):
+        ensemble_depth(torch.zeros(3, 1, 4, 4), scale_invariant=False, shift_invariant=True)
+
+
+def test_replace_unet_conv_in_like_run_py():
+    from genpercept_amd.weights import replace_unet_conv_in
+    w, b = torch.randn(8, 4, 3, 3), torch.randn(8)
+    sd = replace_unet_conv_in({"conv_in.weight": w, "conv_in.bias": b})
+    assert sd["conv_in.weight"].shape == (8, 8, 3, 3) and torch.equal(sd["conv_in.bias"], b)
+    assert torch.equal(sd["conv_in.weight"][:, :4], w * 0.5) and torch.equal(sd["conv_in.weight"][:, 4:], w * 0.5)
+    assert torch.equal(opipe.replace_unet_conv_in({"conv_in.weight": w})["conv_in.weight"], sd["conv_in.weight"])
+
+
+def test_multistep_golden_is_reproducible():
+    """The committed multi-step fixture is what the oracle's loop computes today (one case per arch)."""
+    g = np.load(os.path.join(GOLD, "e2e_multistep.npz"))
+    sched_cfg = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False, steps_offset=1,
+                     prediction_type="v_prediction", timestep_spacing="leading")
+    vc, uc4 = osd.VAECfg.tiny(), osd.UNetCfg.tiny()
+    uc8 = osd.UNetCfg(in_channels=8, block_out_channels=uc4.block_out_channels, num_heads=uc4.num_heads, cross_attention_dim=uc4.cross_attention_dim)
+    vsd = osd.synth_state_dict(osd.vae_manifest(vc), seed=2)
+    u4 = osd.synth_state_dict(osd.unet_manifest(uc4), seed=1)
+    u8 = opipe.replace_unet_conv_in(u4)
+    x = opipe.normalize_rgb(torch.from_numpy(g["sq_rgb"]))
+    ctx = torch.from_numpy(g["ctx"])
+    with torch.no_grad():
+        a = opipe.multi_step_infer(vsd, vc, u8, uc8, x, ctx, "depth", opipe.DDIM(**sched_cfg), 4, torch.from_numpy(g["sq_noise"]))
+        b = opipe.multi_step_infer(vsd, vc, u4, uc4, x, ctx, "depth", opipe.DDIM(**sched_cfg), 4)
+    assert np.abs(a.numpy() - g["sq_marigold_4"]).max() < 1e-4
+    assert np.abs(b.numpy() - g["sq_blend_4"]).max() < 1e-4
+    # one step of rgb_blending with the beta == 1 scheduler is the GenPercept one-step path
+    one = dict(sched_cfg, beta_start=1.0, beta_end=1.0)
+    with torch.no_grad():
+        c = opipe.multi_step_infer(vsd, vc, u4, uc4, x, ctx, "depth", opipe.DDIM(**one), 1)
+        d = opipe.single_infer(vsd, vc, u4, uc4, x, ctx, "depth")
+    assert torch.allclose(c, d, atol=1e-6)

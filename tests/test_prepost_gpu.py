@@ -68,7 +68,7 @@ def test_pipeline_device_prepost_matches_host_path(monkeypatch, metric_log):
     uc, vc = osd.UNetCfg.tiny(), osd.VAECfg.tiny()
     g = torch.Generator().manual_seed(9)
     pipe = GenPerceptPipeline(unet=osd.synth_state_dict(osd.unet_manifest(uc), 1), vae=osd.synth_state_dict(osd.vae_manifest(vc), 2),
-                              scheduler=dict(beta_start=1.0, beta_end=1.0, prediction_type="v_prediction"), text_encoder=torch.randn(2, 64, generator=g), tokenizer=None)
+                              scheduler=dict(beta_start=1.0, beta_end=1.0, prediction_type="v_prediction", clip_sample=False), text_encoder=torch.randn(2, 64, generator=g), tokenizer=None)
     pipe.to("cuda")
     arr = torch.randint(0, 256, (150, 200, 3), generator=g, dtype=torch.uint8).numpy()
     arr[:, :100] = np.linspace(0, 255, 100, dtype=np.uint8)[None, :, None]
