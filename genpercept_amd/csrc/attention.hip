@@ -220,6 +220,344 @@ void launch_flash_attn64(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t*
     else hipLaunchKernelGGL((flash_attn64_kernel<2, 3>), grid, dim3(256), 3 * 16384, s, q, k, vt, out, zero, T, heads, ldq, ldk, Tpad, ldo);
 }
 
+// ---- flash_attn512: the VAE mid-block attention (one head, head_dim 512; genpercept_pipeline.py:500-501,521-522) ----------------------
+// Same dataflow as flash_attn64 (S^T = K Q^T on v_mfma_f32_32x32x16, lane-local online softmax, the probabilities already in
+// B-operand order for O^T += V^T P^T), sized for d = 512:
+//   * one wave = 32 queries: Q^T stays in 128 VGPRs, O^T (512 x 32 fp32) in 256 accumulator registers -> one wave per SIMD, one
+//     256-thread workgroup (128 queries) per CU;
+//   * 32-key tiles: K tile [32 keys][512 d] (1 KiB rows) + V^T tile [512 d][32 keys] (64-byte rows) = 64 KiB per stage, two stages;
+//     64 MFMAs (2048 matrix-pipe cycles) per wave and tile against 64 KiB of ds_read_b128 per wave (1024 LDS cycles per CU);
+//   * the K rows are staged in the order pi(i) = i with bits 2 and 3 swapped, so that the 8 keys a lane's accumulator registers
+//     8j .. 8j+7 belong to are CONSECUTIVE (16 j + 8 hh + 0..7) and its V^T operand is one 16-byte read (flash_attn64 needs two 8-byte
+//     reads; those only reach their rate with >= 4 waves per SIMD);
+//   * LDS slots: K physical slot = slot ^ (row & 15) (64 slots per row, XOR on the low four bits), V^T physical slot =
+//     slot ^ ((row >> 2) & 3) (4 slots per row): both conflict-free for the 32-row fragments (tests/test_lds_layout.py);
+//   * work split: B * ceil(T / 128) query blocks over G = min(blocks, CUs) persistent workgroups.  Whole rounds of G blocks are
+//     written directly; the L = blocks mod G left-over blocks are cut along the KEYS into S = G / L parts, one per workgroup
+//     (unnormalised O^T, running maximum and sum to a workspace), and flash512_combine_kernel merges the parts.  At 768^2, batch 4:
+//     288 blocks on 256 CUs = 1.125 rounds instead of 2.
+constexpr int F5_KBYTES = 32 * 1024;                    // one K tile [32 keys][512 d] or one V^T tile [512 d][32 keys]
+constexpr int F5_QV = 24;                               // Q k-steps (of 32) kept in VGPRs; the rest is parked in LDS
+constexpr int F5_NB = 4;                                // fragments per read-ahead set
+constexpr int F5_LDS = 4 * F5_KBYTES + 4 * (32 - F5_QV) * 1024;
+// max / sum over the two half-waves without going through the LDS crossbar (ds_bpermute): v_permlane32_swap exchanges the upper half of
+// one register with the lower half of another
+typedef __attribute__((address_space(3))) h16x8_t* lds_frag_wptr;
+GP_DEV float other_half(float v) {
+    typedef unsigned u32x2p_t __attribute__((ext_vector_type(2)));
+    const u32x2p_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return (threadIdx.x & 32) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);   // r[0] = [lo, lo], r[1] = [hi, hi]
+}
+GP_DEV int k512_off(int row, int slot) { return row * 1024 + ((slot ^ (row & 15)) << 4); }
+GP_DEV int v512_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+GP_DEV int pi23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }  // swap bits 2 and 3
+
+__global__ __launch_bounds__(256) void flash_attn512_kernel(const h16_t* __restrict__ Q, const h16_t* __restrict__ K,
+                                                             const h16_t* __restrict__ Vt, h16_t* __restrict__ O,
+                                                             const h16_t* __restrict__ zero, float* __restrict__ part_o,
+                                                             float* __restrict__ part_ml, int B, int T, int ldq, int ldk, int Tpad, int ldo,
+                                                             float scale, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int nqb = (T + 127) >> 7, nblocks = B * nqb, G = gridDim.x;
+    const int nt = (T + 31) >> 5;
+    const int rounds = nblocks / G, L = nblocks - rounds * G, S = L ? G / L : 0;
+    const int sid = xcd_remap(blockIdx.x, G);           // consecutive sid = consecutive query blocks of one image on one XCD
+    const unsigned smem_base = (unsigned)(unsigned long long)smem;
+    const float sc = scale * 1.44269504088896340736f;
+    f32x16_t zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+
+    const int items = rounds + ((L && sid / S < L) ? 1 : 0);
+    for (int it = 0; it < items; ++it) {
+        const bool whole = it < rounds;
+        const int blk = whole ? it * G + sid : rounds * G + sid / S;
+        const int part = whole ? 0 : sid % S;
+        const int t0 = whole ? 0 : (int)((long long)nt * part / S), t1 = whole ? nt : (int)((long long)nt * (part + 1) / S);
+        const int b = blk / nqb, qb = blk - b * nqb;
+        const int q0 = qb * 128 + wave * 32;
+        const h16_t* Qb = Q + (long long)b * T * ldq;
+        const h16_t* Kb = K + (long long)b * T * ldk;
+        const h16_t* Vb = Vt + (long long)b * 512 * Tpad;
+
+        // Q fragments (B operand of S^T = K Q^T): lane (q = l31, half hh) holds Q[q][16 ks + 8 hh .. +7].  k-steps 0 .. F5_QV-1 stay in
+        // VGPRs, the rest (32 KiB for the workgroup: what is left of the LDS) is parked in LDS, lane-major, and read back per tile
+        __syncthreads();                                  // the previous item's last tile and Q rows have been read by every wave
+        h16x8_t qf[F5_QV];
+        const unsigned q_lds = smem_base + 4 * F5_KBYTES + wave * ((32 - F5_QV) * 1024) + lane * 16;
+        {
+            const int q = q0 + l31;
+            const bool ok = q < T;
+#pragma unroll
+            for (int ks = 0; ks < 32; ++ks) {
+                h16x8_t v = h16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) v = *(const h16x8_t*)(Qb + (long long)q * ldq + ks * 16 + hh * 8);
+                if ((ks & 3) != 3) qf[3 * (ks >> 2) + (ks & 3)] = v;   // every fourth k-step is parked in LDS
+                else *(lds_frag_wptr)(q_lds + (ks >> 2) * 1024) = v;
+            }
+            // the loads have landed HERE (they return in order): otherwise hipcc waits for them, with vmcnt(0), at their first use inside
+            // the tile loop, i.e. behind the LDS-DMA of the next tile that was just issued
+            asm volatile("" ::"v"(qf[F5_QV - 1]));
+        }
+        // DMA sources: a uniform row pointer + a per-lane offset that is the same for every tile.  The offsets live in registers of their
+        // own (made opaque so that they are not recomputed into one temporary): hipcc orders a write to the ADDRESS register of an LDS-DMA
+        // still in flight behind it with vmcnt(0), which would serialise the sixteen loads of a stage.
+        // (unsigned BYTE offsets: uniform base + zero-extended 32-bit lane offset is the saddr + voffset form of global_load_lds)
+        unsigned koff[8];  // K: my LDS slot `lane` of row i = 8 wave + n holds logical slot lane ^ (i & 15)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            koff[n] = (unsigned)(lane ^ ((wave & 1) * 8 + n)) << 4;
+            asm volatile("" : "+v"(koff[n]));
+        }
+        unsigned v_lane_off = ((unsigned)(lane >> 2) * Tpad + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2;  // V^T: row 16 n + lane / 4, logical slot of my LDS slot
+        asm volatile("" : "+v"(v_lane_off));
+        // LDS: K slots at 0 / 32 KiB, V^T slots at 64 / 96 KiB (tile t in slot (t - t0) & 1 of each), parked Q fragments at 128 KiB
+        auto stage = [&](int slot, int kt) __attribute__((always_inline)) {
+            char* sb = smem + slot * F5_KBYTES;
+            if (!(dbg & 1))
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {  // K: LDS row i <- key kt * 32 + pi(i); one 1 KiB row per instruction
+                const int i = wave * 8 + n;
+                const int key = min(kt * 32 + pi23(i), T - 1);  // rows past T repeat the last one: their scores are masked (MASK)
+                const char* rowp = (const char*)(Kb + (long long)key * ldk);
+                // uniform base in SGPRs + zero-extended 32-bit lane offset, both opaque HERE so that the sum is formed in this block and
+                // selected as the saddr + voffset form: a per-lane 64-bit address would sit in a temporary that the fragment reads recycle,
+                // and hipcc orders a write to the address register of an LDS-DMA in flight behind the DMA with vmcnt(0)
+                asm volatile("" : "+s"(rowp), "+v"(koff[n]));
+                glds16(rowp + koff[n], sb + i * 1024);
+            }
+            const h16_t* vtile = Vb + (long long)(128 * wave) * Tpad + kt * 32;   // my 8 x 16 channels of this tile
+            asm volatile("" : "+s"(vtile), "+v"(v_lane_off));   // (opaque: as for the K rows)
+            if (!(dbg & 2))
+#pragma unroll
+            for (int m = 0; m < 8; ++m)      // V^T: 16 rows (channels) of 64 bytes per instruction
+                glds16((const char*)(vtile + (unsigned)(16 * m * Tpad)) + v_lane_off, sb + 2 * F5_KBYTES + (wave * 8 + m) * 1024);
+        };
+
+        f32x16_t o_acc[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) o_acc[d] = zero16;
+        float m_run = -1e30f, l_run = 0.f, alpha = 1.f;
+        // fragment addresses inside a slot: K slot (2 ks + hh) ^ (row & 15) = (hh ^ (row & 15)) ^ 2 (ks & 7), plus 256 bytes per 8 k-steps
+        const unsigned ka0 = l31 * 1024 + ((hh ^ (l31 & 15)) << 4);
+        unsigned va[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) va[j] = 2 * F5_KBYTES + l31 * 64 + (((2 * j + hh) ^ ((l31 >> 2) & 3)) << 4);
+
+        // hipcc waits for LDS reads with lgkmcnt(0) only while LDS-DMA is in flight (it treats the DMA as a FLAT access), so fragments are
+        // read in sets of F5_NB, one whole set (F5_NB MFMAs = 32 F5_NB cycles) ahead of their use.
+        // The accumulators (256 registers: the whole AGPR half of the file) must only ever be MFMA operands in the hot loop, so the
+        // online-softmax rescale is (a) lazy -- the reference maximum m_run only moves when some query's tile maximum exceeds it by more
+        // than 8 in log2 units; until then probabilities may reach 2^8, exact in the quotient sum(p v) / sum(p) and harmless in fp32 /
+        // 16-bit P -- and (b) done outside the hot loop: the loop breaks before the tile's P.V, the cold path rescales and finishes the tile.
+        h16x8_t pf[2];
+        // ---- S^T = K Q^T over d = 512: 32 k-steps alternating between two accumulators (a single chain would wait for its own result)
+        auto s_phase = [&](unsigned sb, int kt, auto maskc) __attribute__((always_inline)) -> bool {
+            constexpr bool MASK = decltype(maskc)::value != 0;
+            f32x16_t s0 = zero16, s1 = zero16;
+            h16x8_t fr[2][F5_NB], ql[2];
+            static_assert(F5_NB == 4 && F5_QV == 24, "one parked Q k-step per set of four");
+            auto load = [&](int set, int bb) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < F5_NB; ++i) {
+                    const int ks = F5_NB * bb + i;
+                    fr[set][i] = lds_frag(sb + (ka0 ^ ((ks & 7) << 5)), (ks >> 3) * 256);
+                    if ((ks & 3) == 3) ql[set] = lds_frag(q_lds, (ks >> 2) * 1024);
+                }
+            };
+            load(0, 0);
+#pragma unroll
+            for (int bb = 0; bb < 32 / F5_NB; ++bb) {
+                if (bb + 1 < 32 / F5_NB) load((bb + 1) & 1, bb + 1);
+#pragma unroll
+                for (int i = 0; i < F5_NB; ++i) {
+                    const int ks = F5_NB * bb + i;
+                    const h16x8_t qv = (ks & 3) != 3 ? qf[3 * (ks >> 2) + ((ks & 3) != 3 ? (ks & 3) : 0)] : ql[bb & 1];
+                    if (ks & 1) s1 = mfma_32x32x16(fr[bb & 1][i], qv, s1);
+                    else s0 = mfma_32x32x16(fr[bb & 1][i], qv, s0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            f32x16_t s_acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_acc[r] = s0[r] + s1[r];
+            // register r <-> LDS row (r & 3) + 4 hh + 8 (r >> 2) <-> key kt * 32 + 8 hh + (r & 7) + 16 (r >> 3)
+            if (MASK) {
+                const int kbase = kt * 32 + 8 * hh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + (r & 7) + 16 * (r >> 3) >= T) s_acc[r] = -1e30f;
+            }
+            float mx = s_acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_acc[r]);
+            mx = fmaxf(mx, other_half(mx));
+            const bool moved = __builtin_amdgcn_ballot_w64((mx - m_run) * sc > 8.f) != 0ull;  // uniform
+            if (moved) {
+                const float m_new = fmaxf(m_run, mx);
+                alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+                m_run = m_new;
+                l_run *= alpha;
+            }
+            const float nm = -m_run * sc;
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s_acc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[r], sc, nm));
+                rs += s_acc[r];
+            }
+            l_run += rs;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                union { h16x8_t v; unsigned u[4]; } t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t.u[e] = pack_h16x2_ns(s_acc[8 * j + 2 * e], s_acc[8 * j + 2 * e + 1]);
+                pf[j] = t.v;
+            }
+            return moved;
+        };
+        // ---- O^T += V^T P^T: two k-steps of 16 keys x 16 channel blocks of 32 (step = 16 j + block)
+        auto pv_phase = [&](unsigned sb) __attribute__((always_inline)) {
+            h16x8_t fr[2][F5_NB];
+            auto load = [&](int set, int bb) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < F5_NB; ++i) {
+                    const int st = F5_NB * bb + i;
+                    fr[set][i] = lds_frag(sb + va[st >> 4], (st & 15) * 2048);
+                }
+            };
+            load(0, 0);
+#pragma unroll
+            for (int bb = 0; bb < 32 / F5_NB; ++bb) {
+                if (bb + 1 < 32 / F5_NB) load((bb + 1) & 1, bb + 1);
+#pragma unroll
+                for (int i = 0; i < F5_NB; ++i) {
+                    const int st = F5_NB * bb + i;
+                    o_acc[st & 15] = mfma_32x32x16(fr[bb & 1][i], pf[st >> 4], o_acc[st & 15]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
+        if (t0 < t1) stage(0, t0);
+        __builtin_amdgcn_s_waitcnt(0x0070);              // (compiler-visible: see the end of the cold path)
+        int kt = t0;
+        for (;;) {
+            bool pending = false;
+            unsigned sb = 0;
+            for (; kt < t1; ++kt) {                       // hot loop
+                const int rel = (kt - t0) & 1;
+                sb = smem_base + rel * F5_KBYTES;
+                wait_vm<0>();
+                __builtin_amdgcn_s_barrier();
+                if (kt + 1 < t1) stage(rel ^ 1, kt + 1);
+                const bool moved = (kt * 32 + 32 > T) ? s_phase(sb, kt, IC<1>{}) : s_phase(sb, kt, IC<0>{});
+                if (moved) { pending = true; break; }
+                pv_phase(sb);
+            }
+            if (!pending) break;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {                // one 16-register block at a time through the VGPRs (no reordering across blocks:
+#pragma unroll                                            // all 256 at once would spill the Q fragments)
+                for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            pv_phase(sb);
+            ++kt;
+            // a wait the COMPILER sees (its own bookkeeping ignores the asm waits): whatever this cold path reloaded from scratch is
+            // complete here, so that the hot loop's first MFMA is not made to wait, with vmcnt(0), behind the DMA it has just issued
+            __builtin_amdgcn_s_waitcnt(0x0070);
+        }
+        l_run += other_half(l_run);
+        const int q = q0 + l31;
+        if (whole) {
+            // ---- normalise and store O[q][d] (this lane: q = l31, d = 32 blk + 8 (r >> 2) + 4 hh + (r & 3))
+            const float inv = 1.f / l_run;
+            if (q < T) {
+                h16_t* ob = O + ((long long)b * T + q) * ldo;
+#pragma unroll
+                for (int d = 0; d < 16; ++d)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint2 pk = pack_h16x4(o_acc[d][4 * g] * inv, o_acc[d][4 * g + 1] * inv, o_acc[d][4 * g + 2] * inv, o_acc[d][4 * g + 3] * inv);
+                        *(uint2*)(ob + d * 32 + 8 * g + 4 * hh) = pk;
+                    }
+            }
+        } else {
+            // ---- one part of a left-over block: unnormalised accumulators + (maximum, sum) per query
+            const long long slot = (long long)(sid / S) * S + part;
+            float* po = part_o + (slot * 128 + wave * 32 + l31) * 512;
+#pragma unroll
+            for (int d = 0; d < 16; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(float4*)(po + d * 32 + 8 * g + 4 * hh) = float4{o_acc[d][4 * g], o_acc[d][4 * g + 1], o_acc[d][4 * g + 2], o_acc[d][4 * g + 3]};
+            if (hh == 0) {
+                float* pm = part_ml + (slot * 128 + wave * 32 + l31) * 2;
+                pm[0] = m_run;
+                pm[1] = l_run;
+            }
+        }
+    }
+}
+
+// merge the S key-parts of each left-over query block: out = sum_p w_p O_p / sum_p w_p l_p, w_p = 2^((m_p - max m) sc)
+__global__ __launch_bounds__(256) void flash512_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                                h16_t* __restrict__ O, int T, int nqb, int first_blk, int S, int ldo, float scale) {
+    const int lb = blockIdx.x >> 2, qq = (blockIdx.x & 3) * 32 + (threadIdx.x >> 3);   // 32 queries per workgroup, 8 threads per query
+    const int blk = first_blk + lb, b = blk / nqb, q = (blk - b * nqb) * 128 + qq;
+    if (q >= T) return;
+    const float sc = scale * 1.44269504088896340736f;
+    float m = -1e30f;
+    for (int p = 0; p < S; ++p) m = fmaxf(m, part_ml[(((long long)lb * S + p) * 128 + qq) * 2]);
+    float l = 0.f;
+    float acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+    const int c0 = (threadIdx.x & 7) * 4;               // this thread: channels c0 + 32 i .. + 3, i = 0..15
+    for (int p = 0; p < S; ++p) {
+        const long long row = ((long long)lb * S + p) * 128 + qq;
+        const float w = __builtin_amdgcn_exp2f((part_ml[row * 2] - m) * sc);
+        l += w * part_ml[row * 2 + 1];
+        const float* po = part_o + row * 512 + c0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 v = *(const float4*)(po + 32 * i);
+            acc[4 * i] += w * v.x; acc[4 * i + 1] += w * v.y; acc[4 * i + 2] += w * v.z; acc[4 * i + 3] += w * v.w;
+        }
+    }
+    const float inv = 1.f / l;
+    h16_t* ob = O + ((long long)b * T + q) * ldo + c0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        *(uint2*)(ob + 32 * i) = pack_h16x4(acc[4 * i] * inv, acc[4 * i + 1] * inv, acc[4 * i + 2] * inv, acc[4 * i + 3] * inv);
+}
+
+bool flash_attn512_supported(int C) { return C == 512 && getenv("GENPERCEPT_NO_FLASH512") == nullptr; }
+// floats of workspace the launch needs (0: the blocks divide evenly over the workgroups)
+long long flash_attn512_workspace_floats(int B, int T, int ncu) {
+    const int nblocks = B * ((T + 127) / 128), G = nblocks < ncu ? nblocks : ncu;
+    const int L = nblocks % G;
+    return L ? (long long)(G / L) * L * 128 * (512 + 2) : 0;
+}
+void launch_flash_attn512(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t* out, const h16_t* zero, float* ws, int B, int T, int ldq,
+                          int ldk, int Tpad, int ldo, float scale, int ncu, hipStream_t s) {
+    static unsigned long long attr_mask = 0;
+    if (gp_first_use_on_device(&attr_mask))
+        (void)hipFuncSetAttribute((const void*)flash_attn512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F5_LDS);
+    const int nqb = (T + 127) / 128, nblocks = B * nqb, G = nblocks < ncu ? nblocks : ncu;
+    const int rounds = nblocks / G, L = nblocks - rounds * G, S = L ? G / L : 0;
+    float* part_o = ws;
+    float* part_ml = ws ? ws + (long long)S * L * 128 * 512 : nullptr;
+    static const int dbg = getenv("GENPERCEPT_F5_DBG") ? atoi(getenv("GENPERCEPT_F5_DBG")) : 0;  // timing ablations only: 1 no K DMA, 2 no V DMA
+    hipLaunchKernelGGL(flash_attn512_kernel, dim3(G), dim3(256), F5_LDS, s, q, k, vt, out, zero, part_o, part_ml, B, T, ldq, ldk, Tpad,
+                       ldo, scale, dbg);
+    if (L) hipLaunchKernelGGL(flash512_combine_kernel, dim3(L * 4), dim3(256), 0, s, part_o, part_ml, out, T, nqb, rounds * G, S, ldo, scale);
+}
+
 // ---- cross-attention with a tiny constant context -------------------------------------------------------------------
 // One thread per (row, head): q (64 bf16) against L keys/values held in fp32 (folded at load time).
 __global__ __launch_bounds__(256) void cross_attn_small_kernel(const h16_t* __restrict__ q, const float* __restrict__ kc,

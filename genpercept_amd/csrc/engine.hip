@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <thread>
 #include <mutex>
 #include <memory>
 #include <stdexcept>
@@ -194,6 +195,7 @@ struct gp_engine {
     std::vector<float> ctx;                          // [L][D]
     int ctx_L = 0, ctx_D = 0;
     float timestep = 1.f;
+    int ncu = 256;                        // compute units of the device (persistent launches size their grids by it)
     float* temb_arena = nullptr;          // conv1 biases of all UNet resnets at the current timestep
     size_t temb_total = 0;
     std::map<float, float*> temb_cache;   // timestep -> device copy of the arena's contents
@@ -386,17 +388,25 @@ struct gp_engine {
             emb[o] = a / (1.0 + std::exp(-a));  // SiLU(emb), the input of every time_emb_proj
         }
         std::vector<float> all(temb_total);
-        for (auto& kv : resnets) {
-            const ResW& r = kv.second;
-            if (!r.has_temb) continue;
-            const int co = r.c1.cout;
-            for (int o = 0; o < co; ++o) {
-                double a = (double)r.c1_bias_h[o] + r.tb_h[o];
-                const float* wrow = &r.tw_h[(size_t)o * te];
-                for (int i = 0; i < te; ++i) a += (double)wrow[i] * emb[i];
-                all[r.temb_off + o] = (float)a;
-            }
-        }
+        std::vector<const ResW*> rs;
+        for (auto& kv : resnets)
+            if (kv.second.has_temb) rs.push_back(&kv.second);
+        // 26 M multiply-adds in double: spread over a few host threads (a 50-step schedule folds 50 timesteps on its first image)
+        const unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool_thr;
+        for (unsigned w = 0; w < nthr; ++w)
+            pool_thr.emplace_back([&, w] {
+                for (size_t k = w; k < rs.size(); k += nthr) {
+                    const ResW& r = *rs[k];
+                    for (int o = 0; o < r.c1.cout; ++o) {
+                        double a = (double)r.c1_bias_h[o] + r.tb_h[o];
+                        const float* wrow = &r.tw_h[(size_t)o * te];
+                        for (int i = 0; i < te; ++i) a += (double)wrow[i] * emb[i];
+                        all[r.temb_off + o] = (float)a;
+                    }
+                }
+            });
+        for (auto& t : pool_thr) t.join();
         float* d = nullptr;
         HIPCHK(hipMalloc((void**)&d, temb_total * sizeof(float)));
         weights_dev.push_back(d);
@@ -846,15 +856,10 @@ struct gp_engine {
         return y;
     }
 
-    Act vae_attention(const Act& x, const std::string& name) {
-        const VaeAttnW& a = vattn.at(name);
-        const int T = x.H * x.W, C = a.C, Tpad = round_up(T, 64), B = x.B;
-        Act n = groupnorm(x, a.gn, cfg.vae_norm_eps, false);
-        Act qk = linear(n, a.qk);  // [B*T][2C]
-        h16_t* vt = v_transposed(n, a.v, T, Tpad);
-        drop(n);
+    // GEMM -> scores in HBM -> row softmax -> GEMM (head dims other than 512, and the A/B switch GENPERCEPT_NO_FLASH512)
+    void vae_attention_unfused(const Act& qk, const h16_t* vt, Act& o, int B, int T, int Tpad, int C) {
         // logits as fp16 (11 significant bits: finer than the bf16 probabilities they turn into) halve the score traffic, the largest HBM
-        // item of the VAE.  They are the SCALED logits (1/sqrt(C) is folded into the query projection, build_vae_attn) and the fp16
+        // item of this path.  They are the SCALED logits (1/sqrt(C) is folded into the query projection, build_vae_attn) and the fp16
         // conversion saturates at +-65504 (epilogue.h), so an outlier row degrades to a one-hot softmax instead of inf - inf = NaN.
         // GENPERCEPT_FP32_SCORES=1 keeps fp32 (A/B)
         static const bool f32_scores = getenv("GENPERCEPT_FP32_SCORES") != nullptr;
@@ -868,13 +873,11 @@ struct gp_engine {
             p.batch = B; p.in_bs = (long long)T * 2 * C; p.wt_bs = (long long)T * 2 * C; p.out_bs = (long long)T * Tpad;
             run_igemm(p);
         }
-        drop(qk);
         h16_t* P = (h16_t*)pool.alloc((size_t)B * T * Tpad * sizeof(h16_t));
         mark("softmax_rows T=" + std::to_string(T));
         if (half_scores) launch_softmax_rows_f16(S, P, B * T, T, Tpad, 1.0f, st);
         else launch_softmax_rows(S, P, B * T, T, Tpad, 1.0f, st);
         pool.release(S);
-        Act o = new_act(x.B, x.H, x.W, C);
         {
             IGemmParams p{};
             p.in = P; p.wt = vt; p.out = o.p; p.zero = zero;
@@ -884,7 +887,36 @@ struct gp_engine {
             run_igemm(p);
         }
         pool.release(P);
-        pool.release(vt);
+    }
+
+    Act vae_attention(const Act& x, const std::string& name) {
+        const VaeAttnW& a = vattn.at(name);
+        const int T = x.H * x.W, C = a.C, Tpad = round_up(T, 64), B = x.B;
+        Act n = groupnorm(x, a.gn, cfg.vae_norm_eps, false);
+        Act qk = linear(n, a.qk);  // [B*T][2C]
+        h16_t* vt = v_transposed(n, a.v, T, Tpad);
+        drop(n);
+        Act o = new_act(x.B, x.H, x.W, C);
+        if (flash_attn512_supported(C)) {
+            // fused: scores and probabilities never leave the CU (attention.hip: flash_attn512_kernel).  The softmax scale 1/sqrt(C) is
+            // folded into the query projection (build_vae_attn), logits exist in fp32 registers only.
+            const long long wsf = flash_attn512_workspace_floats(B, T, ncu);
+            float* ws = wsf ? (float*)pool.alloc((size_t)wsf * sizeof(float)) : nullptr;
+            const double fl = 4.0 * B * (double)T * T * C;
+            tm.flops_attn += fl;
+            tm.n_attn++;
+            mark("flash_attn512 T=" + std::to_string(T), fl);
+            prof_begin(1);
+            launch_flash_attn512(qk.p, qk.p + C, vt, o.p, zero, ws, B, T, 2 * C, 2 * C, Tpad, C, 1.0f, ncu, st);
+            prof_end();
+            if (ws) pool.release(ws);
+            drop(qk);
+            pool.release(vt);
+        } else {
+            vae_attention_unfused(qk, vt, o, B, T, Tpad, C);
+            drop(qk);
+            pool.release(vt);
+        }
         Act y = linear(o, a.o, x.p, GP_ACT_NONE, nullptr, true);
         drop(o);
         return y;
@@ -1335,6 +1367,9 @@ gp_status gp_create(const gp_config* cfg, gp_engine** out) {
         HIPCHK(hipGetDeviceCount(&n));
         if (cfg->device < 0 || cfg->device >= n) throw std::invalid_argument("no such HIP device");
         HIPCHK(hipSetDevice(cfg->device));
+        hipDeviceProp_t pr;
+        HIPCHK(hipGetDeviceProperties(&pr, cfg->device));
+        if (pr.multiProcessorCount > 0) e->ncu = pr.multiProcessorCount;
         for (int i = 0; i < 4; ++i) {
             if (cfg->unet_block_out[i] % 64 || cfg->vae_block_out[i] % 64) throw std::invalid_argument("block_out_channels must be multiples of 64");
             if (cfg->unet_down_attn[i] && cfg->unet_block_out[i] != 64 * cfg->unet_num_heads[i]) throw std::invalid_argument("attention head_dim must be 64");
@@ -1790,6 +1825,27 @@ gp_status gp_flash_attention(const void* q, const void* k, const void* vt, void*
         std::lock_guard<std::mutex> lk(g_scratch_mu);
         launch_flash_attn64((const h16_t*)q, (const h16_t*)k, (const h16_t*)vt, (h16_t*)out, zero_page(), B, T, heads, ldq, ldk, Tpad, ldo,
                             (hipStream_t)stream);
+        HIPCHK(hipGetLastError());
+        return GP_OK;
+    } catch (...) { return GP_ERR_HIP; }
+}
+
+gp_status gp_flash_attention_hd512(const void* q, const void* k, const void* vt, void* out, int B, int T, int ldq, int ldk, int Tpad, int ldo,
+                                   float scale, int ncu, void* stream) {
+    if (!q || !k || !vt || !out || (Tpad % 64) || Tpad < T || B < 1 || T < 1 || ncu < 0) return GP_ERR_INVALID;
+    try {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (ncu == 0) {
+            int dev = 0;
+            hipDeviceProp_t pr;
+            HIPCHK(hipGetDevice(&dev));
+            HIPCHK(hipGetDeviceProperties(&pr, dev));
+            ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+        }
+        const long long wsf = flash_attn512_workspace_floats(B, T, ncu);
+        float* ws = wsf ? scratch_floats(2, (size_t)wsf) : nullptr;
+        launch_flash_attn512((const h16_t*)q, (const h16_t*)k, (const h16_t*)vt, (h16_t*)out, zero_page(), ws, B, T, ldq, ldk, Tpad, ldo, scale,
+                             ncu, (hipStream_t)stream);
         HIPCHK(hipGetLastError());
         return GP_OK;
     } catch (...) { return GP_ERR_HIP; }

@@ -113,6 +113,7 @@ SYMBOLS = {
     "gp_groupnorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "gp_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "gp_flash_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "gp_flash_attention_hd512": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "gp_cross_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "gp_resize_max_res_size": (None, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "gp_preprocess": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
@@ -490,6 +491,19 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     if st != GP_OK:
         raise RuntimeError(f"gp_layernorm failed ({st})")
     return y
+
+
+def flash_attention_hd512(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, scale: float, ncu: int = 0) -> torch.Tensor:
+    """q, k: [B,T,512] (row stride may exceed 512); vt: [B,512,Tpad], zero beyond T.  softmax(scale q k^T) v, one head."""
+    lib = load_library()
+    b, t, c = q.shape
+    assert c == 512 and vt.shape[1] == 512
+    out = torch.empty((b, t, c), dtype=act_dtype(), device=q.device)
+    st = lib.gp_flash_attention_hd512(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), b, t, q.stride(1), k.stride(1), vt.shape[2], c,
+                                      float(scale), int(ncu), _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_flash_attention_hd512 failed ({st})")
+    return out
 
 
 def flash_attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int) -> torch.Tensor:

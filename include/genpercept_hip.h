@@ -187,6 +187,12 @@ gp_status gp_groupnorm(const void* x, void* y, const float* gamma, const float* 
 gp_status gp_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C, float eps, void* stream);
 gp_status gp_flash_attention(const void* q, const void* k, const void* vt, void* out, int B, int T, int heads, int ldq, int ldk, int Tpad, int ldo,
                              void* stream);
+/* The VAE mid-block attention's core (one head, head_dim 512; diffusers Attention inside AutoencoderKL, call sites
+ * genpercept_pipeline.py:500-501,521-522), fused: softmax(scale * q k^T) v with scores and probabilities kept on the CU.  q, k: [B][T][ld]
+ * (512 channels), vt: [B][512][Tpad] zero beyond T, out [B][T][ldo].  ncu: persistent workgroups to size the launch for (0 = the device's CU
+ * count; the parity tests pass small values to exercise the key-split of the left-over query blocks). */
+gp_status gp_flash_attention_hd512(const void* q, const void* k, const void* vt, void* out, int B, int T, int ldq, int ldk, int Tpad, int ldo,
+                                   float scale, int ncu, void* stream);
 gp_status gp_cross_attention(const void* q, const float* kc, const float* vc, void* out, int rows, int C, int L, void* stream);
 /* BasicTransformerBlock.attn2 (+ norm2, + residual, + norm3 of the result) for a TWO-token context, folded into per-head vectors
  * (gp_set_context does the fold for the engine; csrc/norm.hip states the algebra): y_out = y + c0 + sum_h sigmoid(LNhat(y) . U[h] + u0[h]) G[h],

@@ -7,6 +7,8 @@ so a kernel edit that changes a swizzle has to come back through this model.
   * 18-wide conv halo: key = hx & 7; 10-wide halo of the x2-upsample conv: nibble table 0x4016642254              conv_halo.hip halo_key
   * weight tiles read as rows {8 (a >> 2) + 4 h + (a & 3)}: key = b1 | b3 << 1 | b4 << 2 of the row               igemm / conv_halo / pgemm
   * attention K / V^T tiles read as 32 consecutive rows by the 32x32x16 MFMA: key = (row >> 1) & 7                attention.hip attn_off128
+  * head_dim-512 attention: K tile rows of 1 KiB (64 slots), key = row & 15 on the low four slot bits; V^T tile rows of 64 bytes
+    (4 slots), key = (row >> 2) & 3                                                                              attention.hip k512_off / v512_off
 """
 import os
 import re
@@ -40,6 +42,8 @@ def test_sources_still_use_these_swizzles():
     assert "return slot ^ (row & 7);" in src("common.h")
     assert "0x4016642254ull" in src("conv_halo.hip") and "(hx & 7)" in src("conv_halo.hip")
     assert "((slot ^ ((row >> 1) & 7)) << 4)" in src("attention.hip")
+    assert "return row * 1024 + ((slot ^ (row & 15)) << 4);" in src("attention.hip")
+    assert "return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);" in src("attention.hip")
     for f in ("igemm.hip", "conv_halo.hip", "pgemm.hip"):
         assert re.search(r"\(\(a15 >> 1\) & 1\) \| \(\(\(a15 >> 2\) & 1\) << 1\) \| \(\(\(a15 >> 3\) & 1\) << 2\)", src(f)), f
 
@@ -102,3 +106,23 @@ def test_attention_tile_swizzle_is_conflict_free_for_32_row_fragments():
             assert conflicts(lambda l: (r0 + (l & 31)) * 8 + ((2 * ks + (l >> 5)) ^ (((r0 + (l & 31)) >> 1) & 7))) == 0
     # row & 7 (the conv tiles' key) is NOT conflict-free for this pattern
     assert sum(conflicts(lambda l: (l & 31) * 8 + ((2 * ks + (l >> 5)) ^ ((l & 31) & 7))) for ks in range(4)) > 0
+
+
+def test_hd512_attention_tiles_are_conflict_free():
+    # K tile [32 keys][512 d]: 64 slots of 16 bytes per row; lane (row = lane & 31, hh) reads slot 2 ks + hh, ks = 0..31
+    for ks in range(32):
+        assert conflicts(lambda l: (l & 31) * 64 + ((2 * ks + (l >> 5)) ^ ((l & 31) & 15))) == 0, ks
+    # without the swizzle every row of a lane group lands on the same 16-byte bank column
+    assert conflicts(lambda l: (l & 31) * 64 + (l >> 5)) > 0
+    # V^T tile [512 d][32 keys]: 4 slots per row; lane (row = 32 blk + lane & 31, hh) reads slot 2 j + hh
+    for blk in range(16):
+        for j in range(2):
+            assert conflicts(lambda l: (32 * blk + (l & 31)) * 4 + ((2 * j + (l >> 5)) ^ (((32 * blk + (l & 31)) >> 2) & 3))) == 0, (blk, j)
+    assert conflicts(lambda l: (l & 31) * 4 + (l >> 5)) > 0
+    # the key order of the staged K rows: LDS row i holds key pi(i) = i with bits 2 and 3 swapped, so accumulator register r of half hh
+    # (LDS row (r & 3) + 4 hh + 8 (r >> 2)) belongs to key 8 hh + (r & 7) + 16 (r >> 3): 8 consecutive keys per 16-key k-step and half
+    pi = lambda i: (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1)  # noqa: E731
+    assert sorted(pi(i) for i in range(32)) == list(range(32))
+    for hh in (0, 1):
+        for r in range(16):
+            assert pi((r & 3) + 4 * hh + 8 * (r >> 2)) == 8 * hh + (r & 7) + 16 * (r >> 3)
