@@ -238,7 +238,7 @@ void launch_flash_attn64(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t*
 //     288 blocks on 256 CUs = 1.125 rounds instead of 2.
 constexpr int F5_KBYTES = 32 * 1024;                    // one K tile [32 keys][512 d] or one V^T tile [512 d][32 keys]
 constexpr int F5_QV = 24;                               // Q k-steps (of 32) kept in VGPRs; the rest is parked in LDS
-constexpr int F5_NB = 4;                                // fragments per read-ahead set
+constexpr int F5_RD = 6;                                // fragment reads in flight ahead of their MFMA
 constexpr int F5_LDS = 4 * F5_KBYTES + 4 * (32 - F5_QV) * 1024;
 // max / sum over the two half-waves without going through the LDS crossbar (ds_bpermute): v_permlane32_swap exchanges the upper half of
 // one register with the lower half of another
@@ -302,39 +302,29 @@ __global__ __launch_bounds__(256) void flash_attn512_kernel(const h16_t* __restr
             // the tile loop, i.e. behind the LDS-DMA of the next tile that was just issued
             asm volatile("" ::"v"(qf[F5_QV - 1]));
         }
-        // DMA sources: a uniform row pointer + a per-lane offset that is the same for every tile.  The offsets live in registers of their
-        // own (made opaque so that they are not recomputed into one temporary): hipcc orders a write to the ADDRESS register of an LDS-DMA
-        // still in flight behind it with vmcnt(0), which would serialise the sixteen loads of a stage.
-        // (unsigned BYTE offsets: uniform base + zero-extended 32-bit lane offset is the saddr + voffset form of global_load_lds)
+        // DMA sources: one buffer resource per operand (base of this image), a per-lane byte offset that is the same for every tile and a
+        // uniform byte offset per instruction
+        const buf_rsrc_t k_rs = make_rsrc(Kb, (unsigned)((long long)T * ldk * 2));
+        const buf_rsrc_t v_rs = make_rsrc(Vb, (unsigned)(512ll * Tpad * 2));
         unsigned koff[8];  // K: my LDS slot `lane` of row i = 8 wave + n holds logical slot lane ^ (i & 15)
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            koff[n] = (unsigned)(lane ^ ((wave & 1) * 8 + n)) << 4;
-            asm volatile("" : "+v"(koff[n]));
-        }
-        unsigned v_lane_off = ((unsigned)(lane >> 2) * Tpad + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2;  // V^T: row 16 n + lane / 4, logical slot of my LDS slot
-        asm volatile("" : "+v"(v_lane_off));
+        for (int n = 0; n < 8; ++n) koff[n] = (unsigned)(lane ^ ((wave & 1) * 8 + n)) << 4;
+        const unsigned v_lane_off = ((unsigned)(lane >> 2) * Tpad + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2;  // V^T: row 16 n + lane / 4, logical slot of my LDS slot
         // LDS: K slots at 0 / 32 KiB, V^T slots at 64 / 96 KiB (tile t in slot (t - t0) & 1 of each), parked Q fragments at 128 KiB
-        auto stage = [&](int slot, int kt) __attribute__((always_inline)) {
+        auto stage_piece = [&](int slot, int kt, int pc) __attribute__((always_inline)) {   // piece 0..7: a K row, 8..15: 16 V^T rows
             char* sb = smem + slot * F5_KBYTES;
-            if (!(dbg & 1))
-#pragma unroll
-            for (int n = 0; n < 8; ++n) {  // K: LDS row i <- key kt * 32 + pi(i); one 1 KiB row per instruction
-                const int i = wave * 8 + n;
+            if (pc < 8) {
+                const int i = wave * 8 + pc;                    // LDS row i <- key kt * 32 + pi(i); one 1 KiB row per instruction
                 const int key = min(kt * 32 + pi23(i), T - 1);  // rows past T repeat the last one: their scores are masked (MASK)
-                const char* rowp = (const char*)(Kb + (long long)key * ldk);
-                // uniform base in SGPRs + zero-extended 32-bit lane offset, both opaque HERE so that the sum is formed in this block and
-                // selected as the saddr + voffset form: a per-lane 64-bit address would sit in a temporary that the fragment reads recycle,
-                // and hipcc orders a write to the address register of an LDS-DMA in flight behind the DMA with vmcnt(0)
-                asm volatile("" : "+s"(rowp), "+v"(koff[n]));
-                glds16(rowp + koff[n], sb + i * 1024);
+                if (!(dbg & 1)) blds16(k_rs, koff[pc & 7], (unsigned)key * (unsigned)(ldk * 2), sb + i * 1024);
+            } else {
+                const int m = pc - 8;                           // 16 rows (channels) of 64 bytes per instruction
+                if (!(dbg & 2)) blds16(v_rs, v_lane_off, (unsigned)((128 * wave + 16 * m) * Tpad + kt * 32) * 2u, sb + 2 * F5_KBYTES + (wave * 8 + m) * 1024);
             }
-            const h16_t* vtile = Vb + (long long)(128 * wave) * Tpad + kt * 32;   // my 8 x 16 channels of this tile
-            asm volatile("" : "+s"(vtile), "+v"(v_lane_off));   // (opaque: as for the K rows)
-            if (!(dbg & 2))
+        };
+        auto stage = [&](int slot, int kt) __attribute__((always_inline)) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m)      // V^T: 16 rows (channels) of 64 bytes per instruction
-                glds16((const char*)(vtile + (unsigned)(16 * m * Tpad)) + v_lane_off, sb + 2 * F5_KBYTES + (wave * 8 + m) * 1024);
+            for (int pc = 0; pc < 16; ++pc) stage_piece(slot, kt, pc);
         };
 
         f32x16_t o_acc[16];
@@ -347,39 +337,31 @@ __global__ __launch_bounds__(256) void flash_attn512_kernel(const h16_t* __restr
 #pragma unroll
         for (int j = 0; j < 2; ++j) va[j] = 2 * F5_KBYTES + l31 * 64 + (((2 * j + hh) ^ ((l31 >> 2) & 3)) << 4);
 
-        // hipcc waits for LDS reads with lgkmcnt(0) only while LDS-DMA is in flight (it treats the DMA as a FLAT access), so fragments are
-        // read in sets of F5_NB, one whole set (F5_NB MFMAs = 32 F5_NB cycles) ahead of their use.
+        // Fragments are read F5_RD MFMAs ahead of their use (counted lgkmcnt waits: the DMA is the MUBUF form, common.h); the next tile's
+        // sixteen DMA pieces are issued between the MFMAs of the S^T phase, one per two MFMAs.
         // The accumulators (256 registers: the whole AGPR half of the file) must only ever be MFMA operands in the hot loop, so the
         // online-softmax rescale is (a) lazy -- the reference maximum m_run only moves when some query's tile maximum exceeds it by more
         // than 8 in log2 units; until then probabilities may reach 2^8, exact in the quotient sum(p v) / sum(p) and harmless in fp32 /
         // 16-bit P -- and (b) done outside the hot loop: the loop breaks before the tile's P.V, the cold path rescales and finishes the tile.
         h16x8_t pf[2];
         // ---- S^T = K Q^T over d = 512: 32 k-steps alternating between two accumulators (a single chain would wait for its own result)
-        auto s_phase = [&](unsigned sb, int kt, auto maskc) __attribute__((always_inline)) -> bool {
+        auto s_phase = [&](unsigned sb, int kt, bool do_stage, int slot_next, auto maskc) __attribute__((always_inline)) -> bool {
             constexpr bool MASK = decltype(maskc)::value != 0;
             f32x16_t s0 = zero16, s1 = zero16;
-            h16x8_t fr[2][F5_NB], ql[2];
-            static_assert(F5_NB == 4 && F5_QV == 24, "one parked Q k-step per set of four");
-            auto load = [&](int set, int bb) __attribute__((always_inline)) {
-#pragma unroll
-                for (int i = 0; i < F5_NB; ++i) {
-                    const int ks = F5_NB * bb + i;
-                    fr[set][i] = lds_frag(sb + (ka0 ^ ((ks & 7) << 5)), (ks >> 3) * 256);
-                    if ((ks & 3) == 3) ql[set] = lds_frag(q_lds, (ks >> 2) * 1024);
-                }
+            h16x8_t fr[F5_RD], ql[2];
+            auto rd = [&](int ks) __attribute__((always_inline)) {
+                fr[ks % F5_RD] = lds_frag(sb + (ka0 ^ ((ks & 7) << 5)), (ks >> 3) * 256);
+                if ((ks & 3) == 3) ql[(ks >> 2) & 1] = lds_frag(q_lds, (ks >> 2) * 1024);
             };
-            load(0, 0);
 #pragma unroll
-            for (int bb = 0; bb < 32 / F5_NB; ++bb) {
-                if (bb + 1 < 32 / F5_NB) load((bb + 1) & 1, bb + 1);
+            for (int ks = 0; ks < F5_RD; ++ks) rd(ks);
 #pragma unroll
-                for (int i = 0; i < F5_NB; ++i) {
-                    const int ks = F5_NB * bb + i;
-                    const h16x8_t qv = (ks & 3) != 3 ? qf[3 * (ks >> 2) + ((ks & 3) != 3 ? (ks & 3) : 0)] : ql[bb & 1];
-                    if (ks & 1) s1 = mfma_32x32x16(fr[bb & 1][i], qv, s1);
-                    else s0 = mfma_32x32x16(fr[bb & 1][i], qv, s0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int ks = 0; ks < 32; ++ks) {
+                const h16x8_t qv = (ks & 3) != 3 ? qf[3 * (ks >> 2) + ((ks & 3) != 3 ? (ks & 3) : 0)] : ql[(ks >> 2) & 1];
+                if (ks & 1) s1 = mfma_32x32x16(fr[ks % F5_RD], qv, s1);
+                else s0 = mfma_32x32x16(fr[ks % F5_RD], qv, s0);
+                if (ks + F5_RD < 32) rd(ks + F5_RD);
+                if (do_stage && (ks & 1)) stage_piece(slot_next, kt + 1, ks >> 1);   // the next tile's 16 DMA pieces, one per two MFMAs
             }
             f32x16_t s_acc;
 #pragma unroll
@@ -421,24 +403,14 @@ __global__ __launch_bounds__(256) void flash_attn512_kernel(const h16_t* __restr
         };
         // ---- O^T += V^T P^T: two k-steps of 16 keys x 16 channel blocks of 32 (step = 16 j + block)
         auto pv_phase = [&](unsigned sb) __attribute__((always_inline)) {
-            h16x8_t fr[2][F5_NB];
-            auto load = [&](int set, int bb) __attribute__((always_inline)) {
+            h16x8_t fr[F5_RD];
+            auto rd = [&](int st) __attribute__((always_inline)) { fr[st % F5_RD] = lds_frag(sb + va[st >> 4], (st & 15) * 2048); };
 #pragma unroll
-                for (int i = 0; i < F5_NB; ++i) {
-                    const int st = F5_NB * bb + i;
-                    fr[set][i] = lds_frag(sb + va[st >> 4], (st & 15) * 2048);
-                }
-            };
-            load(0, 0);
+            for (int st = 0; st < F5_RD; ++st) rd(st);
 #pragma unroll
-            for (int bb = 0; bb < 32 / F5_NB; ++bb) {
-                if (bb + 1 < 32 / F5_NB) load((bb + 1) & 1, bb + 1);
-#pragma unroll
-                for (int i = 0; i < F5_NB; ++i) {
-                    const int st = F5_NB * bb + i;
-                    o_acc[st & 15] = mfma_32x32x16(fr[bb & 1][i], pf[st >> 4], o_acc[st & 15]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int st = 0; st < 32; ++st) {
+                o_acc[st & 15] = mfma_32x32x16(fr[st % F5_RD], pf[st >> 4], o_acc[st & 15]);
+                if (st + F5_RD < 32) rd(st + F5_RD);
             }
         };
 
@@ -453,8 +425,8 @@ __global__ __launch_bounds__(256) void flash_attn512_kernel(const h16_t* __restr
                 sb = smem_base + rel * F5_KBYTES;
                 wait_vm<0>();
                 __builtin_amdgcn_s_barrier();
-                if (kt + 1 < t1) stage(rel ^ 1, kt + 1);
-                const bool moved = (kt * 32 + 32 > T) ? s_phase(sb, kt, IC<1>{}) : s_phase(sb, kt, IC<0>{});
+                const bool nx = kt + 1 < t1;
+                const bool moved = (kt * 32 + 32 > T) ? s_phase(sb, kt, nx, rel ^ 1, IC<1>{}) : s_phase(sb, kt, nx, rel ^ 1, IC<0>{});
                 if (moved) { pending = true; break; }
                 pv_phase(sb);
             }

@@ -79,6 +79,17 @@ GP_DEV void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 GP_DEV void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The same LDS-DMA through a buffer resource (buffer_load_dwordx4 ... offen lds): base in four SGPRs, a 32-bit per-lane byte offset and
+// a 32-bit uniform byte offset, no 64-bit address VGPRs.  Unlike global_load_lds (FLAT-encoded: while one is in flight hipcc's waitcnt
+// pass degrades EVERY LDS wait to lgkmcnt(0)), the MUBUF form leaves the LDS counter alone, so ds_read results can be waited for one
+// by one (counted lgkmcnt) underneath a DMA in flight.  Reads past `bytes` return zero.
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+GP_DEV buf_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+GP_DEV void blds16(buf_rsrc_t rsrc, unsigned lane_off, unsigned uniform_off, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, lane_off, uniform_off, 0, 0);
+}
 
 // LDS tiles are [rows][64 bf16] = 128-byte rows split into eight 16-byte slots.  Logical slot c of row r lives at
 // physical slot c ^ (r & 7): with ds_read_b128's lane groups ({0-3,12-15,20-27}, ...) any window of sixteen consecutive
