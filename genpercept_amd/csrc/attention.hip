@@ -5,9 +5,9 @@
 //   and V^T tiles [64 d][64 keys] are brought in by LDS-DMA (double-buffered, swizzled like the GEMM tiles).
 //   The wave computes S^T = K Q^T (keys x queries), so every lane holds 32 scores of ONE query (q = lane & 31):
 //   the softmax max/sum/rescale are lane-local (one cross-half exchange with lane ^ 32), and the probabilities are
-//   already in B-operand order for O^T += V^T P^T -- no LDS round trip, no permutes.  The V^T A-operand is read in the
-//   matching key order (keys 16j+4h+{0..3} and 16j+8+4h+{0..3} for half h), which is why V is produced transposed
-//   ([C][Tpad], zero-padded beyond T) by the projection GEMM.
+//   already in B-operand order for O^T += V^T P^T -- no LDS round trip, no permutes.  The K rows are staged with bits 2 and 3 of
+//   their index swapped, which makes the 8 keys of a lane's k-step consecutive: the V^T A-operand is then one 16-byte read of the
+//   tile the projection GEMM produced transposed ([C][Tpad], zero-padded beyond T).
 // cross_attn_small: cross-attention against the constant, tiny text context (L = 2 for GenPercept's empty prompt).
 // softmax_rows: row softmax for the GEMM-based single-head VAE attention (head_dim 512).
 #include <cstdlib>
@@ -62,23 +62,29 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
 
     const int chunk = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
     const int nt = (T + KEYS - 1) / KEYS;
+    // LDS-DMA through buffer resources (common.h: blds16): K rows of this (image, head) -- reads past row T - 1 return zeros -- and the 64
+    // V^T rows of this head; per lane a byte offset that is the same for every tile, per instruction a uniform one
+    const buf_rsrc_t k_rs = make_rsrc(Kb, (unsigned)(((long long)T - 1) * ldk * 2 + 128));
+    const buf_rsrc_t v_rs = make_rsrc(Vb, (unsigned)(64ll * Tpad * 2));
+    // (the K rows of a 16-key group are staged in the order pi(i) = i with bits 2 and 3 swapped: LDS rows 8 g + r hold keys
+    // 16 (g >> 1) + 4 (g & 1) + (r & 3) + 8 (r >> 2), so that accumulator registers 8 j .. 8 j + 7 of a lane are the CONSECUTIVE keys
+    // 16 j + 8 hh + 0..7 and the matching V^T operand is one 16-byte LDS read instead of two 8-byte ones)
+    const unsigned k_lane = (unsigned)(((lane >> 3) & 3) + 8 * (lane >> 5)) * (unsigned)(ldk * 2) + chunk * 16;
+    const unsigned v_lane = ((unsigned)(lane >> 3) * Tpad + chunk * 8) * 2;
     auto stage = [&](int buf, int kt) {
         char* sb = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < NKB; ++i) {  // K rows: 8 * (wave + 4 i) + lane / 8
             const int g = wave + 4 * i;
-            const int key = kt * KEYS + g * 8 + (lane >> 3);
-            const h16_t* src = key < T ? Kb + (long long)key * ldk + chunk * 8 : zero + chunk * 8;
-            glds16(src, sb + g * 1024);
+            blds16(k_rs, k_lane, (unsigned)(kt * KEYS + (g >> 1) * 16 + 4 * (g & 1)) * (unsigned)(ldk * 2), sb + g * 1024);
         }
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {  // V^T rows = head channels d
-                const int r = (wave + 4 * i) * 8 + (lane >> 3);
+            for (int i = 0; i < 2; ++i) {  // V^T rows = head channels d; key blocks past Tpad: an offset outside the resource (zeros)
                 const int k0 = kt * KEYS + hf * 64;
-                const h16_t* vsrc = k0 < Tpad ? Vb + (long long)r * Tpad + k0 + chunk * 8 : zero + chunk * 8;  // (Tpad % 64 == 0)
-                glds16(vsrc, sb + KBYTES + hf * 8192 + (wave + 4 * i) * 1024);
+                const unsigned so = k0 < Tpad ? (unsigned)((wave + 4 * i) * 8 * Tpad + k0) * 2u : 0xfffff000u;  // (Tpad % 64 == 0)
+                blds16(v_rs, v_lane, so, sb + KBYTES + hf * 8192 + (wave + 4 * i) * 1024);
             }
     };
 
@@ -95,8 +101,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
     int cur = 0;
     const unsigned smem_base = (unsigned)(unsigned long long)smem;  // integer-addressed LDS reads: see common.h (no compiler vmcnt(0) before them)
-    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-    typedef const __attribute__((address_space(3))) u32x2_t* lds_u2_ptr;
 
     // One KV tile.  The softmax is the bound of this kernel (head_dim 64: 16 MFMAs of 32 cycles against ~32 scores per lane), so it is
     // kept to the minimum: raw v_exp_f32 (the libm exp2f wrapper added a compare, two selects and a v_ldexp per score), the 1/sqrt(d)
@@ -119,12 +123,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
         }
         // ---- online softmax over this lane's 32 keys (+ the other half's 32 via lane ^ 32)
         if (MASK) {
-            const int kbase = kt * KEYS + 4 * hh;
+            const int kbase = kt * KEYS + 8 * hh;  // register r <-> LDS row (r & 3) + 4 hh + 8 (r >> 2) <-> key 8 hh + (r & 7) + 16 (r >> 3)
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (kbase + kb * 32 + (r & 3) + 8 * (r >> 2) >= T) s_acc[kb][r] = -1e30f;
+                    if (kbase + kb * 32 + (r & 7) + 16 * (r >> 3) >= T) s_acc[kb][r] = -1e30f;
         }
         float mx = s_acc[0][0];
 #pragma unroll
@@ -159,16 +163,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
                 union { h16x8_t v; unsigned u[4]; } pf;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) pf.u[e] = pack_h16x2_ns(s_acc[kb][8 * j + 2 * e], s_acc[kb][8 * j + 2 * e + 1]);  // probabilities: in [0, 1]
-                const int ko = (kb & 1) * 32 + 16 * j + 4 * hh;  // key offset inside the 64-key half (multiple of 4)
+                const int slot = (kb & 1) * 4 + 2 * j + hh;  // keys 8 slot .. 8 slot + 7 of the 64-key half
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
-                    const int row = d * 32 + l31;
-                    const unsigned vr = sb + KBYTES + (kb >> 1) * 8192 + row * 128;
-                    const int sw = (row >> 1) & 7;
-                    union { h16x8_t v; u32x2_t h2[2]; } vf;
-                    vf.h2[0] = *(lds_u2_ptr)(vr + ((((ko >> 3)) ^ sw) << 4) + (ko & 7) * 2);
-                    vf.h2[1] = *(lds_u2_ptr)(vr + ((((ko >> 3) + 1) ^ sw) << 4) + (ko & 7) * 2);
-                    o_acc[d] = mfma_32x32x16(vf.v, pf.v, o_acc[d]);
+                    const h16x8_t vf = lds_frag(sb + KBYTES + (kb >> 1) * 8192 + attn_off128(d * 32 + l31, slot), 0);
+                    o_acc[d] = mfma_32x32x16(vf, pf.v, o_acc[d]);
                 }
             }
     };
