@@ -273,10 +273,22 @@ __global__ __launch_bounds__(256) void flash_attn512_kernel(const h16_t* __restr
     const int items = rounds + ((L && sid / S < L) ? 1 : 0);
     for (int it = 0; it < items; ++it) {
         const bool whole = it < rounds;
-        const int blk = whole ? it * G + sid : rounds * G + sid / S;
         const int part = whole ? 0 : sid % S;
         const int t0 = whole ? 0 : (int)((long long)nt * part / S), t1 = whole ? nt : (int)((long long)nt * (part + 1) / S);
-        const int b = blk / nqb, qb = blk - b * nqb;
+        // which blocks are cut along the keys must not depend on the image's position in the batch (results are compared bit for bit
+        // across batch permutations): when L divides by B every image contributes its LAST L / B query blocks, otherwise the last L
+        // blocks of the batch are taken
+        const int Li = (L % B == 0) ? L / B : 0;
+        int b, qb;
+        if (whole) {
+            const int w = it * G + sid, per = nqb - Li;
+            b = Li ? w / per : w / nqb;
+            qb = Li ? w - b * per : w - b * nqb;
+        } else {
+            const int lb = sid / S;
+            b = Li ? lb / Li : (rounds * G + lb) / nqb;
+            qb = Li ? nqb - Li + (lb - b * Li) : rounds * G + lb - b * nqb;
+        }
         const int q0 = qb * 128 + wave * 32;
         const h16_t* Qb = Q + (long long)b * T * ldq;
         const h16_t* Kb = K + (long long)b * T * ldk;
@@ -477,9 +489,11 @@ __global__ __launch_bounds__(256) void flash_attn512_kernel(const h16_t* __restr
 
 // merge the S key-parts of each left-over query block: out = sum_p w_p O_p / sum_p w_p l_p, w_p = 2^((m_p - max m) sc)
 __global__ __launch_bounds__(256) void flash512_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                                h16_t* __restrict__ O, int T, int nqb, int first_blk, int S, int ldo, float scale) {
+                                                                h16_t* __restrict__ O, int T, int nqb, int first_blk, int Li, int S, int ldo,
+                                                                float scale) {
     const int lb = blockIdx.x >> 2, qq = (blockIdx.x & 3) * 32 + (threadIdx.x >> 3);   // 32 queries per workgroup, 8 threads per query
-    const int blk = first_blk + lb, b = blk / nqb, q = (blk - b * nqb) * 128 + qq;
+    const int b = Li ? lb / Li : (first_blk + lb) / nqb;                                // (the kernel's block numbering)
+    const int q = (Li ? nqb - Li + (lb - b * Li) : first_blk + lb - b * nqb) * 128 + qq;
     if (q >= T) return;
     const float sc = scale * 1.44269504088896340736f;
     float m = -1e30f;
@@ -526,7 +540,8 @@ void launch_flash_attn512(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t
     static const int dbg = getenv("GENPERCEPT_F5_DBG") ? atoi(getenv("GENPERCEPT_F5_DBG")) : 0;  // timing ablations only: 1 no K DMA, 2 no V DMA
     hipLaunchKernelGGL(flash_attn512_kernel, dim3(G), dim3(256), F5_LDS, s, q, k, vt, out, zero, part_o, part_ml, B, T, ldq, ldk, Tpad,
                        ldo, scale, dbg);
-    if (L) hipLaunchKernelGGL(flash512_combine_kernel, dim3(L * 4), dim3(256), 0, s, part_o, part_ml, out, T, nqb, rounds * G, S, ldo, scale);
+    if (L) hipLaunchKernelGGL(flash512_combine_kernel, dim3(L * 4), dim3(256), 0, s, part_o, part_ml, out, T, nqb, rounds * G, (L % B == 0) ? L / B : 0,
+                              S, ldo, scale);
 }
 
 // ---- cross-attention with a tiny constant context -------------------------------------------------------------------

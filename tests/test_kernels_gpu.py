@@ -441,6 +441,11 @@ def test_flash_attention_hd512(case, metric_log):
     # the outputs are averages over hundreds of keys, all of similar magnitude: the rounding of the stored result alone is 2.1e-3 (bf16) /
     # 2.6e-4 (fp16) of the mean |ref|, i.e. exactly the generic mean gate; measured 1.9-2.1e-3 / 2.3-2.6e-4 in every case, split or not
     check(f"flash512{case}", y, ref, metric_log, mean_factor=1.25)
+    if case == (2, 300, 4):
+        # which query blocks are cut along the keys does not depend on the image's slot (each image gives its last L / B blocks):
+        # a permuted batch gives the permuted result, bit for bit
+        y2 = e.flash_attention_hd512(qkd.flip(0)[..., :c], qkd.flip(0)[..., c:], vt.flip(0).contiguous(), scale, ncu)
+        assert torch.equal(y2.flip(0), y)
 
 
 def test_flash_attention_hd512_outlier_logits(metric_log):
