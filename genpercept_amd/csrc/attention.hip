@@ -522,9 +522,18 @@ __global__ __launch_bounds__(256) void flash512_combine_kernel(const float* __re
 }
 
 bool flash_attn512_supported(int C) { return C == 512 && getenv("GENPERCEPT_NO_FLASH512") == nullptr; }
+// Workgroups to launch: the CU count, or -- when the query blocks would leave half of the chip idle (one image at 768^2 is 72 blocks on
+// 256 CUs) -- a multiple of the block count, so that EVERY block is cut along the keys into G / blocks parts.
+static int flash512_grid(int nblocks, int ncu, int T) {
+    if (nblocks >= ncu) return ncu;
+    const int nt = (T + 31) / 32;
+    int parts = ncu / nblocks;
+    if (parts > nt / 8) parts = nt / 8;          // at least eight 32-key tiles per part
+    return parts >= 2 ? parts * nblocks : nblocks;
+}
 // floats of workspace the launch needs (0: the blocks divide evenly over the workgroups)
 long long flash_attn512_workspace_floats(int B, int T, int ncu) {
-    const int nblocks = B * ((T + 127) / 128), G = nblocks < ncu ? nblocks : ncu;
+    const int nblocks = B * ((T + 127) / 128), G = flash512_grid(nblocks, ncu, T);
     const int L = nblocks % G;
     return L ? (long long)(G / L) * L * 128 * (512 + 2) : 0;
 }
@@ -533,7 +542,7 @@ void launch_flash_attn512(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t
     static unsigned long long attr_mask = 0;
     if (gp_first_use_on_device(&attr_mask))
         (void)hipFuncSetAttribute((const void*)flash_attn512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F5_LDS);
-    const int nqb = (T + 127) / 128, nblocks = B * nqb, G = nblocks < ncu ? nblocks : ncu;
+    const int nqb = (T + 127) / 128, nblocks = B * nqb, G = flash512_grid(nblocks, ncu, T);
     const int rounds = nblocks / G, L = nblocks - rounds * G, S = L ? G / L : 0;
     float* part_o = ws;
     float* part_ml = ws ? ws + (long long)S * L * 128 * 512 : nullptr;

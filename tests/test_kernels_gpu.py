@@ -418,11 +418,13 @@ def test_flash_attention_spiky_scores(metric_log):
     check("flash64_spiky", y, ref, metric_log)
 
 
-@pytest.mark.parametrize("case", [(1, 64, 0), (1, 1131, 0), (2, 300, 4), (1, 1131, 4), (3, 200, 5), (2, 1000, 3), (1, 4100, 0)])
+@pytest.mark.parametrize("case", [(1, 64, 0), (1, 1131, 0), (2, 300, 4), (1, 1131, 4), (3, 200, 5), (2, 1000, 3), (1, 4100, 0), (1, 1000, 40)])
 def test_flash_attention_hd512(case, metric_log):
     """The fused VAE mid-block attention (one head, head_dim 512).  ncu != 0 sizes the launch for that many workgroups: (2, 300, 4) = 6 query
     blocks on 4 -> one whole round + 2 left-over blocks cut into 2 key parts each; (1, 1131, 4) = 9 blocks -> two rounds + 1 block in 4 parts;
-    (3, 200, 5) = 6 blocks -> 1 left-over block in 5 parts of 7 tiles (uneven); (2, 1000, 3) = 16 blocks -> 5 rounds + 1 block in 3 parts."""
+    (3, 200, 5) = 6 blocks -> 1 left-over block in 5 parts of 7 tiles (uneven); (2, 1000, 3) = 16 blocks -> 5 rounds + 1 block in 3 parts;
+    fewer blocks than half the workgroups -> EVERY block is cut along the keys: (1, 4100, 0) = 33 blocks on 256 CUs in 7 parts each,
+    (1, 1000, 40) = 8 blocks in 4 parts (the cap of eight tiles per part; 40 / 8 = 5 would leave parts of 6 tiles)."""
     e = _eng()
     b, t, ncu = case
     c = 512
