@@ -275,3 +275,85 @@ def test_igemm_model_matches_source():
                  "const bool do_stage = kt + NSTAGE - 1 < nk && !(p.dbg & 1);",
                  "if (second_half && do_stage) stage(nxt);", "if (!second_half && do_stage) stage(nxt);"]:
         assert line in s, line
+
+
+# ---- flash_attn512_kernel (attention.hip): two K / V^T slots, one full wait + one barrier per 32-key tile --------------------------------
+def simulate_flash512(tiles_per_item, nw=4):
+    """Work items of a workgroup in sequence; per tile: wait vmcnt(0), barrier, then the S^T phase (reads K of the tile's slot) with the
+    NEXT tile's sixteen DMA pieces issued between its MFMAs into the other slot, then the P.V phase (reads V^T of the tile's slot).  Every
+    item starts with a workgroup barrier (it re-parks its Q rows in LDS and restarts the slots at 0)."""
+    certified, done, fifo = set(), [set() for _ in range(nw)], [[] for _ in range(nw)]
+    last_read = {}                              # resource -> event index of its last LDS read
+    slot_content = {0: None, 1: None}
+    clock = [0]
+
+    def tick():
+        clock[0] += 1
+        return clock[0]
+
+    def barrier():
+        for r in set.intersection(*done):
+            certified.add(r)
+        return tick()
+
+    last_barrier = [0]
+    for item, ntiles in enumerate(tiles_per_item):
+        last_barrier[0] = barrier()             # __syncthreads() at the top of the item (nothing new is certified by it)
+        for t in range(ntiles):
+            res = (item, t)
+            if t == 0:                          # `if (t0 < t1) stage(0, t0)`: all sixteen pieces of the first tile, before the loop
+                prev = slot_content[0]
+                assert prev is None or last_read.get(prev, 0) < last_barrier[0], f"{res} overwrites {prev} before a barrier after its last read"
+                for w in range(nw):
+                    fifo[w].append(res)
+                slot_content[0] = res
+            for w in range(nw):                 # wait_vm<0>()
+                done[w].update(fifo[w])
+                fifo[w] = []
+            last_barrier[0] = barrier()
+            slot = t & 1
+            assert slot_content[slot] == res and res in certified, f"tile {res}: S^T reads a slot that is not certified"
+            if t + 1 < ntiles:                  # stage_piece(slot_next, kt + 1, ...) between the S^T MFMAs
+                nxt = (item, t + 1)
+                prev = slot_content[slot ^ 1]
+                assert prev is None or last_read.get(prev, 0) < last_barrier[0], f"{nxt} overwrites {prev} before a barrier after its last read"
+                for w in range(nw):
+                    fifo[w].append(nxt)
+                slot_content[slot ^ 1] = nxt
+            last_read[res] = tick()             # S^T phase reads K, then (possibly after the cold rescale path) P.V reads V^T
+            last_read[res] = tick()
+
+
+@pytest.mark.parametrize("tiles", [[1], [2], [3, 1], [288, 36], [5, 4, 7], [1, 1, 1]])
+def test_flash512_slot_protocol_is_safe(tiles):
+    simulate_flash512(tiles)
+
+
+def test_flash512_model_detects_a_missing_item_barrier():
+    """Without the barrier at the top of an item, the first tile of the next item would be staged into slot 0 while slower waves may
+    still read the previous item's last tile from it (odd tile counts end in slot 0)."""
+    def broken(tiles_per_item):  # the same bookkeeping for slot 0, the item barrier left out
+        clock, last_read, slot0, last_barrier = [0], {}, None, 0
+        for item, ntiles in enumerate(tiles_per_item):
+            for t in range(ntiles):
+                res = (item, t)
+                if t == 0:
+                    assert slot0 is None or last_read.get(slot0, 0) < last_barrier, "overwrite before barrier"
+                if (t & 1) == 0:
+                    slot0 = res
+                clock[0] += 1
+                last_barrier = clock[0]         # per-tile barrier
+                clock[0] += 1
+                last_read[res] = clock[0]
+    with pytest.raises(AssertionError):
+        broken([3, 1])
+    broken([2, 1])  # (an even tile count ends in slot 1: the per-tile barrier of the last tile already covers slot 0)
+
+
+def test_flash512_model_matches_source():
+    src = open(os.path.join(ROOT, "genpercept_amd", "csrc", "attention.hip")).read()
+    k = src[src.index("void flash_attn512_kernel"):src.index("void flash512_combine_kernel")]
+    loop = k[k.index("for (; kt < t1; ++kt) {"):]
+    assert loop.index("wait_vm<0>();") < loop.index("__builtin_amdgcn_s_barrier();") < loop.index("s_phase(sb, kt, nx, rel ^ 1") < loop.index("pv_phase(sb);")
+    assert "stage_piece(slot_next, kt + 1, ks >> 1)" in k and "if (t0 < t1) stage(0, t0);" in k
+    assert k.index("__syncthreads();") < k.index("if (t0 < t1) stage(0, t0);")   # the item barrier precedes the first staging of the item
