@@ -70,7 +70,20 @@ GP_DEV f32x16_t mfma_32x32x16(h16x8_t a, h16x8_t b, f32x16_t c) {
 GP_DEV h16_t f_to_h16(float f) { return (h16_t)(pack_h16x2(f, 0.f) & 0xffffu); }
 
 GP_DEV float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }  // v_exp + v_rcp (1 ulp), no IEEE division sequence
-GP_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+// GELU(x) = x/2 (1 + erf(x / sqrt 2)), the exact (erf) form diffusers' GEGLU uses.  erf through Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7, far below the 16-bit output rounding): E = (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z), z = |x| / sqrt 2;
+// 1 + erf = 2 - E for x >= 0 and = E for x < 0 (the complementary form: no cancellation in the negative tail).  About 16 VALU
+// instructions with two transcendentals, no branches; the device library's erff is ~40 with two data-dependent paths.
+GP_DEV float gelu_erf_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float e = p * t * __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);
+    return 0.5f * x * (x >= 0.f ? 2.f - e : e);
+}
 
 // Asynchronous 16-byte-per-lane global -> LDS copy (LDS-DMA).  The LDS destination is wave-uniform base + lane*16,
 // the global source is per lane; swizzles therefore go on the SOURCE address (cdna guide, rule 21).
