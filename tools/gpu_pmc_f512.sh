@@ -22,4 +22,18 @@ for k, v in agg.items():
         print(k, 'n=%d avg=%.5g' % (v[0], v[1] / v[0]))
 PY
 done
+python - <<'PY'
+import csv, glob, json, collections
+out = collections.OrderedDict()
+for f in sorted(glob.glob("gpurun_out/pmc512/**/*counter_collection.csv", recursive=True)):
+    for r in csv.DictReader(open(f)):
+        if "flash_attn512" not in r.get("Kernel_Name", ""):
+            continue
+        k = "grid_%s" % r.get("Grid_Size", r.get("Grid_Size_X", "?"))
+        a = out.setdefault(k, collections.OrderedDict()).setdefault(r["Counter_Name"], [0, 0.0])
+        a[0] += 1; a[1] += float(r["Counter_Value"])
+res = {"note": "rocprofv3 --pmc (separate passes) over tools/attn_bench.py --hd512-only; per-launch averages of flash_attn512_kernel; grid = threads "
+               "(65536 = batch 4 x 9216 tokens on 256 workgroups)", "kernels": {k: {c: v[1] / v[0] for c, v in d.items()} for k, d in out.items()}}
+json.dump(res, open("gpurun_out/pmc512/summary.json", "w"), indent=1)
+PY
 find gpurun_out/pmc512 -name "*.csv" -size +2M -delete
