@@ -171,3 +171,84 @@ def test_multistep_golden_is_reproducible():
         c = opipe.multi_step_infer(vsd, vc, u4, uc4, x, ctx, "depth", opipe.DDIM(**one), 1)
         d = opipe.single_infer(vsd, vc, u4, uc4, x, ctx, "depth")
     assert torch.allclose(c, d, atol=1e-6)
+
+
+class _FakeLib:
+    @staticmethod
+    def gp_latent_size(x):  # three VAE downsamples, each x -> (x - 2) // 2 + 1 (include/genpercept_hip.h)
+        for _ in range(3):
+            x = (x - 2) // 2 + 1
+        return x
+
+
+class _FakeEngine:
+    """Records what the pipeline hands to the engine (no GPU): the plumbing of steps / noise / ensembling / timesteps."""
+
+    def __init__(self):
+        self.lib, self.calls, self.ctx, self.timestep = _FakeLib(), [], None, 1
+
+    def set_context(self, e):
+        self.ctx = e
+
+    def set_timestep(self, t):
+        self.timestep = t
+
+    def infer(self, rgb, mode):
+        self.calls.append(("infer", tuple(rgb.shape), mode, self.timestep))
+        return torch.full((rgb.shape[0], 1 if mode == "depth" else 3, rgb.shape[2], rgb.shape[3]), 0.5)
+
+    def infer_steps(self, rgb, mode, plan, noise):
+        self.calls.append(("steps", tuple(rgb.shape), mode, [p["timestep"] for p in plan], None if noise is None else noise.clone()))
+        b, _, h, w = rgb.shape
+        base = torch.linspace(0.1, 0.9, h * w).reshape(1, 1, h, w).repeat(b, 1, 1, 1)
+        if noise is not None:  # members that differ by an affine map, like real ensemble members
+            k = noise.reshape(b, -1)[:, :1].reshape(b, 1, 1, 1)
+            base = base * (1 + 0.1 * k) + 0.05 * k
+        return base if mode == "depth" else base.repeat(1, 3, 1, 1)
+
+
+def _fake_pipe(monkeypatch, **kw):
+    from types import SimpleNamespace
+    from genpercept_amd import GenPerceptPipeline
+    monkeypatch.setenv("GENPERCEPT_HOST_PREPOST", "1")          # host pre / post: no device kernels involved
+    monkeypatch.setattr(GenPerceptPipeline, "_device", torch.device("cpu"), raising=False)
+    pipe = GenPerceptPipeline(unet={}, vae={}, text_encoder=np.zeros((2, 8), np.float32), **kw)
+    pipe._device = torch.device("cpu")
+    pipe._engine, pipe._timestep, pipe._ctx_loaded = _FakeEngine(), 1, None
+    pipe.vae_config = SimpleNamespace(latent_channels=4)
+    return pipe
+
+
+def test_pipeline_multistep_plumbing_without_gpu(monkeypatch):
+    sched = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False, steps_offset=1,
+                 prediction_type="v_prediction")
+    img = torch.randint(0, 256, (1, 3, 64, 80), dtype=torch.uint8)
+    # marigold: noise from the generator, one draw per engine call, E members in batches of `batch_size`
+    pipe = _fake_pipe(monkeypatch, scheduler=sched, genpercept_pipeline=False, rgb_blending=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = pipe(img, denoising_steps=4, ensemble_size=5, batch_size=2, processing_res=0, generator=torch.Generator().manual_seed(9), mode="depth",
+                   color_map=None)
+    calls = pipe._engine.calls
+    assert [c[0] for c in calls] == ["steps"] * 3 and [c[1][0] for c in calls] == [2, 2, 1]       # 5 members = 2 + 2 + 1
+    assert all(c[3] == [751.0, 501.0, 251.0, 1.0] for c in calls)
+    g = torch.Generator().manual_seed(9)
+    for c in calls:                                               # the draws follow the generator's sequence, fp32, latent shape
+        assert torch.equal(c[4], torch.randn((c[1][0], 4, 8, 10), generator=g))
+    assert out.pred_np.shape == (64, 80) and out.pred_np.min() == 0.0 and out.pred_np.max() == 1.0   # ensembled + rescaled to [0,1]
+    # rgb_blending: no noise; fix_timesteps repeats one timestep; default steps
+    pb = _fake_pipe(monkeypatch, scheduler=sched, genpercept_pipeline=False, rgb_blending=True)
+    pb(img, processing_res=0, mode="depth", color_map=None, fix_timesteps=300)
+    (c,) = pb._engine.calls
+    assert c[0] == "steps" and c[3] == [300.0] * 10 and c[4] is None
+    with pytest.raises(ValueError):                               # ensemble_depth takes 1-channel maps only, like the reference's
+        pb(img, denoising_steps=2, ensemble_size=2, processing_res=0, mode="normal", color_map=None)
+    # the one-step pipeline: beta == 1 -> gp_infer with the timestep set; another scheduler -> one step of the loop
+    p1 = _fake_pipe(monkeypatch, scheduler=dict(sched, beta_start=1.0, beta_end=1.0))
+    p1(img, processing_res=0, mode="depth", color_map=None, fix_timesteps=77)
+    assert p1._engine.calls == [("infer", (1, 3, 64, 80), "depth", 77)]
+    p2 = _fake_pipe(monkeypatch, scheduler=sched)
+    p2(img, processing_res=0, mode="depth", color_map=None)
+    assert p2._engine.calls[0][0] == "steps" and p2._engine.calls[0][3] == [1.0] and p2._engine.calls[0][4] is None
+    with pytest.raises(AssertionError):
+        p2(img, denoising_steps=2, mode="depth")
