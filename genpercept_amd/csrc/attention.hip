@@ -26,9 +26,8 @@ GP_DEV int attn_off128(int row, int slot) { return row * 128 + ((slot ^ ((row >>
 // the top of tile t+2, so an L2 / MALL round trip no longer has to fit inside one tile's compute.
 template <int NKB, int NST>
 __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __restrict__ Q, const h16_t* __restrict__ K,
-                                                            const h16_t* __restrict__ Vt, h16_t* __restrict__ O,
-                                                            const h16_t* __restrict__ zero, int T, int heads, int ldq, int ldk, int Tpad,
-                                                            int ldo) {
+                                                            const h16_t* __restrict__ Vt, h16_t* __restrict__ O, int T, int heads, int ldq,
+                                                            int ldk, int Tpad, int ldo) {
     constexpr int KEYS = 32 * NKB, KBYTES = KEYS * 128, NH = NKB / 2;  // NH 64-key halves, each with its own [64 d][64 keys] V^T tile
     constexpr int STAGE = 2 * KBYTES;  // K tile + V^T tiles
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -205,18 +204,18 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
     }
 }
 
-void launch_flash_attn64(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t* out, const h16_t* zero, int B, int T, int heads,
+void launch_flash_attn64(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t* out, int B, int T, int heads,
                          int ldq, int ldk, int Tpad, int ldo, hipStream_t s) {
     dim3 grid(((T + 127) / 128) * heads * B);
-    // 64-key tiles: 194 VGPRs as hipcc 7.2 allocates them, i.e. two waves per SIMD (forcing three, __launch_bounds__(256, 3), spills 38 registers).
+    // 64-key tiles: 183 VGPRs as hipcc 7.2 allocates them (194 with the FLAT LDS-DMA and its 64-bit addresses), i.e. two waves per SIMD (forcing three, __launch_bounds__(256, 3), spills 38 registers).
     // Measured alternatives, all slower at T = 9216 (610 us, kernel only): 128-key tiles -8 % (r1); a three-stage K / V ring with counted waits
     // -2 % (stays as a switch, GENPERCEPT_FLASH_RING3: K / V latency is not what the kernel waits for); two 32-query blocks per wave so that each
     // K / V^T fragment read feeds two MFMAs: 1100 us with 256 VGPRs + 42 spilled, 1050 us at one wave per SIMD; one online-softmax update per
     // 32 keys instead of 64 (165 VGPRs): 644 us.  r2 ablations of the shipped shape: no softmax arithmetic 494 us, no P.V MFMAs 587 us, neither
     // 442 us, additionally no K.Q^T MFMAs 249 us (the LDS fragment reads, DMA and loop alone), no waits / barriers 601 us.
     static const bool ring2 = getenv("GENPERCEPT_FLASH_RING3") == nullptr;
-    if (ring2) hipLaunchKernelGGL((flash_attn64_kernel<2, 2>), grid, dim3(256), 2 * 16384, s, q, k, vt, out, zero, T, heads, ldq, ldk, Tpad, ldo);
-    else hipLaunchKernelGGL((flash_attn64_kernel<2, 3>), grid, dim3(256), 3 * 16384, s, q, k, vt, out, zero, T, heads, ldq, ldk, Tpad, ldo);
+    if (ring2) hipLaunchKernelGGL((flash_attn64_kernel<2, 2>), grid, dim3(256), 2 * 16384, s, q, k, vt, out, T, heads, ldq, ldk, Tpad, ldo);
+    else hipLaunchKernelGGL((flash_attn64_kernel<2, 3>), grid, dim3(256), 3 * 16384, s, q, k, vt, out, T, heads, ldq, ldk, Tpad, ldo);
 }
 
 // ---- flash_attn512: the VAE mid-block attention (one head, head_dim 512; genpercept_pipeline.py:500-501,521-522) ----------------------
@@ -253,7 +252,7 @@ GP_DEV int pi23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }  
 
 __global__ __launch_bounds__(256) void flash_attn512_kernel(const h16_t* __restrict__ Q, const h16_t* __restrict__ K,
                                                              const h16_t* __restrict__ Vt, h16_t* __restrict__ O,
-                                                             const h16_t* __restrict__ zero, float* __restrict__ part_o,
+                                                             float* __restrict__ part_o,
                                                              float* __restrict__ part_ml, int B, int T, int ldq, int ldk, int Tpad, int ldo,
                                                              float scale, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -537,7 +536,7 @@ long long flash_attn512_workspace_floats(int B, int T, int ncu) {
     const int L = nblocks % G;
     return L ? (long long)(G / L) * L * 128 * (512 + 2) : 0;
 }
-void launch_flash_attn512(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t* out, const h16_t* zero, float* ws, int B, int T, int ldq,
+void launch_flash_attn512(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t* out, float* ws, int B, int T, int ldq,
                           int ldk, int Tpad, int ldo, float scale, int ncu, hipStream_t s) {
     static unsigned long long attr_mask = 0;
     if (gp_first_use_on_device(&attr_mask))
@@ -547,7 +546,7 @@ void launch_flash_attn512(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t
     float* part_o = ws;
     float* part_ml = ws ? ws + (long long)S * L * 128 * 512 : nullptr;
     static const int dbg = getenv("GENPERCEPT_F5_DBG") ? atoi(getenv("GENPERCEPT_F5_DBG")) : 0;  // timing ablations only: 1 no K DMA, 2 no V DMA
-    hipLaunchKernelGGL(flash_attn512_kernel, dim3(G), dim3(256), F5_LDS, s, q, k, vt, out, zero, part_o, part_ml, B, T, ldq, ldk, Tpad,
+    hipLaunchKernelGGL(flash_attn512_kernel, dim3(G), dim3(256), F5_LDS, s, q, k, vt, out, part_o, part_ml, B, T, ldq, ldk, Tpad,
                        ldo, scale, dbg);
     if (L) hipLaunchKernelGGL(flash512_combine_kernel, dim3(L * 4), dim3(256), 0, s, part_o, part_ml, out, T, nqb, rounds * G, (L % B == 0) ? L / B : 0,
                               S, ldo, scale);

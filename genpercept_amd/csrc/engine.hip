@@ -907,7 +907,7 @@ struct gp_engine {
             tm.n_attn++;
             mark("flash_attn512 T=" + std::to_string(T), fl);
             prof_begin(1);
-            launch_flash_attn512(qk.p, qk.p + C, vt, o.p, zero, ws, B, T, 2 * C, 2 * C, Tpad, C, 1.0f, ncu, st);
+            launch_flash_attn512(qk.p, qk.p + C, vt, o.p, ws, B, T, 2 * C, 2 * C, Tpad, C, 1.0f, ncu, st);
             prof_end();
             if (ws) pool.release(ws);
             drop(qk);
@@ -939,7 +939,7 @@ struct gp_engine {
         tm.n_attn++;
         mark("flash_attn64 T=" + std::to_string(T) + " heads=" + std::to_string(t.heads), 4.0 * x.B * t.heads * (double)T * T * 64);
         prof_begin(1);
-        launch_flash_attn64(qk.p, qk.p + C, vt, a.p, zero, x.B, T, t.heads, 2 * C, 2 * C, Tpad, C, st);
+        launch_flash_attn64(qk.p, qk.p + C, vt, a.p, x.B, T, t.heads, 2 * C, 2 * C, Tpad, C, st);
         prof_end();
         drop(qk);
         pool.release(vt);
@@ -1823,7 +1823,7 @@ gp_status gp_flash_attention(const void* q, const void* k, const void* vt, void*
     if (!q || !k || !vt || !out || (Tpad % 64) || Tpad < T) return GP_ERR_INVALID;
     try {
         std::lock_guard<std::mutex> lk(g_scratch_mu);
-        launch_flash_attn64((const h16_t*)q, (const h16_t*)k, (const h16_t*)vt, (h16_t*)out, zero_page(), B, T, heads, ldq, ldk, Tpad, ldo,
+        launch_flash_attn64((const h16_t*)q, (const h16_t*)k, (const h16_t*)vt, (h16_t*)out, B, T, heads, ldq, ldk, Tpad, ldo,
                             (hipStream_t)stream);
         HIPCHK(hipGetLastError());
         return GP_OK;
@@ -1844,7 +1844,7 @@ gp_status gp_flash_attention_hd512(const void* q, const void* k, const void* vt,
         }
         const long long wsf = flash_attn512_workspace_floats(B, T, ncu);
         float* ws = wsf ? scratch_floats(2, (size_t)wsf) : nullptr;
-        launch_flash_attn512((const h16_t*)q, (const h16_t*)k, (const h16_t*)vt, (h16_t*)out, zero_page(), ws, B, T, ldq, ldk, Tpad, ldo, scale,
+        launch_flash_attn512((const h16_t*)q, (const h16_t*)k, (const h16_t*)vt, (h16_t*)out, ws, B, T, ldq, ldk, Tpad, ldo, scale,
                              ncu, (hipStream_t)stream);
         HIPCHK(hipGetLastError());
         return GP_OK;

@@ -91,12 +91,12 @@ void launch_layernorm(const h16_t* x, h16_t* y, const float* gamma, const float*
 
 // Flash self-attention, head_dim 64.  q/k: [B][T][ld] bf16 (head h at column h*64), vt: [B][heads*64][Tpad] bf16,
 // out [B][T][ldo].
-void launch_flash_attn64(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t* out, const h16_t* zero, int B, int T, int heads,
+void launch_flash_attn64(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t* out, int B, int T, int heads,
                          int ldq, int ldk, int Tpad, int ldo, hipStream_t s);
 // VAE mid-block attention (one head, head_dim 512), fused; ws: flash_attn512_workspace_floats() floats (may be null when that is 0)
 bool flash_attn512_supported(int C);
 long long flash_attn512_workspace_floats(int B, int T, int ncu);
-void launch_flash_attn512(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t* out, const h16_t* zero, float* ws, int B, int T, int ldq,
+void launch_flash_attn512(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t* out, float* ws, int B, int T, int ldq,
                           int ldk, int Tpad, int ldo, float scale, int ncu, hipStream_t s);
 
 // Cross-attention against a small constant context: q [rows][C] bf16, kc/vc [L][C] fp32, head_dim 64.
