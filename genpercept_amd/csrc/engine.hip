@@ -757,8 +757,11 @@ struct gp_engine {
         p.lda = wv.cin_pad; p.ldw = x.C; p.ldo = Tpad; p.n_store = Tpad;
         p.bias_mode = wv.bias ? GP_BIAS_ROW : GP_BIAS_NONE;
         p.batch = x.B; p.in_bs = 0; p.wt_bs = (long long)T * x.C; p.out_bs = (long long)C * Tpad; p.bias_bs = 0;
-        // rows = channels: 320 / 640 of them leave the last 256-row tile of the large-problem configuration 25 / 50 % full -> 128-row tiles
-        run_igemm(p, (C % 256) ? 1 : 0);
+        // rows = channels (320 ... 1280), columns = tokens: 64x64 tiles when there are few tokens or the channel count is not a multiple of 128
+        // (320 rows leave a 128-row tile half empty), 128x64 tiles otherwise -- measured per shape with GENPERCEPT_VT_TILE (igemm.hip: tile_hint),
+        // 0.77 -> 0.67 ms per pass over the 18 projections
+        static const int vt_tile = getenv("GENPERCEPT_VT_TILE") ? atoi(getenv("GENPERCEPT_VT_TILE")) : -1;
+        run_igemm(p, vt_tile >= 0 ? vt_tile : (T <= 1024 || (C % 128)) ? 2 : 6);
         return vt;
     }
     // statistics -> per-(image, channel) scale / shift in the GN workspace; from the producer's tile partials when it left some
