@@ -1570,14 +1570,21 @@ gp_status gp_infer_steps(gp_engine* e, const void* rgb_dev, int is_u8, int B, in
         e->mark("ddim_init");
         launch_ddim_init(noise_dev, lat.p, sample, B, lat.H, lat.W, L, lat.C, off, e->st);
         Act x0 = e->new_act(B, lat.H, lat.W, 64);
-        for (int i = 0; i < n_steps; ++i) {
-            const gp_ddim_step& s = steps[i];
-            if (s.timestep != e->timestep) e->set_timestep_on_stream(s.timestep);
-            Act v = e->unet(lat, nullptr, true);
-            const DdimCoef k{s.x0_sample, s.x0_model, s.eps_sample, s.eps_model, s.prev_x0, s.prev_eps, s.clip};
-            e->mark("ddim_step");
-            launch_ddim_step(v.p, v.C, sample, lat.p, lat.C, off, i == n_steps - 1 ? x0.p : nullptr, x0.C, lat.pixels(), L, k, e->st);
-            e->drop(v);
+        try {
+            for (int i = 0; i < n_steps; ++i) {
+                const gp_ddim_step& s = steps[i];
+                if (s.timestep != e->timestep) e->set_timestep_on_stream(s.timestep);
+                Act v = e->unet(lat, nullptr, true);
+                const DdimCoef k{s.x0_sample, s.x0_model, s.eps_sample, s.eps_model, s.prev_x0, s.prev_eps, s.clip};
+                e->mark("ddim_step");
+                launch_ddim_step(v.p, v.C, sample, lat.p, lat.C, off, i == n_steps - 1 ? x0.p : nullptr, x0.C, lat.pixels(), L, k, e->st);
+                e->drop(v);
+            }
+        } catch (...) {  // a failed step must not leave the loop's timestep behind as the engine's (gp_set_timestep) one
+            if (e->timestep != t_before) {
+                try { e->set_timestep_on_stream(t_before); } catch (...) {}
+            }
+            throw;
         }
         e->pool.release(sample);
         e->drop(lat);
