@@ -15,7 +15,13 @@ inside the timed region, its own cost reported as `gather_ms`.  Rank 0 prints ON
                on the engine's stream in an instrumented pass right after the timed region (events around ~300 launches would perturb
                the timed region itself); `family_*` = the whole implicit-GEMM conv / linear family; `peak` = the nominal 2.5 PFLOP/s,
                `peak_measured` = this chip's own back-to-back-MFMA rate (gp_mfma_peak_tflops) measured in the same run.
-  cpu_baseline the fp32 oracle (oracle/, a restatement: kind "port") timed on the host cores at the benched size: ONE 768x768 image.
+  cpu_baseline the fp32 oracle (oracle/, a restatement: kind "port") timed on the host cores at the benched size: ONE 768x768 image --
+               image 0 of the benched batch, so the same run also reports
+  parity       HIP map vs that fp32 oracle map at the benched size (mean / max |delta| on [0,1], AbsRel after the reference's least-squares
+               alignment), for the benched element type and, in `fp16`, for the fp16 library (the build inside north_star's 1e-3), which
+               is timed in the same run: `value_fp16` / `ms_per_step_fp16` (same K steps, same barriers).
+  stages       per-stage times from a pass with FOUR events only (profiling level 1); the per-kernel sums of `roofline` come from a second,
+               per-launch-instrumented pass whose ~500 event pairs cost ~7 % and must not leak into `unet_mfma_util`.
 """
 import argparse
 import json
@@ -52,6 +58,31 @@ def cpu_model() -> str:
     return "unknown"
 
 
+def source_build_id() -> str:
+    """sha1 over the HIP sources + the C-ABI header: what a PMC / profile artefact must carry to count as THIS build's (there is no .git on
+    the GPU box)."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "genpercept_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../../include/genpercept_hip.h"]:
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def parity_vs(ref, out) -> dict:
+    """HIP map vs the fp32 oracle map (both [C,H,W] on the host, values in [0,1]): mean / max |delta| and AbsRel after the reference's
+    least-squares alignment (eval.py protocol: src/util/alignment.py:29-76, metric.py:34-44), channel 0."""
+    import numpy as np
+    from genpercept_amd.eval_metrics import abs_relative_difference, align_depth_least_square
+    r, o = ref.double().numpy(), out.double().numpy()
+    d = np.abs(o - r)
+    gt = r[0].clip(1e-3, None)
+    aligned, _, _ = align_depth_least_square(gt, o[0], np.ones_like(gt, dtype=bool))
+    return {"mean_abs": float(d.mean()), "max_abs": float(d.max()),
+            "absrel_ls": float(abs_relative_difference(np.clip(aligned, 1e-3, None), gt)), "ref": "fp32 oracle (oracle/), image 0 of the benched batch"}
+
+
 def respawn_under_torchrun(n: int):
     """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`."""
     with socket.socket() as s:
@@ -78,6 +109,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the result maps on their GPUs")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-fp16", action="store_true", help="skip the second timed leg with the fp16 library")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -106,47 +138,57 @@ def main():
     t0 = time.time()
     usd = gw.synth_state_dict(gw.unet_manifest(ucfg), seed=0)
     vsd = gw.synth_state_dict(gw.vae_manifest(vcfg), seed=1)
+    dsd = gw.synth_state_dict(gw.dpt_manifest(dcfg), seed=3) if dpt else None
     ctx = torch.randn(2, ucfg.cross_attention_dim, generator=torch.Generator().manual_seed(2))
-    eng = Engine(local_rank, ucfg, vcfg, dcfg, precision=args.precision)
-    eng.load_state_dict("vae", vsd)
-    eng.load_state_dict("unet", usd)
-    if dpt:
-        eng.load_state_dict("dpt", gw.synth_state_dict(gw.dpt_manifest(dcfg), seed=3))
-    eng.set_context(ctx)
-    eng.finalize()
+
+    def build_engine(precision):
+        e = Engine(local_rank, ucfg, vcfg, dcfg, precision=precision)
+        e.load_state_dict("vae", vsd)
+        e.load_state_dict("unet", usd)
+        if dpt:
+            e.load_state_dict("dpt", dsd)
+        e.set_context(ctx)
+        e.finalize()
+        return e
+
+    eng = build_engine(args.precision)
     t_load = time.time() - t0
-    if not (rank == 0 and n_gpus == 1 and not args.no_cpu and not dpt):
-        del usd  # the CPU-baseline leg needs the fp32 weights
 
     n_total = args.batch * n_gpus
     lo, hi = gd.shard_range(n_total, rank, n_gpus)
     rgb = synthetic_rgb(n_total, args.res, 1234, "cpu")[lo:hi].to(dev)
     do_gather = n_gpus > 1 and not args.no_gather
 
-    def step():
-        out = eng.infer(rgb, args.mode)
-        if do_gather:
-            return gd.gather_results(out, n_total, dst=0)  # rank 0: [N*B, C, H, W]; others: None
-        return out
+    def timed(engine):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        def step():
+            o = engine.infer(rgb, args.mode)
+            if do_gather:
+                return gd.gather_results(o, n_total, dst=0)  # rank 0: [N*B, C, H, W]; others: None
+            return o
+        o = None
+        for _ in range(args.warmup):
+            o = step()
+        torch.cuda.synchronize()
+        gd.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            o = step()
+        torch.cuda.synchronize()
+        gd.barrier()
+        el = gd.max_over_ranks(time.perf_counter() - t0, dev)
+        if o is not None:
+            assert torch.isfinite(o).all()
+            if do_gather:
+                assert o.shape[0] == n_total
+        return el, o
 
-    for _ in range(args.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    gd.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    gd.barrier()
-    elapsed = gd.max_over_ranks(time.perf_counter() - t0, dev)
+    elapsed, out = timed(eng)
     ms_per_step = elapsed / args.steps * 1e3
     images = n_total * args.steps
     value = images / elapsed
-    if out is not None:
-        assert torch.isfinite(out).all()
-        if do_gather:
-            assert out.shape[0] == n_total
+    out0 = out[0].float().cpu() if (out is not None and rank == 0) else None  # image 0 of the benched batch: the parity sample
 
     gather_ms = None
     if do_gather:  # the gather alone (same tensors), max over ranks
@@ -162,7 +204,11 @@ def main():
     roofline = None
     stages = None
     if not args.no_profile:
-        eng.set_profile(2)
+        eng.set_profile(1)  # four events per pass: the stage times are not perturbed by per-launch instrumentation
+        eng.reset_timings()
+        eng.infer(rgb, args.mode)
+        tm1 = eng.timings()
+        eng.set_profile(2)  # an event pair around every conv / GEMM / attention launch: their summed durations
         eng.reset_timings()
         eng.infer(rgb, args.mode)
         tm = eng.timings()
@@ -172,13 +218,19 @@ def main():
         if tm["ms_halo"] > 0:
             ach = tm["flops_halo"] / (tm["ms_halo"] * 1e-3) / 1e12
             fam = tm["flops_igemm"] / (tm["ms_igemm"] * 1e-3) / 1e12
-            traffic, traffic_note = None, "not collected for this build (tools/gpu_pmc_traffic.sh writes profiles/r02_pmc_traffic_summary.json)"
-            try:  # PMC passes of THIS round's build, if they were taken (separate --pmc runs; FETCH_SIZE doubled on gfx950)
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_summary.json")))
-                sel = lambda d: sum(v["sum_kb"] for k, v in d.items() if "conv3x3_halo3" in k)  # noqa: E731
-                nd = sum(v["dispatches"] for k, v in tj["FETCH_SIZE"].items() if "conv3x3_halo3" in k)
-                traffic = round((2.0 * sel(tj["FETCH_SIZE"]) + sel(tj["WRITE_SIZE"])) * 1024.0 / max(nd, 1))
-                traffic_note = f"HBM bytes per launch, PMC (2*FETCH_SIZE + WRITE_SIZE), build {tj.get('commit', '?')}, profiles/r02_pmc_traffic_summary.json"
+            # HBM traffic of the dominant kernel: PMC passes (separate --pmc runs; FETCH_SIZE doubled on gfx950) are a different command
+            # (tools/gpu_pmc_traffic.sh); their summary counts only when it was taken from THESE sources (build id = sha1 of csrc/)
+            bid = source_build_id()
+            traffic, traffic_note = None, f"null: no PMC summary of this build ({bid}) under profiles/ (tools/gpu_pmc_traffic.sh collects it)"
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_summary.json")))
+                if tj.get("build_id") == bid:
+                    sel = lambda d: sum(v["sum_kb"] for k, v in d.items() if "conv3x3_halo3" in k)  # noqa: E731
+                    nd = sum(v["dispatches"] for k, v in tj["FETCH_SIZE"].items() if "conv3x3_halo3" in k)
+                    traffic = round((2.0 * sel(tj["FETCH_SIZE"]) + sel(tj["WRITE_SIZE"])) * 1024.0 / max(nd, 1))
+                    traffic_note = f"HBM bytes per launch, PMC (2*FETCH_SIZE + WRITE_SIZE), same build ({bid}), profiles/r03_pmc_traffic_summary.json"
+                else:
+                    traffic_note = f"null: profiles/r03_pmc_traffic_summary.json is of build {tj.get('build_id')}, this is {bid}"
             except Exception:
                 pass
             roofline = {"bound": "mfma", "kernel": f"conv3x3_halo3_kernel (3x3 stride-1 convs of the large maps, v_mfma_f32_16x16x32_{'f16' if args.precision == 'fp16' else 'bf16'})",
@@ -194,25 +246,55 @@ def main():
                         "attn_achieved": round(tm["flops_attn"] / max(tm["ms_attn"], 1e-9) / 1e9, 2), "attn_launches": tm["n_attn"],
                         "pipeline_achieved": round(TFLOP_PER_IMAGE_768 * scale * args.batch / (ms_per_step * 1e-3), 2),
                         "pipeline_frac": round(TFLOP_PER_IMAGE_768 * scale * args.batch / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4)}
-        stages = {"ms_encode": round(tm["ms_encode"], 3), "ms_unet": round(tm["ms_unet"], 3), "ms_head": round(tm["ms_head"], 3),
+        stages = {"ms_encode": round(tm1["ms_encode"], 3), "ms_unet": round(tm1["ms_unet"], 3), "ms_head": round(tm1["ms_head"], 3),
+                  "ms_unet_per_launch_instrumented": round(tm["ms_unet"], 3),
                   "ms_igemm_sum": round(tm["ms_igemm"], 3), "ms_attn_sum": round(tm["ms_attn"], 3), "kernel_launches": tm["n_launches"],
                   # executed conv / linear / attention flops; below SURVEY's 10.50 because the 2-token cross-attention is folded (F6)
                   "executed_tflop_per_image": round((tm["flops_igemm"] + tm["flops_attn"]) / 1e12 / args.batch, 3),
                   # second half of BASELINE.json's metric: UNet stage alone, 2.137 ALGORITHMIC TFLOP per 768x768 image
-                  "unet_mfma_util": round(2.137 * (args.res / 768.0) ** 2 * args.batch / (max(tm["ms_unet"], 1e-9) * 1e-3) / PEAK_BF16_TFLOPS, 4)}
+                  "unet_mfma_util": round(2.137 * (args.res / 768.0) ** 2 * args.batch / (max(tm1["ms_unet"], 1e-9) * 1e-3) / PEAK_BF16_TFLOPS, 4)}
+
+    # ---- second timed leg: the fp16 library (the build that meets north_star's 1e-3), same steps / barriers ---------------------------
+    fp16 = None
+    out0_f16 = None
+    if args.precision == "bf16" and not args.no_fp16:
+        eng.close()
+        eng = build_engine("fp16")
+        el16, o16 = timed(eng)
+        if o16 is not None and rank == 0:
+            out0_f16 = o16[0].float().cpu()
+        fp16 = {"value_fp16": round(images / el16, 3), "ms_per_step_fp16": round(el16 / args.steps * 1e3, 3)}
+        if not args.no_profile:
+            eng.set_profile(1)
+            eng.reset_timings()
+            eng.infer(rgb, args.mode)
+            t16 = eng.timings()
+            eng.set_profile(0)
+            fp16["stages_fp16"] = {"ms_encode": round(t16["ms_encode"], 3), "ms_unet": round(t16["ms_unet"], 3), "ms_head": round(t16["ms_head"], 3)}
 
     cpu = None
+    parity = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu and not dpt:
-        from oracle import pipeline as opipe  # CPU baseline leg only
+        from oracle import pipeline as opipe  # CPU baseline leg only: the oracle is the checker and the reported baseline, never the product
         from oracle import sd21 as osd
         nthr = max(1, min(os.cpu_count(), args.cpu_threads))
         torch.set_num_threads(nthr)
         r = args.cpu_res
-        x = opipe.normalize_rgb(synthetic_rgb(1, r, 99, "cpu"))
+        same = r == args.res
+        x = opipe.normalize_rgb(synthetic_rgb(n_total, r, 1234, "cpu")[:1] if same else synthetic_rgb(1, r, 99, "cpu"))
         with torch.no_grad():
             t0 = time.perf_counter()
             ref = opipe.single_infer(vsd, osd.VAECfg(), usd, osd.UNetCfg(), x, ctx, args.mode)
             dt = time.perf_counter() - t0
+        if same and out0 is not None:  # the map just timed on the GPU against the map just timed on the CPU: same image, same weights
+            parity = {args.precision: parity_vs(ref[0], out0), "tolerance": "north_star: within 1e-3 (mean |delta| on [0,1] maps)"}
+            parity[args.precision]["within_1e-3"] = parity[args.precision]["mean_abs"] <= 1e-3
+            if out0_f16 is not None:
+                parity["fp16"] = parity_vs(ref[0], out0_f16)
+                parity["fp16"]["within_1e-3"] = parity["fp16"]["mean_abs"] <= 1e-3
+            if not parity[args.precision]["within_1e-3"]:
+                parity["note"] = (f"the {args.precision} value is OUTSIDE north_star's tolerance (bf16 MFMA operands floor at ~2.3e-3, "
+                                  "DESIGN.md section 4); value_fp16 is the number of the build that meets it")
         cpu = {"value": round(1.0 / dt, 5), "unit": f"images/sec at {r}x{r} fp32", "cores": nthr, "cpu_model": cpu_model(), "kind": "port",
                "sample": f"1 image {r}x{r} ({TFLOP_PER_IMAGE_768 * (r / 768.0) ** 2:.3f} TFLOP), torch-CPU fp32 restatement of the diffusers path "
                          f"(oracle/), timed directly at this size: {dt:.1f} s",
@@ -233,7 +315,9 @@ def main():
                                           (", result maps gathered to rank 0 over RCCL inside the step)" if do_gather else ")"),
                            "gather_ms": gather_ms,
                            "weights": "random-init SD2.1 architecture (865.9M + 83.7M params)", "load_s": round(t_load, 1)},
-                "roofline": roofline, "cpu_baseline": cpu, "stages": stages}
+                "roofline": roofline, "cpu_baseline": cpu, "stages": stages, "parity": parity}
+        if fp16:
+            line.update(fp16)
         print(json.dumps(line), flush=True)
     eng.close()
     if world > 1:

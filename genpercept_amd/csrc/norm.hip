@@ -1,5 +1,7 @@
 // GroupNorm(+SiLU) and LayerNorm for NHWC bf16 activations (K7/K8 of SURVEY.md §2.3).  HBM-bound: every kernel moves
 // 16 bytes per lane per access, statistics in fp32, deterministic (no atomics).
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -235,9 +237,78 @@ void launch_groupnorm_stats(const h16_t* x, const float* gamma, const float* bet
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, (const float*)ws, gamma, beta, scale, shift, HW, C, G, nchunk, eps);
 }
 
+// r3: the same pass with a fixed 8-channel vector per thread.  gn_apply_kernel above spent its time on a 64-bit modulo and sixteen 4-byte LDS
+// reads per 16 bytes moved (2.6 TB/s on the 300 MB tensors of the VAE, 5.6 % of a pass); here a thread keeps scale / shift of ITS eight
+// channels in registers, a workgroup covers R = 256 / (C / 8) consecutive pixels per step (a contiguous 4 KiB of the NHWC tensor) and
+// four steps' loads are in flight before the first one is used.  C / 8 > 256 (C = 2560): the vectors are walked in blocks of 256.
+template <int SILU>
+__global__ __launch_bounds__(256) void gn_apply2_kernel(const h16_t* __restrict__ x, h16_t* __restrict__ y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int HW, int C, int nchunk, int tpr, int R) {
+    const int b = blockIdx.y, ck = blockIdx.x, tid = threadIdx.x;
+    const int nvec = C >> 3;
+    const int r = tid / tpr, v0 = tid - r * tpr;
+    if (r >= R) return;
+    const int per = (HW + nchunk - 1) / nchunk;
+    const int p0 = ck * per, p1 = min(HW, p0 + per);
+    const long long base = (long long)b * HW * C;
+    for (int v = v0; v < nvec; v += 256) {
+        float sc[8], sh[8];
+        {
+            const float4* sp = (const float4*)(scale + (long long)b * C + v * 8);
+            const float4* hp = (const float4*)(shift + (long long)b * C + v * 8);
+            const float4 s0 = sp[0], s1 = sp[1], h0 = hp[0], h1 = hp[1];
+            sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+            sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+        }
+        const h16_t* xp = x + base + v * 8;
+        h16_t* yp = y + base + v * 8;
+        for (int p = p0 + r; p < p1; p += 4 * R) {
+            uint4 raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pp = p + u * R;
+                raw[u] = pp < p1 ? *(const uint4*)(xp + (long long)pp * C) : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pp = p + u * R;
+                if (pp >= p1) break;
+                const unsigned w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+                float o[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    o[2 * k] = __builtin_fmaf(h16_lo(w[k]), sc[2 * k], sh[2 * k]);
+                    o[2 * k + 1] = __builtin_fmaf(h16_hi(w[k]), sc[2 * k + 1], sh[2 * k + 1]);
+                }
+                if (SILU) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = silu_f(o[k]);
+                }
+                uint4 q;
+                q.x = pack_h16x2(o[0], o[1]); q.y = pack_h16x2(o[2], o[3]); q.z = pack_h16x2(o[4], o[5]); q.w = pack_h16x2(o[6], o[7]);
+                *(uint4*)(yp + (long long)pp * C) = q;
+            }
+        }
+    }
+}
+
 void launch_groupnorm_apply(const h16_t* x, h16_t* y, const float* scale, const float* shift, int B, int HW, int C, int silu, hipStream_t s) {
-    const int nchunk = gn_nchunk(HW);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(256), (size_t)2 * C * sizeof(float), s, x, y, scale, shift, HW, C, nchunk, silu);
+    static const bool old_kernel = getenv("GENPERCEPT_GN_APPLY_OLD") != nullptr;  // A/B switch
+    if (old_kernel) {
+        const int nchunk = gn_nchunk(HW);
+        hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(256), (size_t)2 * C * sizeof(float), s, x, y, scale, shift, HW, C, nchunk, silu);
+        return;
+    }
+    const int nvec = C >> 3;
+    const int tpr = nvec < 256 ? nvec : 256;   // threads per pixel row
+    const int R = 256 / tpr;                   // pixel rows per workgroup step
+    // workgroups per image: ~8 per CU over the batch, at least 4 * R pixels each (one unrolled step)
+    int nchunk = HW / (4 * R);
+    const int cap = (2048 + B - 1) / B;
+    if (nchunk > cap) nchunk = cap;
+    if (nchunk < 1) nchunk = 1;
+    if (silu) hipLaunchKernelGGL(gn_apply2_kernel<1>, dim3(nchunk, B), dim3(256), 0, s, x, y, scale, shift, HW, C, nchunk, tpr, R);
+    else hipLaunchKernelGGL(gn_apply2_kernel<0>, dim3(nchunk, B), dim3(256), 0, s, x, y, scale, shift, HW, C, nchunk, tpr, R);
 }
 
 // ws: >= groupnorm_ws_floats() + 2*B*C floats (partials, then scale, then shift)

@@ -37,12 +37,17 @@ def resize_to(img: torch.Tensor, size, mode: str) -> torch.Tensor:
     return _interp(img, size, mode)
 
 
+def resize_max_res_size(h: int, w: int, max_edge_resolution: int):
+    """The size rule of resize_max_res alone (image_util.py:95-100): keep aspect ratio, longest edge -> max_edge_resolution, int() truncation."""
+    f = min(max_edge_resolution / w, max_edge_resolution / h)
+    return int(h * f), int(w * f)
+
+
 def resize_max_res(img: torch.Tensor, max_edge_resolution: int, resample_method: str = "bilinear") -> torch.Tensor:
     """image_util.py:75-105: keep aspect ratio, longest edge -> max_edge_resolution, int() truncation of the new size."""
     assert img.dim() == 4, f"Invalid input shape {img.shape}"
     h, w = img.shape[-2:]
-    f = min(max_edge_resolution / w, max_edge_resolution / h)
-    return resize_to(img, (int(h * f), int(w * f)), resample_method)
+    return resize_to(img, resize_max_res_size(int(h), int(w), max_edge_resolution), resample_method)
 
 
 def colorize_depth_maps(depth_map: np.ndarray, min_depth: float, max_depth: float, cmap: str = "Spectral") -> np.ndarray:

@@ -192,6 +192,9 @@ class GenPerceptPipeline:
         # most precise build (final maps within 1e-3 of the fp32 path)
         from .engine import precision_of
         self._precision = precision_of(torch_dtype)
+        # dtype single_infer draws marigold's initial noise in (genpercept_pipeline.py:416-420: torch.randn(..., dtype=self.dtype)): the dtype the
+        # caller asked for (run.py:273-281: fp32 unless --half_precision), the engine's element type when none was given
+        self._noise_dtype = torch_dtype if torch_dtype is not None else torch.float32  # (diffusers loads fp32 modules when no torch_dtype is given)
         self._timestep = None
         self._device = torch.device("cuda", 0) if device is None else torch.device(device if not isinstance(device, int) else f"cuda:{device}")
         self.mode = None
@@ -216,6 +219,20 @@ class GenPerceptPipeline:
         for name in ("unet", "vae"):
             if kw.get(name) is None:
                 kw[name] = os.path.join(checkpoint, name)
+        # DiffusionPipeline.from_pretrained fills every module the caller did not pass from the checkpoint's own sub-folders: run.py leaves
+        # `scheduler` unset for archs marigold / rgb_blending (run.py:361-368) and relies on <checkpoint>/scheduler/scheduler_config.json
+        if kw.get("scheduler") is None and os.path.isfile(os.path.join(checkpoint, "scheduler", "scheduler_config.json")):
+            from .scheduler import DDIMSchedulerCustomized
+            kw["scheduler"] = DDIMSchedulerCustomized.from_pretrained(checkpoint, subfolder="scheduler")
+        # ... and the registered config values (register_to_config, genpercept_pipeline.py:128-132) from model_index.json
+        mi = os.path.join(checkpoint, "model_index.json")
+        if os.path.isfile(mi):
+            import json
+            with open(mi) as fh:
+                idx = json.load(fh)
+            for key in ("default_denoising_steps", "default_processing_resolution", "rgb_blending"):
+                if key in idx and idx[key] is not None:
+                    kw.setdefault(key, idx[key])
         if kw.get("text_encoder") is None and os.path.isdir(os.path.join(checkpoint, "text_encoder")):
             from transformers import CLIPTextModel, CLIPTokenizer
             kw["text_encoder"] = CLIPTextModel.from_pretrained(os.path.join(checkpoint, "text_encoder"))
@@ -236,6 +253,7 @@ class GenPerceptPipeline:
             if self._engine is not None and precision_of(dt) != self._precision:
                 raise RuntimeError("the engine is already built with " + self._precision + " elements")
             self._precision = precision_of(dt)
+            self._noise_dtype = dt
         return self
 
     @property
@@ -307,7 +325,13 @@ class GenPerceptPipeline:
         if self._ctx_loaded is not self.text_embed:
             eng.set_context(self.text_embed)
             self._ctx_loaded = self.text_embed
-        t = int(fix_timesteps) if fix_timesteps else 1  # set_timesteps(1) => [1] (leading spacing, steps_offset 1)
+        if fix_timesteps:
+            t = int(fix_timesteps)
+        elif self.scheduler is not None:  # genpercept_pipeline.py:403: scheduler.set_timesteps(1) -- [1] for the shipped config (leading
+            self.scheduler.set_timesteps(1)  # spacing, steps_offset 1), 999 for trailing spacing, 0 for steps_offset 0 / linspace
+            t = int(self.scheduler.timesteps[0])
+        else:
+            t = 1
         if t != self._timestep:
             eng.set_timestep(t)
             self._timestep = t
@@ -322,7 +346,8 @@ class GenPerceptPipeline:
             assert num_inference_steps == 1, "GenPercept only forward once."
         rgb_in = rgb_in.to(self._device)
         mode = self.mode or "depth"
-        if self.genpercept_pipeline and self._x0_is_neg_v:
+        # the DPT-head branch never consults scheduler.step (:474-482: one UNet feature pass, then the head), whatever its prediction type
+        if self.genpercept_pipeline and (self._x0_is_neg_v or self.customized_head is not None):
             return self._prepare(fix_timesteps, prompt).infer(rgb_in, mode)
         # the denoising loop (:447-465): the scheduler becomes one affine update per step, the loop itself runs in the engine
         eng = self._prepare(None, prompt)
@@ -332,7 +357,8 @@ class GenPerceptPipeline:
             lh, lw = eng.lib.gp_latent_size(rgb_in.shape[-2]), eng.lib.gp_latent_size(rgb_in.shape[-1])
             shape = (rgb_in.shape[0], self.vae_config.latent_channels, lh, lw)
             gdev = generator.device if generator is not None else self._device
-            noise = torch.randn(shape, device=gdev, dtype=torch.float32, generator=generator).to(self._device)
+            # drawn in the pipeline's dtype like the reference (:416-420): a half-precision run consumes the generator differently from fp32
+            noise = torch.randn(shape, device=gdev, dtype=self._noise_dtype, generator=generator).to(device=self._device, dtype=torch.float32)
         return eng.infer_steps(rgb_in, mode, plan, noise)
 
     @torch.no_grad()
@@ -365,11 +391,6 @@ class GenPerceptPipeline:
         else:
             self._check_inference_step(denoising_steps)
         resample = get_resample_method(resample_method)
-        # genpercept_pipeline.py:264-270: batch size of the ensemble loader (always 1 on the one-step path: ensemble_size == 1)
-        if batch_size <= 0:
-            batch_size = find_batch_size(ensemble_size=ensemble_size, input_res=max(int(processing_res), 1), dtype=self.dtype)
-        assert batch_size >= 1
-
         if isinstance(input_image, Image.Image):
             arr = np.asarray(input_image.convert("RGB"))
             rgb = torch.from_numpy(arr.copy()).permute(2, 0, 1).unsqueeze(0)  # [1, rgb, H, W] uint8
@@ -379,6 +400,15 @@ class GenPerceptPipeline:
             raise TypeError(f"Unknown input type: {type(input_image) = }")
         input_size = rgb.shape
         assert 4 == rgb.dim() and 3 == input_size[-3], f"Wrong input shape {input_size}, expected [1, rgb, H, W]"
+        # genpercept_pipeline.py:258-266: batch size of the ensemble loader from the longest edge of the RESIZED image, max(rgb_norm.shape[1:])
+        # (always 1 on the one-step path: ensemble_size == 1)
+        if batch_size <= 0:
+            h, w = int(input_size[-2]), int(input_size[-1])
+            if processing_res > 0:
+                from .image_util import resize_max_res_size
+                h, w = resize_max_res_size(h, w, int(processing_res))
+            batch_size = find_batch_size(ensemble_size=ensemble_size, input_res=max(3, h, w), dtype=self._noise_dtype)
+        assert batch_size >= 1
         opts = dict(steps=int(denoising_steps), ensemble_size=int(ensemble_size), batch_size=int(batch_size), generator=generator,
                     ensemble_kwargs=ensemble_kwargs)
         outs = self._run(rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt, opts)

@@ -654,3 +654,31 @@ def test_dpt_head_more_than_64_images(eng_dpt, golden):
     # (70 images vs 1: the launchers pick other tiles / split-K factors for the other M, so the accumulation order -- not the math -- differs)
     alone = eng_dpt.infer(rgb[69:70], "disparity")
     assert float((alone - out[69:70]).abs().mean()) <= 2 * TOLS[eng_dpt.precision]["map_mean"]
+
+
+def test_modes_seg_matting_dis_on_the_gpu(eng_vae, tiny_weights, golden, metric_log):
+    """genpercept_pipeline.py:199,523-525: `seg` keeps the three decoder channels like `normal`, `matting` and `dis` average them like
+    `depth` -- the same decode, so the engine's maps must be bit-equal to the normal / depth ones, through gp_infer and through
+    GenPerceptPipeline.__call__ (these modes were mapped but never run on the GPU)."""
+    d = torch.device("cuda", 0)
+    rgb = torch.as_tensor(golden["sq_rgb_u8"]).to(d)
+    dep, nrm = eng_vae.infer(rgb, "depth"), eng_vae.infer(rgb, "normal")
+    assert torch.equal(eng_vae.infer(rgb, "seg"), nrm) and eng_vae.infer(rgb, "seg").shape[1] == 3
+    for m in ("matting", "dis"):
+        o = eng_vae.infer(rgb, m)
+        assert o.shape[1] == 1 and torch.equal(o, dep), m
+    from genpercept_amd import GenPerceptPipeline
+    pipe = GenPerceptPipeline(unet=tiny_weights["usd"], vae=tiny_weights["vsd"], text_encoder=golden["sq_ctx"], tokenizer=None,
+                              torch_dtype=torch.float16 if eng_vae.precision == "fp16" else torch.bfloat16)
+    try:
+        img = torch.as_tensor(golden["sq_rgb_u8"])[:1]
+        outs = {m: pipe(img, processing_res=0, mode=m, color_map=None) for m in ("depth", "normal", "seg", "matting", "dis")}
+        assert outs["seg"].pred_np.shape == outs["normal"].pred_np.shape and outs["seg"].pred_np.ndim == 3 and outs["seg"].pred_np.shape[-1] == 3
+        assert np.array_equal(outs["seg"].pred_np, outs["normal"].pred_np)
+        for m in ("matting", "dis"):
+            assert outs[m].pred_np.ndim == 2 and np.array_equal(outs[m].pred_np, outs["depth"].pred_np), m
+        with pytest.raises(AssertionError):  # genpercept_pipeline.py:318: a colour map is only legal for depth / disparity
+            pipe(img, processing_res=0, mode="seg", color_map="Spectral")
+    finally:
+        if pipe._engine is not None:
+            pipe._engine.close()

@@ -252,3 +252,64 @@ def test_pipeline_multistep_plumbing_without_gpu(monkeypatch):
     assert p2._engine.calls[0][0] == "steps" and p2._engine.calls[0][3] == [1.0] and p2._engine.calls[0][4] is None
     with pytest.raises(AssertionError):
         p2(img, denoising_steps=2, mode="depth")
+
+
+def test_from_pretrained_picks_up_the_checkpoints_scheduler_and_model_index(tmp_path):
+    """run.py:361-368 leaves `scheduler` unset for archs marigold / rgb_blending: DiffusionPipeline.from_pretrained then loads
+    <checkpoint>/scheduler, and the registered defaults (genpercept_pipeline.py:128-132) come from model_index.json."""
+    import json
+    from genpercept_amd import GenPerceptPipeline
+    ck = tmp_path / "ckpt"
+    (ck / "scheduler").mkdir(parents=True)
+    cfg = dict(_class_name="DDIMScheduler", beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+               set_alpha_to_one=False, steps_offset=1, prediction_type="v_prediction", timestep_spacing="trailing")
+    (ck / "scheduler" / "scheduler_config.json").write_text(json.dumps(cfg))
+    (ck / "model_index.json").write_text(json.dumps({"_class_name": "GenPerceptPipeline", "default_denoising_steps": 4,
+                                                     "default_processing_resolution": 512, "rgb_blending": True}))
+    pipe = GenPerceptPipeline.from_pretrained(str(ck), unet={}, vae={}, text_encoder=np.zeros((2, 8), np.float32), genpercept_pipeline=False)
+    assert pipe.scheduler is not None and pipe.scheduler.config.timestep_spacing == "trailing" and pipe.scheduler.config.beta_end == 0.012
+    assert pipe.default_denoising_steps == 4 and pipe.default_processing_resolution == 512 and pipe.rgb_blending is True
+    # explicit keywords win over model_index.json; the one-step pipeline still forces steps = 1 (genpercept_pipeline.py:115-117)
+    p2 = GenPerceptPipeline.from_pretrained(str(ck), unet={}, vae={}, text_encoder=np.zeros((2, 8), np.float32), default_processing_resolution=640)
+    assert p2.default_processing_resolution == 640 and p2.default_denoising_steps == 1
+    # without a scheduler folder the multi-step archs still refuse to build
+    ck2 = tmp_path / "bare"
+    ck2.mkdir()
+    with pytest.raises(ValueError):
+        GenPerceptPipeline.from_pretrained(str(ck2), unet={}, vae={}, text_encoder=np.zeros((2, 8), np.float32), genpercept_pipeline=False)
+
+
+def test_pipeline_host_semantics_follow_the_reference(monkeypatch):
+    """genpercept_pipeline.py:262-266 (batch size from the RESIZED image), :403 (the UNet timestep comes from scheduler.set_timesteps(1)),
+    :416-420 (noise drawn in the pipeline's dtype), :474-482 (the DPT-head branch never consults scheduler.step)."""
+    import genpercept_amd.pipeline as gp
+    img = torch.randint(0, 256, (1, 3, 64, 80), dtype=torch.uint8)
+    b11 = dict(beta_start=1.0, beta_end=1.0, beta_schedule="linear", prediction_type="v_prediction", clip_sample=False, steps_offset=1)
+    # timestep of the one-step path: leading + offset 1 -> 1; trailing -> 999; offset 0 -> 0
+    for extra, want in ((dict(), 1), (dict(timestep_spacing="trailing"), 999), (dict(steps_offset=0), 0)):
+        p = _fake_pipe(monkeypatch, scheduler=dict(b11, **extra))
+        p._timestep = -1
+        p(img, processing_res=0, mode="depth", color_map=None)
+        assert p._engine.calls == [("infer", (1, 3, 64, 80), "depth", want)], (extra, p._engine.calls)
+    # half-precision marigold draws its noise in fp16 (then widened), fp32 pipelines in fp32
+    sched = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False, steps_offset=1,
+                 prediction_type="v_prediction")
+    for dt in (torch.float16, torch.float32, None):
+        p = _fake_pipe(monkeypatch, scheduler=sched, genpercept_pipeline=False, rgb_blending=False, torch_dtype=dt)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            p(img, denoising_steps=2, processing_res=0, generator=torch.Generator().manual_seed(3), mode="depth", color_map=None)
+        want = torch.randn((1, 4, 8, 10), generator=torch.Generator().manual_seed(3), dtype=dt or torch.float32).float()
+        assert torch.equal(p._engine.calls[0][4], want) and p._engine.calls[0][4].dtype == torch.float32
+    # find_batch_size sees the longest edge AFTER resize_max_res, not processing_res
+    seen = []
+    monkeypatch.setattr(gp, "find_batch_size", lambda ensemble_size, input_res, dtype=None: seen.append((ensemble_size, input_res, dtype)) or 1)
+    p = _fake_pipe(monkeypatch, scheduler=b11)
+    p(torch.randint(0, 256, (1, 3, 100, 50), dtype=torch.uint8), processing_res=32, mode="depth", color_map=None)
+    p(torch.randint(0, 256, (1, 3, 40, 56), dtype=torch.uint8), processing_res=0, mode="depth", color_map=None)
+    assert [s[:2] for s in seen] == [(1, 32), (1, 56)] and seen[0][2] == torch.float32
+    # a customized head routes to the one-step engine call whatever the scheduler's prediction type (ADVICE r2)
+    p = _fake_pipe(monkeypatch, scheduler=dict(b11, prediction_type="epsilon", clip_sample=True), customized_head={"neck.fusion_stage.x": torch.zeros(1)},
+                   head_type="identity")
+    p(img, processing_res=0, mode="disparity", color_map=None)
+    assert p._engine.calls[0][0] == "infer"
