@@ -539,8 +539,7 @@ long long flash_attn512_workspace_floats(int B, int T, int ncu) {
 void launch_flash_attn512(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t* out, float* ws, int B, int T, int ldq,
                           int ldk, int Tpad, int ldo, float scale, int ncu, hipStream_t s) {
     static unsigned long long attr_mask = 0;
-    if (gp_first_use_on_device(&attr_mask))
-        (void)hipFuncSetAttribute((const void*)flash_attn512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F5_LDS);
+    gp_once_per_device(&attr_mask, [&] { (void)hipFuncSetAttribute((const void*)flash_attn512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F5_LDS); });
     const int nqb = (T + 127) / 128, nblocks = B * nqb, G = flash512_grid(nblocks, ncu, T);
     const int rounds = nblocks / G, L = nblocks - rounds * G, S = L ? G / L : 0;
     float* part_o = ws;

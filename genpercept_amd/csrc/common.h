@@ -134,6 +134,24 @@ typedef __attribute__((address_space(3))) f32x4_t* lds_f4_ptr;
 typedef __attribute__((address_space(3))) float* lds_f_ptr;
 GP_DEV h16x8_t lds_frag(unsigned base, int imm) { return *(lds_frag_ptr)(base + (unsigned)imm); }
 
+// Sum over the 64 lanes of a wave, result uniform (an SGPR broadcast to every lane).  Pure VALU: four DPP adds inside each row of 16 lanes
+// (xor 1, xor 2, half-mirror, mirror: after each step the paired groups already hold equal values, so any pairing of the groups works), two
+// row-broadcast adds across the four rows, one v_readlane of lane 63.  `__shfl_xor` butterflies compile to ds_bpermute_b32 + s_waitcnt each:
+// 216 serialized LDS round trips per four rows in cross_fold_kernel (r3: that chain, not memory, bound the kernel).
+template <int CTRL, int ROW_MASK>
+GP_DEV float dpp_move(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, true));
+}
+GP_DEV float wave_sum(float x) {
+    x += dpp_move<0xB1, 0xf>(x);   // quad_perm [1,0,3,2]
+    x += dpp_move<0x4E, 0xf>(x);   // quad_perm [2,3,0,1]
+    x += dpp_move<0x141, 0xf>(x);  // row_half_mirror
+    x += dpp_move<0x140, 0xf>(x);  // row_mirror: every lane of a row holds the row's sum
+    x += dpp_move<0x142, 0xa>(x);  // row_bcast15 into rows 1 and 3
+    x += dpp_move<0x143, 0xc>(x);  // row_bcast31 into rows 2 and 3: lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
 // one group of the scheduler's instruction pattern (masks: 0x002 VALU, 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x400 transcendental)
 template <int MASK, int N>
 GP_DEV void sgb() { __builtin_amdgcn_sched_group_barrier(MASK, N, 0); }

@@ -858,8 +858,9 @@ bool conv_halo_applicable(const IGemmParams& p) {
 template <bool UPS, int FUSED, int ABL>
 static void launch_halo3_one(const IGemmParams& p, int grid, hipStream_t s) {
     static unsigned long long attr_mask = 0;
-    if (gp_first_use_on_device(&attr_mask))
+    gp_once_per_device(&attr_mask, [&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<UPS, FUSED, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo3Geom<UPS>::LDS);
+    });
     hipLaunchKernelGGL((conv3x3_halo3_kernel<UPS, FUSED, ABL>), dim3(grid), dim3(512), Halo3Geom<UPS>::LDS, s, p);
 }
 
@@ -915,10 +916,10 @@ void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
     const int tiles_n = (ncols + 127) / 128, tiles_sp = ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
     const int ncu = halo_ncu();
     static unsigned long long attr_mask = 0;
-    if (gp_first_use_on_device(&attr_mask)) {
+    gp_once_per_device(&attr_mask, [&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<false>::LDS);
         (void)hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<true>::LDS);
-    }
+    });
     // (conv_halo_applicable guarantees whole 128-row weight tiles)
     if (halo_persistent(p)) {
         launch_halo3(p, p.B * halo3_wgs_per_image(p, ncu), s);

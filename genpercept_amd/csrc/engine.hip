@@ -149,7 +149,7 @@ struct ResW {
 };
 struct TfW {
     NormW gn, ln1, ln2, ln3;
-    PackedW proj_in, qk, v, o1, q2, o2, ff1, ff2, proj_out;
+    PackedW proj_in, qkv, qk, v, o1, q2, o2, ff1, ff2, proj_out;  // qk / v: views of qkv's rows [0, 2C) / [2C, 3C)
     float* kc = nullptr;  // folded cross-attention keys / values [L][C] fp32
     float* vc = nullptr;
     std::vector<float> wk_h, wv_h;  // attn2.to_k / to_v [C][D]
@@ -277,25 +277,29 @@ struct gp_engine {
     }
     // two linear layers stacked along the output dimension ([Wa; Wb]), optional biases
     // (scale_a multiplies the first layer's weight and bias: the softmax scale of an attention folded into its query projection)
-    PackedW pack_stacked(const std::string& a, const std::string& b, float scale_a = 1.f) {
-        const HostTensor& wa = H(a + ".weight");
-        const HostTensor& wb = H(b + ".weight");
-        const int ca = (int)wa.shape[0], cb = (int)wb.shape[0], cin = (int)(wa.numel() / ca);
-        std::vector<float> w((size_t)(ca + cb) * cin);
-        memcpy(w.data(), wa.v.data(), (size_t)ca * cin * 4);
-        memcpy(w.data() + (size_t)ca * cin, wb.v.data(), (size_t)cb * cin * 4);
-        std::vector<float> bias;
-        if (has(a + ".bias")) {
-            bias.resize(ca + cb);
-            memcpy(bias.data(), H(a + ".bias").v.data(), ca * 4);
-            memcpy(bias.data() + ca, H(b + ".bias").v.data(), cb * 4);
+    PackedW pack_stacked(const std::vector<std::string>& names, float scale_first = 1.f) {
+        const int cin = (int)(H(names[0] + ".weight").numel() / H(names[0] + ".weight").shape[0]);
+        int ctot = 0;
+        for (auto& n : names) ctot += (int)H(n + ".weight").shape[0];
+        std::vector<float> w((size_t)ctot * cin), bias;
+        const bool with_bias = has(names[0] + ".bias");
+        if (with_bias) bias.resize(ctot);
+        int row = 0;
+        for (size_t k = 0; k < names.size(); ++k) {
+            const HostTensor& wk = H(names[k] + ".weight");
+            const int ck = (int)wk.shape[0];
+            if ((int)(wk.numel() / ck) != cin) throw std::invalid_argument("stacked projections must share their input width");
+            memcpy(w.data() + (size_t)row * cin, wk.v.data(), (size_t)ck * cin * 4);
+            if (with_bias) memcpy(bias.data() + row, H(names[k] + ".bias").v.data(), (size_t)ck * 4);
+            if (k == 0 && scale_first != 1.f) {
+                for (size_t i = 0; i < (size_t)ck * cin; ++i) w[i] *= scale_first;
+                for (int i = 0; i < ck && with_bias; ++i) bias[i] *= scale_first;
+            }
+            row += ck;
         }
-        if (scale_a != 1.f) {
-            for (size_t i = 0; i < (size_t)ca * cin; ++i) w[i] *= scale_a;
-            for (int i = 0; i < ca && !bias.empty(); ++i) bias[i] *= scale_a;
-        }
-        return pack(w.data(), bias.empty() ? nullptr : bias.data(), ca + cb, cin, 1, round_up(cin, 64));
+        return pack(w.data(), with_bias ? bias.data() : nullptr, ctot, cin, 1, round_up(cin, 64));
     }
+    PackedW pack_stacked(const std::string& a, const std::string& b, float scale_a = 1.f) { return pack_stacked(std::vector<std::string>{a, b}, scale_a); }
     NormW norm_named(const std::string& name) {
         NormW n;
         const HostTensor& g = H(name + ".weight");
@@ -332,8 +336,12 @@ struct gp_engine {
         t.ln1 = norm_named(b + ".norm1");
         t.ln2 = norm_named(b + ".norm2");
         t.ln3 = norm_named(b + ".norm3");
-        t.qk = pack_stacked(b + ".attn1.to_q", b + ".attn1.to_k");
-        t.v = pack_named(b + ".attn1.to_v", 1);
+        // to_q | to_k | to_v stacked along the output dimension: ONE projection launch writes q | k row-major and V transposed (pgemm.hip:
+        // IGemmParams::vt_out); the two-launch form (q | k GEMM + transposed V GEMM) reads the same buffer through row views
+        t.qkv = pack_stacked({b + ".attn1.to_q", b + ".attn1.to_k", b + ".attn1.to_v"});
+        t.qk = t.qkv; t.qk.cout = 2 * t.C;
+        t.v = t.qkv; t.v.cout = t.C; t.v.w = t.qkv.w + (size_t)2 * t.C * t.qkv.cin_pad; t.v.n_rows = t.qkv.n_rows - 2 * t.C;
+        if (t.qkv.bias) { t.v.bias = t.qkv.bias + 2 * t.C; }
         t.o1 = pack_named(b + ".attn1.to_out.0", 1);
         t.q2 = pack_named(b + ".attn2.to_q", 1);
         t.o2 = pack_named(b + ".attn2.to_out.0", 1);
@@ -675,7 +683,7 @@ struct gp_engine {
             const char* path = conv_uses_halo(p, hint) ? (p.in_scale ? (p.in_silu ? "halo+gn+silu" : "halo+gn") : "halo") : igemm_uses_pgemm(p, hint) ? "pgemm" : "igemm";
             mark(std::string(p.ks == 3 ? (p.ups ? "conv3x3up " : (p.stride == 2 ? "conv3x3s2 " : "conv3x3 ")) : (p.batch > 1 ? "bgemm " : "gemm ")) + path + " M=" + std::to_string(p.M) +
                      " N=" + std::to_string(p.N) + " K=" + std::to_string(p.Cin * taps) + (p.batch > 1 ? " batch=" + std::to_string(p.batch) : "") + (p.res ? " +res" : "") +
-                     (p.act == GP_ACT_GEGLU ? " geglu" : "") + (p.stats_out ? " +stats" : ""),
+                     (p.act == GP_ACT_GEGLU ? " geglu" : "") + (p.stats_out ? " +stats" : "") + (p.vt_out ? " q|k|vT" : ""),
                  2.0 * (double)p.M * (double)p.N * (double)p.Cin * taps * (p.batch > 0 ? p.batch : 1));
         } else {
             tm.n_launches++;
@@ -934,8 +942,32 @@ struct gp_engine {
         drop(n);
         // self-attention
         Act l1 = layernorm(y, t.ln1);
-        Act qk = linear(l1, t.qk);
-        h16_t* vt = v_transposed(l1, t.v, T, Tpad);
+        Act qk;
+        h16_t* vt = nullptr;
+        {   // q | k | V^T in ONE launch when the persistent GEMM takes it (T % 16 == 0 ...), else the q | k GEMM + the transposed V GEMM
+            static const bool no_fuse = getenv("GENPERCEPT_NO_QKV_FUSE") != nullptr;  // A/B switch
+            IGemmParams p{};
+            p.in = l1.p; p.wt = t.qkv.w; p.zero = zero;
+            p.M = (int)l1.pixels(); p.N = 3 * C; p.Cin = t.qkv.cin_pad; p.n_rows = t.qkv.n_rows; p.ks = 1;
+            p.B = x.B; p.Hi = x.H; p.Wi = x.W; p.Ho = x.H; p.Wo = x.W; p.stride = 1;
+            p.lda = l1.C; p.ldo = 2 * C; p.ldres = 2 * C; p.ldw = t.qkv.cin_pad; p.n_store = 2 * C; p.act = GP_ACT_NONE;
+            p.bias_mode = GP_BIAS_NONE; p.batch = 1;
+            p.vt_col0 = 2 * C; p.vt_T = T; p.vt_Tpad = Tpad;
+            p.vt_out = (h16_t*)zero;  // (non-null for the applicability test)
+            // measured (tools/kbench, weight-cold): 4 x 2304 tokens, C = 640: 43 us fused vs 25 + 25; 4 x 576, C = 1280: 46 vs 29 + 25; at
+            // 4 x 9216 tokens, C = 320 the transposed stores of the V third (16 bytes per channel row and lane) eat the saving: 55 vs 29 + 25
+            static const int fuse_max_rows = getenv("GENPERCEPT_QKV_FUSE_MAX_ROWS") ? atoi(getenv("GENPERCEPT_QKV_FUSE_MAX_ROWS")) : 16384;
+            if (!no_fuse && p.M <= fuse_max_rows && !t.qkv.bias && l1.C == t.qkv.cin_pad && igemm_uses_pgemm(p, 0)) {
+                qk = new_act(x.B, x.H, x.W, 2 * C);
+                vt = (h16_t*)pool.alloc((size_t)x.B * C * Tpad * sizeof(h16_t));
+                if (Tpad != T) HIPCHK(hipMemsetAsync(vt, 0, (size_t)x.B * C * Tpad * sizeof(h16_t), st));  // keys beyond T must read as zero
+                p.out = qk.p; p.vt_out = vt;
+                run_igemm(p);
+            } else {
+                qk = linear(l1, t.qk);
+                vt = v_transposed(l1, t.v, T, Tpad);
+            }
+        }
         drop(l1);
         Act a = new_act(x.B, x.H, x.W, C);
         tm.flops_attn += 4.0 * x.B * t.heads * (double)T * T * 64;
@@ -1803,7 +1835,28 @@ gp_status gp_gemm(const void* a, int lda, const void* bt, int ldb, const float* 
         p.M = M; p.N = N; p.Cin = K; p.n_rows = n_rows_bt; p.ks = 1; p.stride = 1;
         p.lda = lda; p.ldw = ldb; p.ldo = ldo; p.ldres = ldres; p.n_store = n_store > 0 ? n_store : N; p.out_fp32 = out_fp32; p.act = act;
         p.bias_mode = bias ? bias_mode : GP_BIAS_NONE; p.batch = batch > 0 ? batch : 1; p.in_bs = a_bs; p.wt_bs = bt_bs; p.out_bs = out_bs;
+        if (const char* dbg = getenv("GENPERCEPT_IGEMM_DBG")) p.dbg = atoi(dbg);  // profiling ablations (tools/kbench)
+        attach_splitk_scratch(p, tile_hint);
         launch_igemm(p, tile_hint, (hipStream_t)stream);
+        HIPCHK(hipGetLastError());
+        return GP_OK;
+    } catch (...) { return GP_ERR_HIP; }
+}
+
+gp_status gp_gemm_qkv(const void* a, int lda, const void* w_packed, int ldw, int n_rows_w, int K, void* qk_out, void* vt_out, int B, int T, int C,
+                      int Tpad, void* stream) {
+    if (!a || !w_packed || !qk_out || !vt_out || (K % 64) || B < 1 || T < 1 || C < 1 || Tpad < T) return GP_ERR_INVALID;
+    try {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        IGemmParams p{};
+        p.in = (const h16_t*)a; p.wt = (const h16_t*)w_packed; p.out = qk_out; p.zero = zero_page();
+        p.M = B * T; p.N = 3 * C; p.Cin = K; p.n_rows = n_rows_w; p.ks = 1; p.stride = 1;
+        p.lda = lda; p.ldw = ldw; p.ldo = 2 * C; p.ldres = 2 * C; p.n_store = 2 * C; p.act = GP_ACT_NONE; p.bias_mode = GP_BIAS_NONE; p.batch = 1;
+        p.vt_out = (h16_t*)vt_out; p.vt_col0 = 2 * C; p.vt_T = T; p.vt_Tpad = Tpad;
+        if (const char* dbg = getenv("GENPERCEPT_IGEMM_DBG")) p.dbg = atoi(dbg);
+        if (!igemm_uses_pgemm(p, 0)) return GP_ERR_INVALID;  // only the persistent GEMM has the transposed epilogue
+        if (Tpad != T) HIPCHK(hipMemsetAsync(vt_out, 0, (size_t)B * C * Tpad * sizeof(h16_t), (hipStream_t)stream));
+        launch_igemm(p, 0, (hipStream_t)stream);
         HIPCHK(hipGetLastError());
         return GP_OK;
     } catch (...) { return GP_ERR_HIP; }

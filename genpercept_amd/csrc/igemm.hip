@@ -25,13 +25,9 @@
 
 #include <atomic>
 
-// true exactly once per (mask, current device): callers guard their one-time per-device setup with it (thread-safe, lock-free)
-bool gp_first_use_on_device(unsigned long long* mask) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
-    const unsigned long long bit = 1ull << dev;
-    auto* a = reinterpret_cast<std::atomic<unsigned long long>*>(mask);
-    return !(a->fetch_or(bit, std::memory_order_acq_rel) & bit);
+std::mutex& gp_attr_mutex() {
+    static std::mutex m;
+    return m;
 }
 
 constexpr bool PRIO = true;   // s_setprio around the MFMA cluster made hipcc wait lgkmcnt(0) before the first MFMA
@@ -303,8 +299,9 @@ template <int BM, int BN, int WM, int WN, int KS, int NSTAGE>
 static void launch_one(const IGemmParams& p, dim3 grid, hipStream_t s) {
     constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
     static unsigned long long attr_mask = 0;  // per device: every GPU of the process needs its own attribute
-    if (gp_first_use_on_device(&attr_mask))
+    gp_once_per_device(&attr_mask, [&] {
         (void)hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, KS, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, KS, NSTAGE>), grid, dim3(64 * WM * WN), lds, s, p);
 }
 

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #ifndef GP_F16
 #define GP_F16 0  // 1: the library's 16-bit element is IEEE fp16 instead of bf16 (common.h)
 #endif
@@ -46,14 +48,32 @@ struct IGemmParams {
     int ksplit;           // > 1: grid.z = ksplit slices of the K loop, slice z writes fp32 partials at out + z * split_bs (set by launch_igemm)
     long long split_bs;
     long long in_bs, wt_bs, out_bs, res_bs, bias_bs;
+    // Fused q | k | v projection of a self-attention (pgemm.hip only): output columns >= vt_col0 (a multiple of 128) are written TRANSPOSED,
+    // vt_out[(b * (N - vt_col0) + (n - vt_col0)) * vt_Tpad + t] for row m = b * vt_T + t (vt_T % 16 == 0), instead of into `out` -- the layout
+    // flash_attn64 reads its V^T operand in.  Columns [0, vt_col0) go to `out` as usual (n_store = ldo = vt_col0).  nullptr: plain GEMM.
+    h16_t* vt_out;
+    int vt_col0, vt_T, vt_Tpad;
 };
 
 // tile_hint: 0 auto (halo conv / persistent GEMM / split-K / generic tile by heuristic), 1 = 128x128, 2 = 64x64, 3 = 256x32, 4 = 256x128,
 //            5 = conv_halo.hip, 6 = 128x64, 7 = pgemm.hip
 void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s);
 int igemm_ksplit(const IGemmParams& p, int tile_hint);   // K slices launch_igemm would like to use (1: none); needs p.splitk_ws to do so
-// >64 KiB of dynamic LDS needs hipFuncSetAttribute once per (kernel, device): true the first time it is asked for this device
-bool gp_first_use_on_device(unsigned long long* mask);
+// >64 KiB of dynamic LDS needs hipFuncSetAttribute once per (kernel, device).  `f` runs exactly once per (mask, current device); a second host
+// thread that arrives meanwhile WAITS until it has finished (the r2 form set the "done" bit before the attribute call: another engine thread
+// could launch in between and be refused for its LDS size).  The bit is published with release order after f(), read with acquire order.
+std::mutex& gp_attr_mutex();
+template <typename F>
+inline void gp_once_per_device(unsigned long long* mask, F&& f) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) { f(); return; }
+    const unsigned long long bit = 1ull << dev;
+    if (__atomic_load_n(mask, __ATOMIC_ACQUIRE) & bit) return;
+    std::lock_guard<std::mutex> lk(gp_attr_mutex());
+    if (__atomic_load_n(mask, __ATOMIC_RELAXED) & bit) return;
+    f();
+    __atomic_store_n(mask, __atomic_load_n(mask, __ATOMIC_RELAXED) | bit, __ATOMIC_RELEASE);
+}
 // pgemm.hip: persistent GEMM for plain-row problems (ks == 1, bf16 out, column bias); tile_hint 7 forces it, 0 prefers it
 bool pgemm_applicable(const IGemmParams& p);
 int pgemm_bm(const IGemmParams& p);                 // rows per tile (256 or 128) launch_pgemm will use

@@ -459,16 +459,43 @@ void launch_layernorm(const h16_t* x, h16_t* y, const float* gamma, const float*
 // HEADS is a template parameter so that both head loops unroll: the U / G loads of all heads are independent and issue together, and the
 // HEADS x R logit reductions interleave -- as a run-time loop every head paid an L2 round trip plus a 6-step shuffle chain in sequence
 // (78 us for 576 rows of 1280 channels, pure latency).
-template <int VPT, int R, int HEADS>
+// LDSM (r3): 0 = U / G / c0 / g3 / b3 straight from global memory (every wave re-streams HEADS x C x 8 bytes per R rows from L2: 470 MB for
+// 2304 rows of 1280 channels, 30 us for an 18 MB tensor); 1 = U and the three per-channel vectors are copied to LDS once per workgroup, G still
+// streams (20 heads x 1280 channels: U alone is 100 KiB); 2 = G in LDS as well.  Workgroups are persistent (they walk row blocks with a grid
+// stride) so that the copy is paid once per CU, not once per 4 R rows.
+template <int VPT, int R, int HEADS, int LDSM>
 __global__ __launch_bounds__(256) void cross_fold_kernel(const h16_t* __restrict__ y, h16_t* __restrict__ y_out, h16_t* __restrict__ n3_out,
                                                           const float* __restrict__ U, const float* __restrict__ u0, const float* __restrict__ G,
                                                           const float* __restrict__ c0, const float* __restrict__ g3, const float* __restrict__ b3,
                                                           int rows, int C, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float cf_sm[];  // LDSM: [HEADS][C] U, ([HEADS][C] G,) [C] c0, [C] g3, [C] b3
     const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
-    if (row0 >= rows) return;
     const int nvec = C >> 3;
     const float invC = 1.f / (float)C;
+    const unsigned sm_base = (unsigned)(unsigned long long)cf_sm;
+    const unsigned sU = sm_base, sG = sU + (unsigned)HEADS * C * 4, sC = LDSM == 2 ? sG + (unsigned)HEADS * C * 4 : sG;
+    if (LDSM) {
+        const int nU = HEADS * C;
+        for (int i = threadIdx.x * 4; i < nU; i += 256 * 4) {
+            *(float4*)(cf_sm + i) = *(const float4*)(U + i);
+            if (LDSM == 2) *(float4*)(cf_sm + nU + i) = *(const float4*)(G + i);
+        }
+        float* cs = cf_sm + (LDSM == 2 ? 2 : 1) * nU;
+        for (int i = threadIdx.x * 4; i < C; i += 256 * 4) {
+            *(float4*)(cs + i) = *(const float4*)(c0 + i);
+            *(float4*)(cs + C + i) = g3 ? *(const float4*)(g3 + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *(float4*)(cs + 2 * C + i) = b3 ? *(const float4*)(b3 + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+    }
+    // 8 consecutive floats of a per-channel table: from LDS (byte address) or from global memory
+    auto ld8 = [&](unsigned lds_addr, const float* gptr, float (&o)[8]) __attribute__((always_inline)) {
+        f32x4_t a, b;
+        if (LDSM) { a = *(lds_f4_ptr)lds_addr; b = *(lds_f4_ptr)(lds_addr + 16); }
+        else { const float4 x = *(const float4*)gptr, y2 = *(const float4*)(gptr + 4); a = f32x4_t{x.x, x.y, x.z, x.w}; b = f32x4_t{y2.x, y2.y, y2.z, y2.w}; }
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    };
+  for (int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R; row0 < rows; row0 += gridDim.x * 4 * R) {
     float v[R][VPT][8];
     // ---- load, LayerNorm statistics (exact two-pass, row in registers)
 #pragma unroll
@@ -490,8 +517,7 @@ __global__ __launch_bounds__(256) void cross_fold_kernel(const h16_t* __restrict
         for (int u = 0; u < VPT; ++u)
 #pragma unroll
             for (int k = 0; k < 8; ++k) s += v[r][u][k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        s = wave_sum(s);
         mean[r] = s * invC;
         float q = 0.f;
 #pragma unroll
@@ -500,8 +526,7 @@ __global__ __launch_bounds__(256) void cross_fold_kernel(const h16_t* __restrict
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const float d = v[r][u][k] - mean[r]; q += d * d; }
             }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        q = wave_sum(q);
         rstd[r] = rsqrtf(q * invC + eps);
     }
     // ---- per-head logits d[r][h] = yhat . U[h]: partial sums over this lane's channels for every head, then one batch of reductions
@@ -516,8 +541,8 @@ __global__ __launch_bounds__(256) void cross_fold_kernel(const h16_t* __restrict
         if (vi < nvec) {
 #pragma unroll
             for (int h = 0; h < HEADS; ++h) {
-                const float4 a = *(const float4*)(U + (long long)h * C + vi * 8), b = *(const float4*)(U + (long long)h * C + vi * 8 + 4);
-                const float uu[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                float uu[8];
+                ld8(sU + (unsigned)(h * C + vi * 8) * 4, U + (long long)h * C + vi * 8, uu);
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -526,11 +551,9 @@ __global__ __launch_bounds__(256) void cross_fold_kernel(const h16_t* __restrict
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int h = 0; h < HEADS; ++h) d[r][h] += __shfl_xor(d[r][h], o);
+        for (int h = 0; h < HEADS; ++h) d[r][h] = wave_sum(d[r][h]);
 #pragma unroll
     for (int h = 0; h < HEADS; ++h) {
         const float uh = u0[h];
@@ -542,16 +565,20 @@ __global__ __launch_bounds__(256) void cross_fold_kernel(const h16_t* __restrict
     for (int u = 0; u < VPT; ++u) {
         const int vi = lane + u * 64;
         if (vi < nvec) {
-            const float4 a0 = *(const float4*)(c0 + vi * 8), b0 = *(const float4*)(c0 + vi * 8 + 4);
-            const float cc[8] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w};
+            float cc[8];
+            ld8(sC + (unsigned)(vi * 8) * 4, c0 + vi * 8, cc);
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[r][u][k] += cc[k];
 #pragma unroll
             for (int h = 0; h < HEADS; ++h) {
-                const float4 a = *(const float4*)(G + (long long)h * C + vi * 8), b = *(const float4*)(G + (long long)h * C + vi * 8 + 4);
-                const float gg[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                float gg[8];
+                if (LDSM == 2) ld8(sG + (unsigned)(h * C + vi * 8) * 4, nullptr, gg);
+                else {
+                    const float4 a = *(const float4*)(G + (long long)h * C + vi * 8), b = *(const float4*)(G + (long long)h * C + vi * 8 + 4);
+                    gg[0] = a.x; gg[1] = a.y; gg[2] = a.z; gg[3] = a.w; gg[4] = b.x; gg[5] = b.y; gg[6] = b.z; gg[7] = b.w;
+                }
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -579,8 +606,7 @@ __global__ __launch_bounds__(256) void cross_fold_kernel(const h16_t* __restrict
             }
         }
         if (!n3_out) continue;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        s = wave_sum(s);
         const float m3 = s * invC;
         float q = 0.f;
 #pragma unroll
@@ -589,16 +615,15 @@ __global__ __launch_bounds__(256) void cross_fold_kernel(const h16_t* __restrict
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const float dd = v[r][u][k] - m3; q += dd * dd; }
             }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        q = wave_sum(q);
         const float r3 = rsqrtf(q * invC + eps);
 #pragma unroll
         for (int u = 0; u < VPT; ++u) {
             const int vi = lane + u * 64;
             if (vi < nvec && row0 + r < rows) {
-                const float4 ga = *(const float4*)(g3 + vi * 8), gb = *(const float4*)(g3 + vi * 8 + 4);
-                const float4 ba = *(const float4*)(b3 + vi * 8), bb = *(const float4*)(b3 + vi * 8 + 4);
-                const float gg[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w}, bt[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+                float gg[8], bt[8];
+                ld8(sC + (unsigned)(C + vi * 8) * 4, g3 + vi * 8, gg);
+                ld8(sC + (unsigned)(2 * C + vi * 8) * 4, b3 + vi * 8, bt);
                 float o8[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) o8[k] = (v[r][u][k] - m3) * r3 * gg[k] + bt[k];
@@ -608,6 +633,7 @@ __global__ __launch_bounds__(256) void cross_fold_kernel(const h16_t* __restrict
             }
         }
     }
+  }
 }
 
 // y_out may alias y (a wave reads its rows completely before it writes them); n3_out optional.  C % 8 == 0, C <= 1536.
@@ -617,8 +643,37 @@ bool cross_attn_fold_supported(int C, int heads) {
 template <int VPT, int R, int HEADS>
 static void launch_cross_fold_one(const h16_t* y, h16_t* y_out, h16_t* n3_out, const float* U, const float* u0, const float* G, const float* c0,
                                   const float* g3, const float* b3, int rows, int C, float eps, hipStream_t s) {
-    dim3 grid((rows + 4 * R - 1) / (4 * R));
-    hipLaunchKernelGGL((cross_fold_kernel<VPT, R, HEADS>), grid, dim3(256), 0, s, y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, eps);
+    static const int mode_env = getenv("GENPERCEPT_XFOLD_LDS") ? atoi(getenv("GENPERCEPT_XFOLD_LDS")) : -1;  // A/B switch: 0 = the r2 kernel
+    const int blocks = (rows + 4 * R - 1) / (4 * R);
+    const size_t tab = (size_t)HEADS * C * 4, vec = (size_t)3 * C * 4;
+    int mode = 2 * tab + vec <= 64 * 1024 ? 2 : (tab + vec <= 120 * 1024 ? 1 : 0);  // tables in LDS when >= 2 (mode 2) / 1 (mode 1) workgroups fit a CU
+    if (mode_env >= 0 && mode_env < mode) mode = mode_env;
+    if (mode == 0 || blocks < 64) {
+        hipLaunchKernelGGL((cross_fold_kernel<VPT, R, HEADS, 0>), dim3(blocks), dim3(256), 0, s, y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, eps);
+        return;
+    }
+    const size_t lds = (mode == 2 ? 2 : 1) * tab + vec;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    int grid = ncu * per_cu;
+    if (grid > blocks) grid = blocks;
+    static unsigned long long attr_mask = 0;
+    if (mode == 2) {
+        gp_once_per_device(&attr_mask, [&] { (void)hipFuncSetAttribute((const void*)cross_fold_kernel<VPT, R, HEADS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); });
+        hipLaunchKernelGGL((cross_fold_kernel<VPT, R, HEADS, 2>), dim3(grid), dim3(256), lds, s, y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, eps);
+    } else {
+        static unsigned long long attr_mask1 = 0;
+        gp_once_per_device(&attr_mask1, [&] { (void)hipFuncSetAttribute((const void*)cross_fold_kernel<VPT, R, HEADS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); });
+        hipLaunchKernelGGL((cross_fold_kernel<VPT, R, HEADS, 1>), dim3(grid), dim3(256), lds, s, y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, eps);
+    }
 }
 template <int VPT, int HEADS>
 static void launch_cross_fold_r(const h16_t* y, h16_t* y_out, h16_t* n3_out, const float* U, const float* u0, const float* G, const float* c0,

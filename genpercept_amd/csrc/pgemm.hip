@@ -272,12 +272,23 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
     // GEGLU (the transformer's first feed-forward GEMM): packed weight rows interleave value and gate so that a lane's 8 columns of a
     // fragment pair are 4 values + their 4 gates (engine: geglu_row); out[m][c] = value * gelu(gate), 4 outputs = 8 bytes per lane,
     // written straight from the accumulators (no staging: the 32-byte row pieces are what igemm_kernel's direct path wrote as well).
-    auto epilogue_geglu = [&]() __attribute__((always_inline)) {
+    auto epilogue_geglu = [&](auto slotc) __attribute__((always_inline)) {
+        // r3: the 4 outputs per (fragment pair, pixel fragment) used to go straight to HBM as 8-byte stores, sixteen per lane, each instruction
+        // touching sixteen rows with 32 bytes: 45 of the 100 us of the 36864 x 2560 x 320 GEMM were those stores (ablation: 97 -> 54 us without
+        // them, while the staged 16-byte stores of the plain epilogue cost 17 us for twice the bytes).  Now the packed outputs of the wave's
+        // 64 x TN/2 block are staged through the wave's own DMA pieces of the slot just consumed (like epilogue_body) and leave as 16-byte
+        // stores covering the wave's whole column span of a row (64 / 32 bytes) per row.
+        constexpr int S = decltype(slotc)::value;
+        constexpr int RB = TN;                 // bytes of one staged row: TN / 2 outputs x 2 bytes
+        constexpr int RPP = 1024 / RB;         // staged rows per 1 KiB DMA piece
+        constexpr int UPR = RB / 16;           // 16-byte units per row
+        constexpr int NIT = 64 * UPR / 64;     // read-back iterations (64 rows x UPR units / 64 lanes)
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
         const int q = lane_o >> 4, a = lane_o & 15;
         const int n_half = p.N >> 1;
         h16_t* outp = (h16_t*)p.out;
+        const unsigned win = smem_base + S * STAGE + wave * 1024;
 #pragma unroll
         for (int ip = 0; ip < FP; ++ip) {
             const f32x4_t bl = *(lds_f4_ptr)(bias_base + (wn * TN + 32 * ip + 8 * q) * 4);
@@ -285,25 +296,85 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
             const int col = ((n0 + wn * TN + 32 * ip) >> 1) + 4 * q;   // first of this lane's 4 output columns
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
-                const int m = cm0 + wm * 64 + 16 * j + a;
-                if (m >= p.M || col >= p.n_store) continue;
                 const f32x4_t val = acc[2 * ip][j] + bl, gate = acc[2 * ip + 1][j] + bh;
                 float v[4] = {val.x * gelu_erf_f(gate.x), val.y * gelu_erf_f(gate.y), val.z * gelu_erf_f(gate.z), val.w * gelu_erf_f(gate.w)};
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (col + r >= n_half) v[r] = 0.f;
-                if (!(ABL & 4)) *(uint2*)(outp + (long long)m * p.ldo + col) = pack_h16x4(v[0], v[1], v[2], v[3]);
+                const uint2 pk = pack_h16x4(v[0], v[1], v[2], v[3]);
+                const int r16 = 16 * j + a;    // staged row; 8-byte slot ip * 4 + q, XORed with an even key of the row (2-way on ds_write_b64 at most)
+                const unsigned d = win + (r16 / RPP) * 8192 + (r16 % RPP) * RB + (((ip * 4 + q) ^ (((r16 >> 1) & (UPR - 1)) << 1)) << 3);
+                asm volatile("ds_write_b64 %0, %1" ::"v"(d), "v"(pk) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const int x = t * 64 + lane_o, r16 = x / UPR, c16 = x % UPR;
+            const unsigned sa = win + (r16 / RPP) * 8192 + (r16 % RPP) * RB + (((2 * c16) ^ (((r16 >> 1) & (UPR - 1)) << 1)) << 3);
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            u32x4_t o4;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(o4) : "v"(sa) : "memory");
+            const int m = cm0 + wm * 64 + r16;
+            const int col = ((n0 + wn * TN) >> 1) + 8 * c16;
+            if (m < p.M && col < p.n_store) {
+                if (!(ABL & 4)) *(uint4*)(outp + (long long)m * p.ldo + col) = make_uint4(o4.x, o4.y, o4.z, o4.w);
+                else asm volatile("" ::"v"(o4));
             }
         }
     };
-    const int ep_variant = p.act == GP_ACT_GEGLU ? 8 : (p.act != GP_ACT_NONE ? 4 : 0) | (p.res ? 2 : 0) | (want_stats ? 1 : 0);
+    // V^T slices of the fused q | k | v projection (IGemmParams::vt_out): the accumulators are staged exactly like epilogue_body's, read back
+    // COLUMN-wise -- a lane takes 8 consecutive rows (tokens) of one channel -- and stored as 16 bytes along t of the transposed tensor.
+    auto epilogue_vt = [&](auto slotc) __attribute__((always_inline)) {
+        constexpr int S = decltype(slotc)::value;
+        constexpr int RPP = 1024 / (TN * 4);
+        constexpr int NI = TN * 2 / 64;       // (channel, row octet) items per lane and pass: TN channels x 2 octets of the 16 staged rows
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int q = lane_o >> 4, a = lane_o & 15;
+        const unsigned win = smem_base + S * STAGE + wave * 1024;
+        const int nv = p.N - p.vt_col0;       // channels of V
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+#pragma unroll
+            for (int ip = 0; ip < FP; ++ip) {
+                const unsigned d = win + (a / RPP) * 8192 + (a % RPP) * (TN * 4) + ((((4 * ip + q) ^ (a & (SLW - 1)))) << 5);
+                *(lds_f4_ptr)d = acc[2 * ip][j];
+                *(lds_f4_ptr)(d + 16) = acc[2 * ip + 1][j];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < NI; ++t) {
+                const int it = t * 64 + lane_o, c = it % TN, o = it / TN;   // channel c of the wave's TN, rows 8 o .. 8 o + 7 of this pass
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = 8 * o + k;
+                    v[k] = *(lds_f_ptr)(win + (r / RPP) * 8192 + (r % RPP) * (TN * 4) + ((((c >> 3) ^ (r & (SLW - 1)))) << 5) + (c & 7) * 4);
+                }
+                const int m = cm0 + wm * 64 + 16 * j + 8 * o;               // first of the 8 rows: all of one image (vt_T % 16 == 0)
+                const int ch = n0 - p.vt_col0 + wn * TN + c;
+                if (m < p.M && ch < nv) {
+                    const int b = m / p.vt_T, tt = m - b * p.vt_T;
+                    uint4 pk;
+                    pk.x = pack_h16x2(v[0], v[1]); pk.y = pack_h16x2(v[2], v[3]); pk.z = pack_h16x2(v[4], v[5]); pk.w = pack_h16x2(v[6], v[7]);
+                    if (!(ABL & 4)) *(uint4*)(p.vt_out + ((long long)b * nv + ch) * p.vt_Tpad + tt) = pk;
+                    else asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the next pass overwrites the window)
+        }
+    };
+    const bool vt_slice = p.vt_out != nullptr && n0 >= p.vt_col0;  // workgroup-uniform
+    const int ep_variant = vt_slice ? 16 : p.act == GP_ACT_GEGLU ? 8 : (p.act != GP_ACT_NONE ? 4 : 0) | (p.res ? 2 : 0) | (want_stats ? 1 : 0);
     auto epilogue = [&](auto slotc) __attribute__((always_inline)) {
         switch (ep_variant) {
             case 0: epilogue_body(slotc, IC<0>{}, IC<0>{}, IC<0>{}); break;
             case 1: epilogue_body(slotc, IC<0>{}, IC<0>{}, IC<1>{}); break;
             case 2: epilogue_body(slotc, IC<0>{}, IC<1>{}, IC<0>{}); break;
             case 3: epilogue_body(slotc, IC<0>{}, IC<1>{}, IC<1>{}); break;
-            case 8: epilogue_geglu(); break;
+            case 8: epilogue_geglu(slotc); break;
+            case 16: epilogue_vt(slotc); break;
             default: epilogue_body(slotc, IC<1>{}, IC<1>{}, IC<1>{}); break;
         }
 #pragma unroll
@@ -396,9 +467,11 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
 }
 
 bool pgemm_applicable(const IGemmParams& p) {
+    if (p.vt_out && ((p.vt_col0 & 127) || (p.vt_T & 15) || (p.vt_Tpad & 7) || p.vt_col0 != p.n_store || p.res || p.stats_out || p.act != GP_ACT_NONE ||
+                     p.bias_mode != GP_BIAS_NONE || p.M % p.vt_T)) return false;
     if (p.ks != 1 || p.batch > 1 || p.out_fp32 || p.bias_mode == GP_BIAS_ROW || p.in_scale) return false;
     if (p.act == GP_ACT_GEGLU) return !p.res && !p.stats_out && (p.N & 63) == 0 && (p.Cin & 63) == 0 && (p.lda & 7) == 0 && (p.ldw & 7) == 0 &&
-                                      (p.ldo & 3) == 0 && (p.n_store & 3) == 0 && p.M >= 256;
+                                      (p.ldo & 7) == 0 && (p.n_store & 7) == 0 && p.M >= 256;  // (16-byte output stores)
     if ((p.Cin & 63) || (p.lda & 7) || (p.ldw & 7) || (p.ldo & 7) || (p.n_store & 7)) return false;
     if (p.res && ((p.ldres & 7) || p.ldres < p.n_store)) return false;
     return p.M >= 256;
@@ -418,7 +491,7 @@ template <int BM, int ABL>
 static void launch_pgemm_one(const IGemmParams& p, int ncu, hipStream_t s) {
     using G = PGemmGeom<BM>;
     static unsigned long long attr_mask = 0;
-    if (gp_first_use_on_device(&attr_mask)) (void)hipFuncSetAttribute((const void*)pgemm_kernel<BM, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    gp_once_per_device(&attr_mask, [&] { (void)hipFuncSetAttribute((const void*)pgemm_kernel<BM, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS); });
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
     const int tiles_n = (ncols + PG_BN - 1) / PG_BN, tiles_m = (p.M + BM - 1) / BM;
     int groups = ncu / tiles_n;

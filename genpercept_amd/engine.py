@@ -110,6 +110,7 @@ SYMBOLS = {
     "gp_rgb_conv_in": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "gp_conv2d_stats": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp, _vp, _i, _f, _vp, _vp, _vp]),
     "gp_gemm": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
+    "gp_gemm_qkv": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "gp_groupnorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "gp_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "gp_flash_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -471,6 +472,21 @@ def gemm(a: torch.Tensor, bt: torch.Tensor, bias=None, bias_mode: int = 1, resid
     if st != GP_OK:
         raise RuntimeError(f"gp_gemm failed ({st})")
     return out if batched else out[0]
+
+
+def gemm_qkv(a: torch.Tensor, w_packed: torch.Tensor, batch: int, tokens: int, c: int):
+    """a [B*T, K]; w_packed = pack_weight(cat(Wq, Wk, Wv)) [rows, 1, K]; returns (qk [B*T, 2C], vt [B, C, Tpad]).  gp_gemm_qkv."""
+    lib = load_library()
+    m, k = a.shape
+    assert m == batch * tokens
+    tpad = (tokens + 63) // 64 * 64
+    qk = torch.empty((m, 2 * c), dtype=act_dtype(), device=a.device)
+    vt = torch.full((batch, c, tpad), float("nan"), dtype=act_dtype(), device=a.device)
+    st = lib.gp_gemm_qkv(a.data_ptr(), a.stride(0), w_packed.data_ptr(), w_packed.stride(0), w_packed.shape[0], k, qk.data_ptr(), vt.data_ptr(), batch, tokens, c,
+                         tpad, _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_gemm_qkv failed ({st})")
+    return qk, vt
 
 
 def groupnorm(x_nhwc: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool) -> torch.Tensor:

@@ -183,6 +183,12 @@ gp_status gp_conv2d_stats(const void* in, const void* w_packed, const float* bia
 gp_status gp_gemm(const void* a, int lda, const void* bt, int ldb, const float* bias, int bias_mode, const void* residual, int ldres, void* out,
                   int ldo, int M, int N, int K, int n_rows_bt, int n_store, int act, int out_fp32 /* 0 bf16, 1 fp32, 2 fp16 */, int batch, long long a_bs, long long bt_bs,
                   long long out_bs, int tile_hint, void* stream);
+/* The self-attention input projections of a BasicTransformerBlock (attn1.to_q / to_k / to_v, bias-free in SD2.1; custom_unet.py's
+ * Transformer2DModel blocks) as ONE GEMM over the stacked weight [3C][K] (gp_pack_weight of the concatenation): q | k go to qk_out
+ * [B*T][2C] row-major, V goes to vt_out TRANSPOSED as [B][C][Tpad] (zero beyond T) -- the operand layout of gp_flash_attention.
+ * Requirements: K % 64 == 0, (2C) % 128 == 0, T % 16 == 0, Tpad % 8 == 0, B*T >= 256; GP_ERR_INVALID otherwise (use gp_gemm twice). */
+gp_status gp_gemm_qkv(const void* a, int lda, const void* w_packed, int ldw, int n_rows_w, int K, void* qk_out, void* vt_out, int B, int T, int C,
+                      int Tpad, void* stream);
 gp_status gp_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int silu, void* stream);
 gp_status gp_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C, float eps, void* stream);
 gp_status gp_flash_attention(const void* q, const void* k, const void* vt, void* out, int B, int T, int heads, int ldq, int ldk, int Tpad, int ldo,

@@ -285,6 +285,7 @@ def test_pipeline_surface(tiny_weights, golden, metric_log):
 
     class Sched:  # what run.py:371 loads from hf_configs/scheduler_beta_1.0_1.0
         beta_start, beta_end, prediction_type, clip_sample = 1.0, 1.0, "v_prediction", False
+        steps_offset, timestep_spacing = 1, "leading"  # => set_timesteps(1) == [1] (genpercept_pipeline.py:403)
 
     pipe = GenPerceptPipeline(unet=tiny_weights["usd"], vae=tiny_weights["vsd"], scheduler=Sched(), text_encoder=golden["sq_ctx"], tokenizer=None)
     pipe.to("cuda")
@@ -608,7 +609,8 @@ def test_infer_eval_loop_with_the_engine(precision, tiny_weights, tmp_path, metr
     tw = tiny_weights
     g = torch.Generator().manual_seed(31)
     ctx = torch.randn(2, tw["uc"].cross_attention_dim, generator=g)
-    pipe = GenPerceptPipeline(unet=tw["usd"], vae=tw["vsd"], scheduler=dict(beta_start=1.0, beta_end=1.0, prediction_type="v_prediction", clip_sample=False),
+    pipe = GenPerceptPipeline(unet=tw["usd"], vae=tw["vsd"], scheduler=dict(beta_start=1.0, beta_end=1.0, prediction_type="v_prediction", clip_sample=False,
+                                                                                       steps_offset=1, timestep_spacing="leading"),
                               text_encoder=ctx, tokenizer=None, torch_dtype=torch.float16 if precision == "fp16" else torch.bfloat16)
     pipe.to("cuda")
     base, outd = tmp_path / "data", tmp_path / "pred"

@@ -317,6 +317,30 @@ def test_gemm_row_bias_batched_zero_fill(metric_log):
     assert float(out[:, :, t:].float().abs().max()) == 0.0, "padding columns must be written as zeros"
 
 
+@pytest.mark.parametrize("case", [(4, 576, 320), (2, 2304, 640), (4, 144, 1280), (1, 400, 64), (3, 272, 128)])
+def test_gemm_qkv_fused_projection(case, metric_log):
+    """gp_gemm_qkv: attn1.to_q | to_k | to_v of a BasicTransformerBlock as one GEMM -- q | k row-major, V written transposed [B][C][Tpad] with
+    zero padding beyond T (the operand layouts of gp_flash_attention); 128- and 256-row tiles, T with and without padding columns, a ragged
+    last V slice (3C not a multiple of 128)."""
+    e = _eng()
+    b, t, c = case
+    g = torch.Generator().manual_seed(b * 1000 + t + c)
+    x = rbf(torch.randn(b * t, c, generator=g))
+    w = rbf(torch.randn(3 * c, c, generator=g) / math.sqrt(c))
+    d = _dev()
+    wp = e.pack_weight(w, device=d)
+    qk, vt = e.gemm_qkv(x.to(d).to(e.act_dtype()), wp.reshape(wp.shape[0], -1), b, t, c)
+    ref = x @ w.t()
+    check(f"gemm_qkv_qk{case}", qk, ref[:, :2 * c], metric_log)
+    vref = ref[:, 2 * c:].reshape(b, t, c).permute(0, 2, 1)
+    check(f"gemm_qkv_vt{case}", vt[:, :, :t], vref, metric_log)
+    if vt.shape[2] > t:
+        assert float(vt[:, :, t:].float().abs().max()) == 0.0, "keys beyond T must read as zero"
+    # the two-launch form (q | k GEMM + row-bias-free transposed V GEMM) gives the same numbers: same MFMA order per output
+    qk2 = e.gemm(x.to(d).to(e.act_dtype()), wp.reshape(wp.shape[0], -1)[:2 * c])
+    assert torch.equal(qk2, qk)
+
+
 @pytest.mark.parametrize("mc", [(200, 128), (4801, 128), (36864, 320), (2304, 64)])
 def test_gemm_geglu(mc, metric_log):
     """GEGLU feed-forward GEMM: M = 200 stays on igemm_kernel's direct path, the larger ones run the persistent GEMM's GEGLU epilogue."""

@@ -88,6 +88,23 @@ __global__ void cmp_kernel(const h16* out, int ldo, const float* ref, int M, int
     atomicMax((unsigned*)&res2[1], __float_as_uint(r));
 }
 
+// GEGLU check: ref holds the pre-activation [M][N] in PACKED row order (value j at 32 (j / 16) + 8 ((j % 16) / 4) + j % 4, its gate 4 rows on);
+// out [M][N/2] bf16 must be value * gelu_erf(gate)
+__global__ void cmp_geglu_kernel(const h16* out, int ldo, const float* ref, int M, int N, float* res2) {
+    const int nh = N / 2;
+    float e = 0.f, r = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)M * nh; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / nh), c = (int)(i % nh);
+        const int vr = (c / 16) * 32 + ((c % 16) / 4) * 8 + (c % 4);
+        const float val = ref[(size_t)m * N + vr], g = ref[(size_t)m * N + vr + 4];
+        const float f = val * 0.5f * g * (1.f + erff(g * 0.70710678f));
+        const float o = bf2f(out[(size_t)m * ldo + c]);
+        e = fmaxf(e, fabsf(o - f));
+        r = fmaxf(r, fabsf(f));
+    }
+    atomicMax((unsigned*)&res2[0], __float_as_uint(e));
+    atomicMax((unsigned*)&res2[1], __float_as_uint(r));
+}
 __global__ void copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
@@ -148,7 +165,7 @@ static void bench_gemm(const std::vector<long long>& a) {
     const double flops = 2.0 * M * (double)N * K;
     const float wscale = 1.f / sqrtf((float)K) * 1.7f;
     (void)wscale;
-    if (g_check && act != 3) {
+    if (g_check) {
         CK(hipMalloc(&ref, (size_t)M * N * 4));
         hipLaunchKernelGGL(ref_gemm_kernel, dim3((N + 63) / 64, M), dim3(64), 0, 0, A, K, g_arena, K, bias, R, nout, ref, M, N, K);
     }
@@ -163,7 +180,8 @@ static void bench_gemm(const std::vector<long long>& a) {
         CK(hipDeviceSynchronize());
         if (ref) {
             CK(hipMemset(res2, 0, 8));
-            hipLaunchKernelGGL(cmp_kernel, dim3(512), dim3(256), 0, 0, O, nout, ref, M, N, 0, res2);
+            if (act == 3) hipLaunchKernelGGL(cmp_geglu_kernel, dim3(512), dim3(256), 0, 0, O, nout, ref, M, N, res2);
+            else hipLaunchKernelGGL(cmp_kernel, dim3(512), dim3(256), 0, 0, O, nout, ref, M, N, 0, res2);
             float h[2];
             CK(hipMemcpy(h, res2, 8, hipMemcpyDeviceToHost));
             err = h[0]; rmax = h[1];
@@ -280,7 +298,13 @@ static void bench_xfold(const std::vector<long long>& a) {  // xfold:rows,C,head
     const float t = time_us([&](int) {
         if (gp_cross_attention_fold(Yb, Yo, N3, U, u0, G, c0, g3, b3, rows, C, heads, 1e-5f, nullptr) != GP_OK) { fprintf(stderr, "xfold failed\n"); exit(3); }
     }, g_iters);
-    printf("xfold rows=%-6d C=%-5d heads=%-2d  %8.2f us  (%.0f MB: %.2f TB/s)\n", rows, C, heads, t, 3.0 * rows * C * 2 / 1e6, 3.0 * rows * C * 2 / t * 1e-6);
+    std::vector<h16> hy((size_t)rows * C), hn((size_t)rows * C);
+    CK(hipMemcpy(hy.data(), Yo, hy.size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hn.data(), N3, hn.size() * 2, hipMemcpyDeviceToHost));
+    double c1 = 0, c2 = 0;
+    for (size_t i = 0; i < hy.size(); ++i) { c1 += bf2f(hy[i]) * (double)((i % 7) + 1); c2 += bf2f(hn[i]) * (double)((i % 5) + 1); }
+    printf("xfold rows=%-6d C=%-5d heads=%-2d  %8.2f us  (%.0f MB: %.2f TB/s)  checksums %.8e %.8e\n", rows, C, heads, t, 3.0 * rows * C * 2 / 1e6,
+           3.0 * rows * C * 2 / t * 1e-6, c1, c2);
     fflush(stdout);
 }
 
@@ -301,7 +325,7 @@ static void bench_qkv(const std::vector<long long>& a) {
     const size_t wel = (size_t)nrows * C;
     hipLaunchKernelGGL(ref_gemm_kernel, dim3((N + 63) / 64, M), dim3(64), 0, 0, A, C, g_arena, C, nullptr, nullptr, 0, ref, M, N, C);
     auto go = [&](const h16* w) {
-        gp_status st = gp_gemm_qkv(A, C, w, C, nrows, QK, 2 * C, VT, Tpad, Bimg, T, C, hint, nullptr);
+        gp_status st = gp_gemm_qkv(A, C, w, C, nrows, C, QK, VT, Bimg, T, C, Tpad, nullptr);
         if (st != GP_OK) { fprintf(stderr, "gp_gemm_qkv failed (%d)\n", (int)st); exit(3); }
     };
     CK(hipMemset(QK, 0xff, (size_t)M * 2 * C * 2));
