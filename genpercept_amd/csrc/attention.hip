@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = xor32_max(mx);                                // the other half-wave holds this query's other 32 keys (v_permlane32_swap, no LDS trip)
         const float m_new = fmaxf(m_run, mx);              // raw-score units
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
         const float nm = -m_new * sc;

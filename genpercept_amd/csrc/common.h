@@ -152,6 +152,44 @@ GP_DEV float wave_sum(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 
+// x[l] + x[l ^ 32] / x[l] + x[l ^ 16] in every lane: v_permlane32_swap / v_permlane16_swap (gfx950) exchange half-waves / odd-even rows of 16
+// between two registers (semantics probed on the chip, tools/probe/permlane_probe.cpp: vdst' = [a.lo, b.lo], src' = [a.hi, b.hi]; rows
+// [a0, b0, a2, b2] / [a1, b1, a3, b3]); with both registers holding x their sum is the pairwise total.  The two wait states a VALU write
+// needs before a permlane reads it are inside the string.
+GP_DEV float xor32_sum(float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+GP_DEV float xor16_sum(float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+GP_DEV float xor32_max(float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+// sum over the lanes l' == l (mod SLW), SLW = 4, 8 or 16, valid in lanes 0 .. SLW-1 (every row's first SLW lanes): row_shl inside the rows of 16
+// (lane i += lane i + 8, then + 4), then the two cross-row exchanges.  Replaces `for (off = 32; off >= SLW; off >>= 1) x += __shfl_xor(x, off)`,
+// which is one ds_bpermute_b32 + s_waitcnt per value and step (the conv / GEMM epilogues reduce 16 statistics values per tile this way).
+template <int SLW>
+GP_DEV float slot_sum(float x) {
+    static_assert(SLW == 4 || SLW == 8 || SLW == 16, "slot width");
+    if (SLW <= 8) x += dpp_move<0x108, 0xf>(x);    // row_shl:8
+    if (SLW == 4) x += dpp_move<0x104, 0xf>(x);    // row_shl:4
+    return xor32_sum(xor16_sum(x));
+}
+// sum over each row of 16 lanes, valid in the row's lane 0
+GP_DEV float row16_sum(float x) {
+    x += dpp_move<0x108, 0xf>(x);
+    x += dpp_move<0x104, 0xf>(x);
+    x += dpp_move<0x102, 0xf>(x);
+    x += dpp_move<0x101, 0xf>(x);
+    return x;
+}
+
 // one group of the scheduler's instruction pattern (masks: 0x002 VALU, 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x400 transcendental)
 template <int MASK, int N>
 GP_DEV void sgb() { __builtin_amdgcn_sched_group_barrier(MASK, N, 0); }

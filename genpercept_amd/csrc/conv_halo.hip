@@ -639,10 +639,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         }
         if (STATS) {
 #pragma unroll
-            for (int off = 32; off >= 8; off >>= 1) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { st_s[e] += __shfl_xor(st_s[e], off); st_q[e] += __shfl_xor(st_q[e], off); }
-            }
+            for (int e = 0; e < 8; ++e) { st_s[e] = slot_sum<8>(st_s[e]); st_q[e] = slot_sum<8>(st_q[e]); }
             if (lane_o < 8) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {

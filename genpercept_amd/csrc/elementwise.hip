@@ -445,11 +445,9 @@ __global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict
     }
     if (stats) {  // per (tile, channel) sums of the stored values: 16 pixel lanes -> lane a == 0, 4 waves -> LDS -> one thread per channel
 #pragma unroll
-        for (int off = 8; off >= 1; off >>= 1)
+        for (int ip = 0; ip < 4; ++ip)
 #pragma unroll
-            for (int ip = 0; ip < 4; ++ip)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { st_s[ip][e] += __shfl_xor(st_s[ip][e], off); st_q[ip][e] += __shfl_xor(st_q[ip][e], off); }
+            for (int e = 0; e < 8; ++e) { st_s[ip][e] = row16_sum(st_s[ip][e]); st_q[ip][e] = row16_sum(st_q[ip][e]); }
         if (a == 0) {
 #pragma unroll
             for (int ip = 0; ip < 4; ++ip)

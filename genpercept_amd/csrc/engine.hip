@@ -376,6 +376,8 @@ struct gp_engine {
     // the host in double once per distinct t and kept on the device, so a change of timestep is one stream-ordered D2D copy
     // (the multi-step archs walk 10-50 timesteps per image; genpercept_pipeline.py:447-463).
     const float* timestep_biases(float t) {
+        // an engine finalised without the UNet's time-embedding weights (a VAE-only engine) has nothing to fold and no arena to copy into
+        if (te_w1.empty() || te_b1.empty() || !temb_arena) throw std::out_of_range("missing weight: unet.time_embedding.* (this engine holds no UNet)");
         auto it = temb_cache.find(t);
         if (it != temb_cache.end()) return it->second;
         const int c0 = cfg.unet_block_out[0], te = c0 * 4, half = c0 / 2;
@@ -956,7 +958,9 @@ struct gp_engine {
             p.vt_out = (h16_t*)zero;  // (non-null for the applicability test)
             // measured (tools/kbench, weight-cold): 4 x 2304 tokens, C = 640: 43 us fused vs 25 + 25; 4 x 576, C = 1280: 46 vs 29 + 25; at
             // 4 x 9216 tokens, C = 320 the transposed stores of the V third (16 bytes per channel row and lane) eat the saving: 55 vs 29 + 25
-            static const int fuse_max_rows = getenv("GENPERCEPT_QKV_FUSE_MAX_ROWS") ? atoi(getenv("GENPERCEPT_QKV_FUSE_MAX_ROWS")) : 16384;
+            // (same-box pipeline A/B, tools/gpu_ab_r03.sh: fusing every level is 0.1-0.2 ms per pass ahead of fusing none, the 4 x 9216 level
+            // included: one launch and one pass over the LayerNorm output less outweigh the slower V slices)
+            static const int fuse_max_rows = getenv("GENPERCEPT_QKV_FUSE_MAX_ROWS") ? atoi(getenv("GENPERCEPT_QKV_FUSE_MAX_ROWS")) : (1 << 30);
             if (!no_fuse && p.M <= fuse_max_rows && !t.qkv.bias && l1.C == t.qkv.cin_pad && igemm_uses_pgemm(p, 0)) {
                 qk = new_act(x.B, x.H, x.W, 2 * C);
                 vt = (h16_t*)pool.alloc((size_t)x.B * C * Tpad * sizeof(h16_t));
@@ -1166,7 +1170,9 @@ struct gp_engine {
     }
 
     // z_in: NHWC with 64 allocated channels holding the UNet output v (in_scale = -1/scaling) or a pred latent (1/scaling)
-    Act vae_decode(const Act& z_in, float in_scale) {
+    // out_dev != nullptr: the caller wants the fp32 NCHW result of decode_pred (+ clip / shift unless raw); when the fused tail kernel takes
+    // the last three layers (conv_few.hip) it is written directly and the returned Act is empty, else the caller runs launch_decode_epilogue
+    Act vae_decode(const Act& z_in, float in_scale, float* out_dev = nullptr, int mean3 = 0, int raw = 0) {
         const int L = cfg.vae_latent_channels;
         Act z = new_act(z_in.B, z_in.H, z_in.W, 64);
         mark("post_quant_conv");
@@ -1192,11 +1198,25 @@ struct gp_engine {
                 h = y;
             }
         }
+        const PackedW& wout = convs.at("vae.decoder.conv_out");
+        if (out_dev && conv_few_applicable(h.C, wout.cout, h.H, h.W) && wout.cin_pad == h.C) {
+            float *scale, *shift;
+            gn_scale_shift(h, norms.at("vae.decoder.conv_norm_out"), cfg.vae_norm_eps, scale, shift);
+            const double fl = 2.0 * (double)h.pixels() * wout.cout * 9.0 * h.C;
+            tm.flops_igemm += fl;
+            tm.n_igemm++;
+            mark("conv_few gn+silu+conv3x3+decode " + dims(h), fl);
+            prof_begin(0);
+            launch_conv_few(h.p, wout.w, wout.bias, scale, shift, zero, out_dev, h.B, h.H, h.W, 1, mean3, raw, ncu, st);
+            prof_end();
+            drop(h);
+            return Act{};
+        }
         Act n = groupnorm(h, norms.at("vae.decoder.conv_norm_out"), cfg.vae_norm_eps, true);
         drop(h);
         ConvOpt o;
         o.n_store = 4;  // 3 real channels + one zero: 8-byte pixels for the epilogue
-        Act out = conv(n, convs.at("vae.decoder.conv_out"), o);
+        Act out = conv(n, wout, o);
         drop(n);
         return out;
     }
@@ -1544,12 +1564,14 @@ gp_status gp_infer(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, i
             e->drop(lat);
             if (stage_ev) HIPCHK(hipEventRecord(e->ev[2], e->st));
             // scheduler step with beta == 1: pred_x0 = -v (F5); decode_pred divides by the scaling factor
-            Act dec = e->vae_decode(v, -1.0f / e->cfg.vae_scaling_factor);
-            e->drop(v);
             const int mean3 = !(mode == GP_MODE_NORMAL || mode == GP_MODE_SEG);
-            e->mark("decode_epilogue");
-            launch_decode_epilogue(dec.p, out_dev, B, dec.H, dec.W, dec.C, mean3, 0, e->st);
-            e->drop(dec);
+            Act dec = e->vae_decode(v, -1.0f / e->cfg.vae_scaling_factor, out_dev, mean3, 0);
+            e->drop(v);
+            if (dec.p) {  // (the fused tail kernel wrote out_dev itself otherwise)
+                e->mark("decode_epilogue");
+                launch_decode_epilogue(dec.p, out_dev, B, dec.H, dec.W, dec.C, mean3, 0, e->st);
+                e->drop(dec);
+            }
         } else {
             Act feats[4];
             e->unet(lat, feats, false);
@@ -1622,12 +1644,14 @@ gp_status gp_infer_steps(gp_engine* e, const void* rgb_dev, int is_u8, int B, in
         e->drop(lat);
         if (e->timestep != t_before) e->set_timestep_on_stream(t_before);
         if (stage_ev) HIPCHK(hipEventRecord(e->ev[2], e->st));
-        Act dec = e->vae_decode(x0, 1.0f / e->cfg.vae_scaling_factor);
-        e->drop(x0);
         const int mean3 = !(mode == GP_MODE_NORMAL || mode == GP_MODE_SEG);
-        e->mark("decode_epilogue");
-        launch_decode_epilogue(dec.p, out_dev, B, dec.H, dec.W, dec.C, mean3, 0, e->st);
-        e->drop(dec);
+        Act dec = e->vae_decode(x0, 1.0f / e->cfg.vae_scaling_factor, out_dev, mean3, 0);
+        e->drop(x0);
+        if (dec.p) {
+            e->mark("decode_epilogue");
+            launch_decode_epilogue(dec.p, out_dev, B, dec.H, dec.W, dec.C, mean3, 0, e->st);
+            e->drop(dec);
+        }
         e->mark("END", 0.0, 0);
         if (stage_ev) {
             HIPCHK(hipEventRecord(e->ev[3], e->st));
@@ -1679,12 +1703,14 @@ gp_status gp_vae_decode(gp_engine* e, const float* pred_latent, int B, int h, in
     return guard(e, [&] {
         check_ready(e, stream);
         Act z = e->from_nchw_f32(pred_latent, B, e->cfg.vae_latent_channels, h, w, 64);
-        Act dec = e->vae_decode(z, 1.0f / e->cfg.vae_scaling_factor);
-        e->drop(z);
         // decode_pred (genpercept_pipeline.py:507-526): channel mean for 1-channel modes, no clip / shift
-        e->mark("decode_epilogue");
-        launch_decode_epilogue(dec.p, out, B, h * 8, w * 8, dec.C, mean3, 1, e->st);
-        e->drop(dec);
+        Act dec = e->vae_decode(z, 1.0f / e->cfg.vae_scaling_factor, out, mean3, 1);
+        e->drop(z);
+        if (dec.p) {
+            e->mark("decode_epilogue");
+            launch_decode_epilogue(dec.p, out, B, h * 8, w * 8, dec.C, mean3, 1, e->st);
+            e->drop(dec);
+        }
         HIPCHK(hipGetLastError());
     });
 }
@@ -1838,6 +1864,22 @@ gp_status gp_gemm(const void* a, int lda, const void* bt, int ldb, const float* 
         if (const char* dbg = getenv("GENPERCEPT_IGEMM_DBG")) p.dbg = atoi(dbg);  // profiling ablations (tools/kbench)
         attach_splitk_scratch(p, tile_hint);
         launch_igemm(p, tile_hint, (hipStream_t)stream);
+        HIPCHK(hipGetLastError());
+        return GP_OK;
+    } catch (...) { return GP_ERR_HIP; }
+}
+
+gp_status gp_decoder_tail(const void* in, const void* w_packed, const float* bias, const float* gamma, const float* beta, int groups, float eps,
+                          int B, int H, int W, int Cin, int mean3, int raw, float* out, void* stream) {
+    if (!in || !w_packed || !gamma || !beta || !out || B < 1 || !conv_few_applicable(Cin, 3, H, W) || (Cin % groups)) return GP_ERR_INVALID;
+    try {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        const size_t need = (size_t)groupnorm_ws_floats(B, H * W, Cin, groups) + 2 * (size_t)B * Cin;
+        float* ws = scratch_floats(0, need);
+        float* scale = ws + groupnorm_ws_floats(B, H * W, Cin, groups);
+        float* shift = scale + (size_t)B * Cin;
+        launch_groupnorm_stats((const h16_t*)in, gamma, beta, B, H * W, Cin, groups, eps, ws, scale, shift, (hipStream_t)stream);
+        launch_conv_few((const h16_t*)in, (const h16_t*)w_packed, bias, scale, shift, zero_page(), out, B, H, W, 1, mean3, raw, 0, (hipStream_t)stream);
         HIPCHK(hipGetLastError());
         return GP_OK;
     } catch (...) { return GP_ERR_HIP; }

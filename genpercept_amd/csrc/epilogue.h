@@ -100,10 +100,7 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
             // deterministic tree: lanes of a wave sharing a slot (xor-shuffles), then the waves through LDS (the staging area is
             // free once everybody has left the store loop), then one thread per channel writes this tile's partial
 #pragma unroll
-            for (int off = 32; off >= SL; off >>= 1) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { st_s[e] += __shfl_xor(st_s[e], off); st_q[e] += __shfl_xor(st_q[e], off); }
-            }
+            for (int e = 0; e < 8; ++e) { st_s[e] = slot_sum<SL>(st_s[e]); st_q[e] = slot_sum<SL>(st_q[e]); }
             __syncthreads();
             constexpr int NWV = NTHREADS / 64;
             float* red = (float*)smem;  // [NWV][SL][16]

@@ -158,6 +158,12 @@ void launch_bilinear(const h16_t* in, h16_t* out, int B, int Hi, int Wi, int Ho,
 void launch_dpt_final(const h16_t* in, const float* w, float bias, float* out, int B, int HW, int Cin, hipStream_t s);  // ReLU'd 32ch -> 1
 void launch_minmax_norm(float* x, int B, long long n, float* ws, hipStream_t s);  // per-image (x-min)/(max-min)
 
+// conv_few.hip: the VAE decoder's tail fused -- GroupNorm apply (+ SiLU) of the input, conv3x3 128 -> 3, [mean of the 3 channels], clip / shift
+// unless raw, fp32 NCHW out (genpercept_pipeline.py:521-525,469-472).  scale / shift: the [B][128] affine form launch_groupnorm_* produce.
+bool conv_few_applicable(int Cin, int Cout, int H, int W);
+void launch_conv_few(const h16_t* in, const h16_t* wt, const float* bias, const float* scale, const float* shift, const h16_t* zero, float* out, int B,
+                     int H, int W, int silu, int mean3, int raw, int ncu, hipStream_t s);
+
 // prepost.hip: device-side pre / post processing of GenPerceptPipeline.__call__ (resize with torchvision semantics, colour map, quantisation)
 void launch_resize(const void* in, void* out, float* tmp, long long planes, int Hi, int Wi, int Ho, int Wo, int mode, int u8, int clip01, hipStream_t s);
 void launch_clip01(const float* in, float* out, long long n, hipStream_t s);

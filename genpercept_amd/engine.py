@@ -110,6 +110,7 @@ SYMBOLS = {
     "gp_rgb_conv_in": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "gp_conv2d_stats": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp, _vp, _i, _f, _vp, _vp, _vp]),
     "gp_gemm": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
+    "gp_decoder_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "gp_gemm_qkv": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "gp_groupnorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "gp_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
@@ -472,6 +473,19 @@ def gemm(a: torch.Tensor, bt: torch.Tensor, bias=None, bias_mode: int = 1, resid
     if st != GP_OK:
         raise RuntimeError(f"gp_gemm failed ({st})")
     return out if batched else out[0]
+
+
+def decoder_tail(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
+                 mean3: bool, raw: bool = False) -> torch.Tensor:
+    """GroupNorm + SiLU + conv3x3(128 -> 3) + [channel mean] + clip / shift, fp32 NCHW (gp_decoder_tail)."""
+    lib = load_library()
+    b, h, w, c = x_nhwc.shape
+    out = torch.empty((b, 1 if mean3 else 3, h, w), dtype=torch.float32, device=x_nhwc.device)
+    st = lib.gp_decoder_tail(x_nhwc.data_ptr(), w_packed.data_ptr(), _ptr(bias), gamma.data_ptr(), beta.data_ptr(), groups, eps, b, h, w, c, int(mean3),
+                             int(raw), out.data_ptr(), _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_decoder_tail failed ({st})")
+    return out
 
 
 def gemm_qkv(a: torch.Tensor, w_packed: torch.Tensor, batch: int, tokens: int, c: int):

@@ -183,6 +183,12 @@ gp_status gp_conv2d_stats(const void* in, const void* w_packed, const float* bia
 gp_status gp_gemm(const void* a, int lda, const void* bt, int ldb, const float* bias, int bias_mode, const void* residual, int ldres, void* out,
                   int ldo, int M, int N, int K, int n_rows_bt, int n_store, int act, int out_fp32 /* 0 bf16, 1 fp32, 2 fp16 */, int batch, long long a_bs, long long bt_bs,
                   long long out_bs, int tile_hint, void* stream);
+/* The VAE decoder's tail in one kernel (diffusers AutoencoderKL.decoder conv_norm_out -> SiLU -> conv_out, call site
+ * genpercept_pipeline.py:521-522; channel mean :523-525; clip / shift :469-472): in NHWC [B][H][W][128] (this library's element type),
+ * w_packed = gp_pack_weight(conv_out.weight [3][128][3][3]), GroupNorm(groups, eps) statistics computed here, out fp32 NCHW
+ * [B][mean3 ? 1 : 3][H][W]; raw = 1: no clip / shift (decode_pred alone).  Cin must be 128 (GP_ERR_INVALID otherwise). */
+gp_status gp_decoder_tail(const void* in, const void* w_packed, const float* bias, const float* gamma, const float* beta, int groups, float eps,
+                          int B, int H, int W, int Cin, int mean3, int raw, float* out, void* stream);
 /* The self-attention input projections of a BasicTransformerBlock (attn1.to_q / to_k / to_v, bias-free in SD2.1; custom_unet.py's
  * Transformer2DModel blocks) as ONE GEMM over the stacked weight [3C][K] (gp_pack_weight of the concatenation): q | k go to qk_out
  * [B*T][2C] row-major, V goes to vt_out TRANSPOSED as [B][C][Tpad] (zero beyond T) -- the operand layout of gp_flash_attention.

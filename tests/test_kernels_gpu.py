@@ -317,6 +317,36 @@ def test_gemm_row_bias_batched_zero_fill(metric_log):
     assert float(out[:, :, t:].float().abs().max()) == 0.0, "padding columns must be written as zeros"
 
 
+@pytest.mark.parametrize("case", [(1, 16, 16), (2, 40, 56), (1, 33, 17), (3, 64, 64)])
+@pytest.mark.parametrize("mean3", [True, False])
+def test_decoder_tail_fused(case, mean3, metric_log):
+    """gp_decoder_tail: GroupNorm(32, eps 1e-6) + SiLU + conv3x3(128 -> 3) + [channel mean] + clip / shift in one kernel, fp32 NCHW out --
+    against torch on the same 16-bit-rounded input and weights (the normalised activations are rounded to the element type before the conv,
+    like every other conv input of the engine); ragged tiles, several tiles / images per persistent workgroup."""
+    e = _eng()
+    b, h, w = case
+    g = torch.Generator().manual_seed(h * 100 + w + b)
+    x = rbf(torch.randn(b, 128, h, w, generator=g) * 1.5 + 0.3)
+    wt = rbf(torch.randn(3, 128, 3, 3, generator=g) / math.sqrt(128 * 9) * 3.0)
+    bias = torch.randn(3, generator=g) * 0.2
+    gamma, beta = torch.randn(128, generator=g) * 0.3 + 1.0, torch.randn(128, generator=g) * 0.2
+    d = _dev()
+    wp = e.pack_weight(wt, device=d)
+    xd = e.to_nhwc_h16(x.to(d))
+    out = e.decoder_tail(xd, wp, bias.to(d), gamma.to(d), beta.to(d), 32, 1e-6, mean3)
+    n = rbf(F.silu(F.group_norm(x, 32, gamma, beta, eps=1e-6)))
+    y = F.conv2d(n, wt, bias, padding=1)
+    if mean3:
+        y = y.mean(dim=1, keepdim=True)
+    ref = (y.clamp(-1, 1) + 1) / 2
+    err = (out.cpu() - ref).abs()
+    tol = 3e-3 if e.act_dtype() == torch.bfloat16 else 5e-4   # the only 16-bit rounding on the path is the normalised conv input
+    metric_log(f"decoder_tail{case}[mean3={mean3}]" + ("" if e.act_dtype() == torch.bfloat16 else "[fp16]"), max_err=err.max().item(), mean_err=err.mean().item())
+    assert err.max().item() <= 4 * tol and err.mean().item() <= tol, (err.max().item(), err.mean().item())
+    raw = e.decoder_tail(xd, wp, bias.to(d), gamma.to(d), beta.to(d), 32, 1e-6, mean3, raw=True)
+    assert (raw.cpu() - y).abs().mean().item() <= 2 * tol
+
+
 @pytest.mark.parametrize("case", [(4, 576, 320), (2, 2304, 640), (4, 144, 1280), (1, 400, 64), (3, 272, 128)])
 def test_gemm_qkv_fused_projection(case, metric_log):
     """gp_gemm_qkv: attn1.to_q | to_k | to_v of a BasicTransformerBlock as one GEMM -- q | k row-major, V written transposed [B][C][Tpad] with

@@ -2,7 +2,7 @@
 # per-dispatch kernel trace (rocprofv3 --kernel-trace, no in-engine events) of two bench passes: true in-pipeline kernel durations and gaps
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out/kt; rm -rf gpurun_out/kt/*
 export TMPDIR=/tmp; ROOTD=$(pwd)
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$ROOTD/gpurun_out/kt/trace" -- python "$ROOTD/bench.py" --steps 1 --warmup 1 --no-cpu --no-profile ${BENCH_ARGS} > "$ROOTD/gpurun_out/kt/bench.log" 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$ROOTD/gpurun_out/kt/trace" -- python "$ROOTD/bench.py" --steps 1 --warmup 1 --no-cpu --no-profile --no-fp16 ${BENCH_ARGS} > "$ROOTD/gpurun_out/kt/bench.log" 2>&1)
 echo "exit $?"; tail -1 gpurun_out/kt/bench.log | cut -c1-200
 python3 - <<'PY'
 import csv, glob

@@ -248,6 +248,30 @@ static void bench_conv(const std::vector<long long>& a) {
     CK(hipFree(X)); CK(hipFree(O)); CK(hipFree(bias));
 }
 
+static void bench_convs(const std::vector<long long>& a) {  // convs:B,H,W,Cin,Cout  conv3x3 whose epilogue leaves GroupNorm statistics (+ finalize launch)
+    const int B = (int)a[0], H = (int)a[1], W = (int)a[2], Cin = (int)a[3], Cout = (int)a[4];
+    const int nrows = gp_packed_rows(Cout);
+    h16 *X, *O;
+    float *bias, *g, *bt, *sc, *sh;
+    CK(hipMalloc(&X, (size_t)B * H * W * Cin * 2)); CK(hipMalloc(&O, (size_t)B * H * W * Cout * 2));
+    CK(hipMalloc(&bias, nrows * 4)); CK(hipMalloc(&g, Cout * 4)); CK(hipMalloc(&bt, Cout * 4)); CK(hipMalloc(&sc, B * Cout * 4)); CK(hipMalloc(&sh, B * Cout * 4));
+    fill(X, (size_t)B * H * W * Cin, 21); fillf(bias, nrows, 7, 0.5f); fillf(g, Cout, 8); fillf(bt, Cout, 9);
+    const double flops = 2.0 * B * H * W * (double)Cout * Cin * 9;
+    auto go = [&]() {
+        if (gp_conv2d_stats(X, g_arena, bias, nullptr, O, B, H, W, Cin, Cout, 3, 0, 0, g, bt, 32, 1e-6f, sc, sh, nullptr) != GP_OK) { fprintf(stderr, "conv2d_stats failed\n"); exit(3); }
+    };
+    const float t = time_us([&](int) { go(); }, g_iters);
+    std::vector<float> hs((size_t)B * Cout), hh((size_t)B * Cout);
+    CK(hipMemcpy(hs.data(), sc, hs.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hh.data(), sh, hh.size() * 4, hipMemcpyDeviceToHost));
+    double c1 = 0, c2 = 0;
+    for (size_t i = 0; i < hs.size(); ++i) { c1 += hs[i] * (double)((i % 7) + 1); c2 += hh[i] * (double)((i % 5) + 1); }
+    printf("convs B=%d %dx%d Cin=%-5d Cout=%-5d  %8.2f us %7.1f TF/s (conv + stats epilogue + finalize)  scale/shift checksums %.8e %.8e\n", B, H, W, Cin, Cout, t,
+           flops / t * 1e-6, c1, c2);
+    fflush(stdout);
+    CK(hipFree(X)); CK(hipFree(O)); CK(hipFree(bias)); CK(hipFree(g)); CK(hipFree(bt)); CK(hipFree(sc)); CK(hipFree(sh));
+}
+
 static void bench_attn(const std::vector<long long>& a) {
     const int B = (int)a[0], T = (int)a[1], heads = (int)a[2];
     const int C = heads * 64, Tpad = (T + 63) / 64 * 64;
@@ -380,6 +404,7 @@ int main(int argc, char** argv) {
         else if (!strncmp(s, "gemm:", 5)) bench_gemm(parse_nums(s + 5));
         else if (!strncmp(s, "conv:", 5)) bench_conv(parse_nums(s + 5));
         else if (!strncmp(s, "attn:", 5)) bench_attn(parse_nums(s + 5));
+        else if (!strncmp(s, "convs:", 6)) bench_convs(parse_nums(s + 6));
         else if (!strncmp(s, "gn:", 3)) bench_gn(parse_nums(s + 3));
         else if (!strncmp(s, "xfold:", 6)) bench_xfold(parse_nums(s + 6));
 #ifdef KBENCH_HAVE_QKV
