@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // 180 workgroups of 4 waves on 256 CUs with 180+ dependent K-steps each -- 200 TFLOP/s; slicing K fills the machine.
 int igemm_ksplit(const IGemmParams& p, int tile_hint) {
     static const bool no_split = getenv("GENPERCEPT_NO_SPLITK") != nullptr;
+    if (tile_hint == 0 && !no_split && conv_img_applicable(p)) return conv_img_ksplit(p);  // whole-image tiles (conv_img.hip)
     if (tile_hint != 0 && tile_hint != 2) return 1;
     if (no_split || p.ks != 3 || p.ups || p.batch > 1 || p.out_fp32 || p.act == GP_ACT_GEGLU || p.bias_mode == GP_BIAS_ROW || p.in_scale) return 1;
     if ((p.n_store & 3) || (p.ldo & 3) || p.n_store != p.ldo) return 1;
@@ -321,6 +322,7 @@ static void launch_cfg(const IGemmParams& p, hipStream_t s) {
 bool conv_uses_halo(const IGemmParams& p, int tile_hint) {
     static const bool no_halo = getenv("GENPERCEPT_NO_HALO") != nullptr;  // A/B switch: generic implicit GEMM everywhere
     if (no_halo && tile_hint != 5) return false;
+    if (tile_hint == 0 && getenv("GENPERCEPT_NO_SPLITK") == nullptr && conv_img_applicable(p)) return false;  // 24x24 / 12x12 maps: conv_img.hip
     if (!(tile_hint == 5 || tile_hint == 0) || !conv_halo_applicable(p)) return false;
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
     const long long tiles = (long long)((p.Wo + 15) / 16) * ((p.Ho + 15) / 16) * p.B * ((ncols + 127) / 128);
@@ -387,6 +389,15 @@ void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s) {
         // the partial sums live in a workspace the CALLER owns (an engine takes it from its pool): no process-global state here
         const size_t slice = (size_t)p.M * p.n_store, need = slice * S;
         float* ws = (p.splitk_ws && (size_t)p.splitk_ws_floats >= need) ? p.splitk_ws : nullptr;
+        if (ws && tile_hint == 0 && conv_img_applicable(p)) {
+            launch_conv_img(p, ws, S, s);
+            const long long total = (long long)p.M * (p.n_store >> 2);
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, S, (long long)slice, p.M, p.N, p.n_store,
+                               p.bias_mode == GP_BIAS_COL ? p.bias : nullptr, p.res, p.ldres, p.act, (h16_t*)p.out, p.ldo);
+            return;
+        }
         if (ws) {
             IGemmParams q = p;
             q.out = ws; q.out_fp32 = 1; q.ldo = p.n_store; q.bias = nullptr; q.bias_mode = GP_BIAS_NONE; q.res = nullptr; q.act = GP_ACT_NONE;

@@ -158,6 +158,12 @@ void launch_bilinear(const h16_t* in, h16_t* out, int B, int Hi, int Wi, int Ho,
 void launch_dpt_final(const h16_t* in, const float* w, float bias, float* out, int B, int HW, int Cin, hipStream_t s);  // ReLU'd 32ch -> 1
 void launch_minmax_norm(float* x, int B, long long n, float* ws, hipStream_t s);  // per-image (x-min)/(max-min)
 
+// conv_img.hip: 3x3 stride-1 convs whose maps tile into 576-pixel units (24x24, 12x12 x 4): whole-image tiles, K split over workgroups,
+// fp32 partial sums [S][M][N] into `part` (then splitk_reduce_kernel)
+bool conv_img_applicable(const IGemmParams& p);
+int conv_img_ksplit(const IGemmParams& p);
+void launch_conv_img(const IGemmParams& p, float* part, int S, hipStream_t s);
+
 // conv_few.hip: the VAE decoder's tail fused -- GroupNorm apply (+ SiLU) of the input, conv3x3 128 -> 3, [mean of the 3 channels], clip / shift
 // unless raw, fp32 NCHW out (genpercept_pipeline.py:521-525,469-472).  scale / shift: the [B][128] affine form launch_groupnorm_* produce.
 bool conv_few_applicable(int Cin, int Cout, int H, int W);
