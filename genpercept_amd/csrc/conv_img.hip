@@ -51,7 +51,7 @@ struct ConvImgParams {
     const h16_t* wt;     // packed [rows][9][Cin]
     const h16_t* zero;
     float* part;         // fp32 [S][B*H*W][Cout]
-    int B, H, W, Cin, Cout, NB, S;
+    int B, H, W, Cin, Cout, NB, S, wrows;   // wrows: rows of `wt` that exist (>= Cout)
 };
 
 __global__ __launch_bounds__(CI_THREADS) void conv_img_kernel(const ConvImgParams p) {
@@ -73,35 +73,37 @@ __global__ __launch_bounds__(CI_THREADS) void conv_img_kernel(const ConvImgParam
 
     // ---- DMA sources ----------------------------------------------------------------------------------------------------------------------------
     // halo: piece = i * 768 + tid -> padded row piece >> 2, physical slot piece & 3; source = that pixel's 8 channels (logical slot), or zeros
-    long long h_off[CI_HIT];
-    unsigned h_ok = 0;
+    // (LDS-DMA through buffer resources, common.h: blds16 -- with the FLAT-encoded global_load_lds in flight hipcc turns every LDS wait into
+    // lgkmcnt(0), which serialised each ds_read with the three MFMAs it feeds; and a lane offset outside the resource simply reads zeros: the
+    // zero padding of the maps needs no zero page)
+    const buf_rsrc_t in_rs = make_rsrc(p.in, (unsigned)((long long)p.B * HWi * p.Cin * 2));
+    const buf_rsrc_t wt_rs = make_rsrc(p.wt, (unsigned)((long long)p.wrows * 9 * p.Cin * 2));
+    unsigned h_off[CI_HIT];   // byte offsets
 #pragma unroll
     for (int i = 0; i < CI_HIT; ++i) {
         const int piece = i * CI_THREADS + tid, row = piece >> 2, ps = piece & 3;
         const int img = row / PP, rem = row - img * PP;
         const int py = rem / Wp, px = rem - py * Wp;
         const bool ok = row < HROWS && py >= 1 && py <= p.H && px >= 1 && px <= p.W;
-        h_off[i] = ((((long long)(b0 + img) * p.H + (py - 1)) * p.W + (px - 1)) * p.Cin) + ((ps ^ ci_swz(row)) << 3);
-        if (ok) h_ok |= 1u << i;
+        h_off[i] = ok ? (unsigned)((((((b0 + img) * p.H + (py - 1)) * p.W + (px - 1)) * p.Cin) + ((ps ^ ci_swz(row)) << 3)) * 2) : 0xfffff000u;
     }
     // weights: piece tid -> tap_in = tid >> 8, row = (tid & 255) >> 2, physical slot tid & 3
-    const h16_t* w_src;
+    unsigned w_off;
     {
         const int tap_in = tid >> 8, row = (tid & 255) >> 2, ps = tid & 3;
-        w_src = p.wt + ((long long)(n0 + row) * 9 + tap_in) * p.Cin + ((ps ^ ci_swz(row)) << 3);
+        w_off = (unsigned)((((n0 + row) * 9 + tap_in) * p.Cin + ((ps ^ ci_swz(row)) << 3)) * 2);
     }
     auto stage_w = [&](int s) __attribute__((always_inline)) {  // step s = (chunk c_begin + s / 3, kernel row s % 3)
         const int c = c_begin + s / 3, ky = s % 3;
-        glds16(w_src + (long long)ky * 3 * p.Cin + c * 32, smem + CI_W_OFF + (s & (CI_NW - 1)) * CI_WSTEP + wave * 1024);
+        blds16(wt_rs, w_off, (unsigned)((ky * 3 * p.Cin + c * 32) * 2), smem + CI_W_OFF + (s & (CI_NW - 1)) * CI_WSTEP + wave * 1024);
     };
     auto stage_h = [&](int cl) __attribute__((always_inline)) {  // local chunk cl
         const int c = c_begin + cl;
         char* dst = smem + (cl & 1) * CI_HBUF;
 #pragma unroll
         for (int i = 0; i < CI_HIT; ++i) {
-            const h16_t* src = ((h_ok >> i) & 1u) ? p.in + h_off[i] + c * 32 : p.zero;
             const int first = i * CI_THREADS + wave * 64;   // first piece of this wave's instruction
-            glds16(src, first < CI_HROWS_MAX * 4 ? dst + first * 16 : smem + CI_DUMP_OFF);
+            blds16(in_rs, h_off[i], (unsigned)(c * 64), first < CI_HROWS_MAX * 4 ? dst + first * 16 : smem + CI_DUMP_OFF);
         }
     };
 
@@ -137,8 +139,11 @@ __global__ __launch_bounds__(CI_THREADS) void conv_img_kernel(const ConvImgParam
     if (nsteps > 1) stage_w(1);
     if (nsteps > 2) stage_w(2);
 
-    for (int s = 0; s < nsteps; ++s) {
-        const int cl = s / 3, ky = s - 3 * cl;
+    // one step = (chunk cl, kernel row KY); KY is a compile-time constant so that the 27 pixel-fragment offsets stay in registers (as a
+    // run-time select hipcc moved the table to scratch memory: a scratch_load + s_waitcnt vmcnt(0) in front of every pixel-fragment read)
+    auto step = [&](auto kyc, int cl) __attribute__((always_inline)) {
+        constexpr int ky = decltype(kyc)::value;
+        const int s = 3 * cl + ky;
         // my DMA of W(s) (and, in a chunk's first step, of its halo) has landed; younger ones may stay in flight: W(s+1), W(s+2) and, after
         // a chunk's first step, the five halo pieces of the next chunk (issue order: W(s+3), then halo(cl+1), right after the barrier below)
         {
@@ -151,22 +156,51 @@ __global__ __launch_bounds__(CI_THREADS) void conv_img_kernel(const ConvImgParam
         if (ky == 0 && cl + 1 < NC) stage_h(cl + 1);      // buffer of chunk cl-1: last read in step s-1
         const unsigned hb = base + (cl & 1) * CI_HBUF;
         const unsigned wb = base + CI_W_OFF + (s & (CI_NW - 1)) * CI_WSTEP;
+        // three taps; the seven fragments of tap kx+1 are requested before tap kx's twelve MFMAs issue (two register sets).  The LDS reads are
+        // inline asm with hand-counted lgkmcnt waits: hipcc orders every ds_read it can see behind the buffer-form LDS-DMA still in flight
+        // (s_waitcnt vmcnt(2) / (1) / (0) inside this loop: the weight ring drained every step), and with the FLAT-form DMA it waits
+        // lgkmcnt(0) before every MFMA batch instead.  What orders these reads against the DMA is the protocol above (counted vmcnt + barrier).
+        struct Frag { h16x8_t w[4], x[3]; };
+        unsigned hb_v = hb, wb_v = wb;   // (non-const copies: the asm operands of a generic lambda may not name the const locals)
+        auto load_frag = [&](Frag& f, auto kxc) __attribute__((always_inline)) {
+            constexpr int KX = decltype(kxc)::value;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            h16x8_t wf[4], xf[3];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = lds_frag(wb + wa[i], kx * 4096);
-            // tap = 3 ky + kx: the row offset is a run-time select between three compile-time columns of xa
+            for (int i = 0; i < 4; ++i) {
+                const unsigned aw = wb_v + wa[i];
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.w[i]) : "v"(aw), "n"(KX * 4096));
+            }
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const unsigned off = ky == 0 ? xa[j][kx] : (ky == 1 ? xa[j][3 + kx] : xa[j][6 + kx]);
-                xf[j] = lds_frag(hb + off, 0);
+                const unsigned ax = hb_v + xa[j][3 * ky + KX];
+                asm volatile("ds_read_b128 %0, %1" : "=v"(f.x[j]) : "v"(ax));
             }
+        };
+        auto mfma12 = [&](const Frag& f) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc[i][j] = mfma_16x16x32(wf[i], xf[j], acc[i][j]);
-        }
+                for (int j = 0; j < 3; ++j) acc[i][j] = mfma_16x16x32(f.w[i], f.x[j], acc[i][j]);
+        };
+        Frag fa, fb;
+        load_frag(fa, IC<0>{});
+        load_frag(fb, IC<1>{});
+        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(fa.w[0]), "+v"(fa.w[1]), "+v"(fa.w[2]), "+v"(fa.w[3]), "+v"(fa.x[0]), "+v"(fa.x[1]), "+v"(fa.x[2]));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma12(fa);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag(fa, IC<2>{});
+        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(fb.w[0]), "+v"(fb.w[1]), "+v"(fb.w[2]), "+v"(fb.w[3]), "+v"(fb.x[0]), "+v"(fb.x[1]), "+v"(fb.x[2]));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma12(fb);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa.w[0]), "+v"(fa.w[1]), "+v"(fa.w[2]), "+v"(fa.w[3]), "+v"(fa.x[0]), "+v"(fa.x[1]), "+v"(fa.x[2]));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma12(fa);
+    };
+    for (int cl = 0; cl < NC; ++cl) {
+        step(IC<0>{}, cl);
+        step(IC<1>{}, cl);
+        step(IC<2>{}, cl);
     }
 
     // ---- fp32 partial sums of this K slice: lane (a15, q) holds channels 16 i + 4 q .. + 3 of pixel 16 j + a15 ---------------------------------------
@@ -202,15 +236,18 @@ int conv_img_ksplit(const IGemmParams& p) {
     const int nb = conv_img_nb(p.B, p.Hi, p.Wi);
     const int tiles = (p.B / nb) * (p.N / CI_BN);
     int S = 256 / tiles;                  // ~ one workgroup per CU
+    if (S < 2 && tiles <= 384) S = 2;     // (batch 8 at 24x24: 160 tiles; the partial sums always go through the workspace, so S >= 2)
     const int nc = p.Cin >> 5;
     if (S > nc / 2) S = nc / 2;           // at least two 32-channel chunks (six steps) per slice
     if (S > 16) S = 16;
+    static const int s_env = getenv("GENPERCEPT_CONV_IMG_S") ? atoi(getenv("GENPERCEPT_CONV_IMG_S")) : 0;  // tuning switch
+    if (s_env > 0 && s_env <= nc / 2 && s_env <= 16) S = s_env;
     return S < 1 ? 1 : S;
 }
 
 void launch_conv_img(const IGemmParams& p, float* part, int S, hipStream_t s) {
     const int nb = conv_img_nb(p.B, p.Hi, p.Wi);
-    ConvImgParams q{p.in, p.wt, p.zero, part, p.B, p.Hi, p.Wi, p.Cin, p.N, nb, S};
+    ConvImgParams q{p.in, p.wt, p.zero, part, p.B, p.Hi, p.Wi, p.Cin, p.N, nb, S, p.n_rows};
     static unsigned long long attr_mask = 0;
     gp_once_per_device(&attr_mask, [&] { (void)hipFuncSetAttribute((const void*)conv_img_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CI_LDS); });
     const int grid = (p.B / nb) * (p.N / CI_BN) * S;

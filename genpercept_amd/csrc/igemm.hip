@@ -332,6 +332,10 @@ bool conv_uses_halo(const IGemmParams& p, int tile_hint) {
 bool igemm_uses_pgemm(const IGemmParams& p, int tile_hint) {
     static const bool no_pgemm = getenv("GENPERCEPT_NO_PGEMM") != nullptr;  // A/B switch
     if (tile_hint == 7) return pgemm_applicable(p);
+    // fewer than 1024 rows (the UNet mid block at 768x768: 4 x 144 tokens): five 128-row tiles per column slice leave the persistent kernel's
+    // workgroups one tile each, 64x64 tiles on three workgroups per CU are 20-25 % faster (tools/kbench: 11.6 vs 15.3 us at N = K = 1280,
+    // 36.7 vs 46.8 us at K = 5120); the GEGLU and the fused q | k | V^T forms only exist in the persistent kernel
+    if (tile_hint == 0 && p.M < 1024 && p.act != GP_ACT_GEGLU && !p.vt_out) return false;
     return tile_hint == 0 && !no_pgemm && pgemm_applicable(p);
 }
 
