@@ -344,7 +344,8 @@ struct Halo3Geom {
 };
 
 // FUSED: 0 plain input, 1 input transform x * scale[b][c] + shift[b][c] (GroupNorm apply), 2 the same followed by SiLU.
-// ABL: compile-time ablations for profiling (2 no MFMA, 4 no output stores, 8 no halo DMA, 16 no weight DMA)
+// ABL: compile-time ablations for profiling (2 no MFMA, 4 no output stores, 8 no halo DMA, 16 no weight DMA, 32 no waits for the DMA,
+// 64 / 128 every wave issues its DMA before / after its MFMAs, 256 every other step barrier, 512 no step barrier; >= 2 except 64 / 128: garbage results)
 template <bool UPS, int FUSED, int ABL = 0>
 __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p) {
     using G = HaloGeom<UPS>;
@@ -558,6 +559,18 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     const unsigned st_base = (unsigned)(unsigned long long)s_st, bias_base = (unsigned)(unsigned long long)s_bias;
     // Specialised at compile time on (activation present, residual present, statistics wanted): with run-time checks per element
     // the epilogue was ~2000 VALU + 130 scalar branches per wave and tile, as much SIMD time as the 18 K-steps of a K = 1152 layer.
+    // the accumulators of a tile start at the bias of their channels (rows of fragment i: channels wn * 64 + 32 * (i / 2) + 8 * q + 4 * (i & 1) ..+3)
+    auto acc_init = [&]() __attribute__((always_inline)) {
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const unsigned ba = bias_base + (wn * TN + 8 * (lane_o >> 4)) * 4;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const f32x4_t bv = *(lds_f4_ptr)(ba + (32 * (i >> 1) + 4 * (i & 1)) * 4);
+#pragma unroll
+            for (int j = 0; j < FM; ++j) acc[i][j] = bv;
+        }
+    };
     auto epilogue_body = [&](unsigned stg, auto actc, auto resc, auto statc) __attribute__((always_inline)) {
         constexpr bool ACT = decltype(actc)::value != 0, RES = decltype(resc)::value != 0, STATS = decltype(statc)::value != 0;
         const int ty = sp_cur / tiles_x, tx = sp_cur - ty * tiles_x;
@@ -568,7 +581,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         const int pl = lane_o >> 3, sl8 = lane_o & 7;      // read-back role: pixels pl and pl + 8 of a tile row, channel slot sl8
         const int col = n0 + wn * TN + 8 * sl8;
         const bool col_ok = col < p.n_store;
-        const bool tail = col + 7 >= n_out;                // slot reaches into the zero-padded channels
+        // slot reaches into the zero-padded channels: masks for the packed words (4 VALU per stored slot instead of 16 selects)
+        unsigned tmask[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tmask[w] = (col + 2 * w < n_out ? 0xffffu : 0u) | (col + 2 * w + 1 < n_out ? 0xffff0000u : 0u);
         h16_t* outp = (h16_t*)p.out;
         int m2[FM][2];
         uint4 rv[FM][2];
@@ -583,12 +599,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
                     if (m2[j][h] >= 0 && p.res) rv[j][h] = *(const uint4*)(p.res + (long long)m2[j][h] * p.ldres + col);
                 }
             }
-        f32x4_t bv[FP][2];
-#pragma unroll
-        for (int ip = 0; ip < FP; ++ip) {
-            bv[ip][0] = *(lds_f4_ptr)(bias_base + (wn * TN + 32 * ip + 8 * q) * 4);
-            bv[ip][1] = *(lds_f4_ptr)(bias_base + (wn * TN + 32 * ip + 8 * q) * 4 + 16);
-        }
         float st_s[8], st_q[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
@@ -597,8 +607,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
 #pragma unroll
             for (int ip = 0; ip < FP; ++ip) {
                 const unsigned d = stg + (a15 * 64 + (((4 * ip + q) ^ (a15 & 7)) << 3)) * 4;
-                *(lds_f4_ptr)d = acc[2 * ip][j] + bv[ip][0];
-                *(lds_f4_ptr)(d + 16) = acc[2 * ip + 1][j] + bv[ip][1];
+                *(lds_f4_ptr)d = acc[2 * ip][j];
+                *(lds_f4_ptr)(d + 16) = acc[2 * ip + 1][j];
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -620,13 +630,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
                             else if (p.act == GP_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
                         }
                     }
-                    if (tail) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (col + e >= n_out) v[e] = 0.f;
-                    }
                     uint4 pk;
-                    pk.x = pack_h16x2(v[0], v[1]); pk.y = pack_h16x2(v[2], v[3]); pk.z = pack_h16x2(v[4], v[5]); pk.w = pack_h16x2(v[6], v[7]);
+                    pk.x = pack_h16x2(v[0], v[1]) & tmask[0]; pk.y = pack_h16x2(v[2], v[3]) & tmask[1];
+                    pk.z = pack_h16x2(v[4], v[5]) & tmask[2]; pk.w = pack_h16x2(v[6], v[7]) & tmask[3];
                     if (!(ABL & 4)) *(uint4*)(outp + m * p.ldo + col) = pk;
                     else asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
                     if (STATS) {
@@ -659,10 +665,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
             case 3: epilogue_body(stg, IC<0>{}, IC<1>{}, IC<1>{}); break;
             default: epilogue_body(stg, IC<1>{}, IC<1>{}, IC<1>{}); break;  // (rare: activation fused into a halo conv)
         }
-#pragma unroll
-        for (int i = 0; i < FN; ++i)
-#pragma unroll
-            for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        acc_init();
     };
     // Statistics are accumulated per WORKGROUP (all its tiles belong to one image and one channel slice) and written once at the end:
     // row (b, jw / tiles_n) of [B * R][N][2], R = J / tiles_n rows per image, followed by the pixel count of every row -- 36x fewer
@@ -694,6 +697,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     };
 
     // ---- prologue (first tile) ---------------------------------------------------------------------------------------------------------
+    acc_init();
     setup_fetch(sp_cur);
     stage_halo(0, 0);
     stage_w(0, w_step);
@@ -730,7 +734,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         const int adv = (TAP + 3) % 9 == 8 ? (tile_end ? w_tile_wrap : w_wrap) : w_step;
         // role split: waves 4-7 issue their DMA before the MFMAs, waves 0-3 after -- except in a tile's last step, where a DMA
         // issued first would sit under the epilogue's vmcnt(0)
-        const bool dma_first = second_half && !(TAP == 8 && tile_end);
+        const bool dma_first = ((ABL & 64) ? true : (ABL & 128) ? false : second_half) && !(TAP == 8 && tile_end);
         if (dma_first) {
             if (issue_w) stage_w(TAP % 3, adv);
             if (issue_h) stage_halo(PAR ^ 1, fcc);
@@ -792,7 +796,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
             mfma16(cur1);
             __builtin_amdgcn_sched_barrier(0);
             if (tile_end) {
-                halo_wait_vm<0>();  // everything this wave has in flight has landed: stores issued below cannot delay a certification
+                if (!(ABL & 32)) halo_wait_vm<0>();  // everything this wave has in flight has landed: stores issued below cannot delay a certification
                 if (!(ABL & 1)) epilogue((UPS ? a_base + G3::EP_OFF : a_base + PAR * A_BUF) + wave * 4096);
             }
             if (!final_) {
@@ -806,12 +810,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
             if (issue_h) stage_halo(PAR ^ 1, fcc);
         }
         if (TAP == 8 && final_) return;
-        if (TAP <= 1) { if (!final_) halo_wait_vm<A_IT + B_IT>(); else halo_wait_vm<B_IT>(); }
+        if (ABL & 32) {}  // (no waits for the DMA: results are garbage)
+        else if (TAP <= 1) { if (!final_) halo_wait_vm<A_IT + B_IT>(); else halo_wait_vm<B_IT>(); }
         else if (TAP < 6) halo_wait_vm<B_IT>();
         else if (TAP < 8) { if (final_) halo_wait_vm<0>(); else halo_wait_vm<B_IT>(); }
         else if (!tile_end) halo_wait_vm<B_IT>();  // (tile end: certified by the vmcnt(0) ahead of the epilogue)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(((ABL & 256) && (TAP & 1)) || (ABL & 512))) __builtin_amdgcn_s_barrier();  // (256: every other barrier, 512: none -- garbage results)
     };
     auto chunk = [&](auto parc, Half& fa, Half& fb) __attribute__((always_inline)) {
         if (tile_end && !final_) setup_fetch(sp_cur + sp_stride);  // from here on halo staging / normalisation belong to the next tile
@@ -862,7 +867,7 @@ static void launch_halo3_one(const IGemmParams& p, int grid, hipStream_t s) {
 }
 
 static void launch_halo3(const IGemmParams& p, int grid, hipStream_t s) {
-    const int abl = (p.dbg >> 9) & 63;  // profiling ablations (GENPERCEPT_IGEMM_DBG = 512 * ABL), plain convs only
+    const int abl = (p.dbg >> 9) & 1023;  // profiling ablations (GENPERCEPT_IGEMM_DBG = 512 * ABL), plain convs only
     const int fused = !p.in_scale ? 0 : p.in_silu ? 2 : 1;
     if (p.ups) {
         if (fused == 2) launch_halo3_one<true, 2, 0>(p, grid, s);
@@ -872,6 +877,17 @@ static void launch_halo3(const IGemmParams& p, int grid, hipStream_t s) {
     else if (fused == 1) launch_halo3_one<false, 1, 0>(p, grid, s);
     else if (abl == 2) launch_halo3_one<false, 0, 2>(p, grid, s);
     else if (abl == 24) launch_halo3_one<false, 0, 24>(p, grid, s);
+#ifdef GP_HALO_ABLATIONS  // the other r3 experiments: hipcc ... -DGP_HALO_ABLATIONS=1
+    else if (abl == 4) launch_halo3_one<false, 0, 4>(p, grid, s);
+    else if (abl == 8) launch_halo3_one<false, 0, 8>(p, grid, s);
+    else if (abl == 16) launch_halo3_one<false, 0, 16>(p, grid, s);
+    else if (abl == 32) launch_halo3_one<false, 0, 32>(p, grid, s);
+    else if (abl == 64) launch_halo3_one<false, 0, 64>(p, grid, s);
+    else if (abl == 128) launch_halo3_one<false, 0, 128>(p, grid, s);
+    else if (abl == 256) launch_halo3_one<false, 0, 256>(p, grid, s);
+    else if (abl == 512) launch_halo3_one<false, 0, 512>(p, grid, s);
+    else if (abl == 536) launch_halo3_one<false, 0, 536>(p, grid, s);
+#endif
     else launch_halo3_one<false, 0, 0>(p, grid, s);
 }
 
