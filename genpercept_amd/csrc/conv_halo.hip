@@ -345,7 +345,7 @@ struct Halo3Geom {
 
 // FUSED: 0 plain input, 1 input transform x * scale[b][c] + shift[b][c] (GroupNorm apply), 2 the same followed by SiLU.
 // ABL: compile-time ablations for profiling (2 no MFMA, 4 no output stores, 8 no halo DMA, 16 no weight DMA, 32 no waits for the DMA,
-// 64 / 128 every wave issues its DMA before / after its MFMAs, 256 every other step barrier, 512 no step barrier; >= 2 except 64 / 128: garbage results)
+// 64 / 128 every wave issues its DMA before / after its MFMAs, 256 every other step barrier, 512 no step barrier, 1024 no epilogue; >= 2 except 64 / 128: garbage results)
 template <bool UPS, int FUSED, int ABL = 0>
 __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p) {
     using G = HaloGeom<UPS>;
@@ -797,7 +797,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
             __builtin_amdgcn_sched_barrier(0);
             if (tile_end) {
                 if (!(ABL & 32)) halo_wait_vm<0>();  // everything this wave has in flight has landed: stores issued below cannot delay a certification
-                if (!(ABL & 1)) epilogue((UPS ? a_base + G3::EP_OFF : a_base + PAR * A_BUF) + wave * 4096);
+                if (ABL & 1024) {  // no epilogue, accumulators kept alive (the MFMAs stay)
+#pragma unroll
+                    for (int i = 0; i < FN; ++i)
+#pragma unroll
+                        for (int j = 0; j < FM; ++j) asm volatile("" ::"v"(acc[i][j]));
+                    acc_init();
+                } else if (!(ABL & 1)) epilogue((UPS ? a_base + G3::EP_OFF : a_base + PAR * A_BUF) + wave * 4096);
             }
             if (!final_) {
                 load_half(f0, IC<TAP1>{}, IC<PAR1>{}, IC<0>{});
@@ -867,7 +873,7 @@ static void launch_halo3_one(const IGemmParams& p, int grid, hipStream_t s) {
 }
 
 static void launch_halo3(const IGemmParams& p, int grid, hipStream_t s) {
-    const int abl = (p.dbg >> 9) & 1023;  // profiling ablations (GENPERCEPT_IGEMM_DBG = 512 * ABL), plain convs only
+    const int abl = (p.dbg >> 9) & 2047;  // profiling ablations (GENPERCEPT_IGEMM_DBG = 512 * ABL), plain convs only
     const int fused = !p.in_scale ? 0 : p.in_silu ? 2 : 1;
     if (p.ups) {
         if (fused == 2) launch_halo3_one<true, 2, 0>(p, grid, s);
@@ -887,6 +893,7 @@ static void launch_halo3(const IGemmParams& p, int grid, hipStream_t s) {
     else if (abl == 256) launch_halo3_one<false, 0, 256>(p, grid, s);
     else if (abl == 512) launch_halo3_one<false, 0, 512>(p, grid, s);
     else if (abl == 536) launch_halo3_one<false, 0, 536>(p, grid, s);
+    else if (abl == 1024) launch_halo3_one<false, 0, 1024>(p, grid, s);
 #endif
     else launch_halo3_one<false, 0, 0>(p, grid, s);
 }
