@@ -137,7 +137,7 @@ def test_model_detects_a_weaker_wait():
 def test_model_matches_source():
     s = open(os.path.join(ROOT, "genpercept_amd", "csrc", "conv_halo.hip")).read()
     for line in ["const bool issue_w = !(final_ && TAP >= 6), issue_h = TAP == 0 && !final_;",
-                 "const bool dma_first = second_half && !(TAP == 8 && tile_end);",
+                 "const bool dma_first = ((ABL & 64) ? true : (ABL & 128) ? false : second_half) && !(TAP == 8 && tile_end);",
                  "if (TAP <= 1) { if (!final_) halo_wait_vm<A_IT + B_IT>(); else halo_wait_vm<B_IT>(); }",
                  "else if (TAP < 6) halo_wait_vm<B_IT>();",
                  "else if (TAP < 8) { if (final_) halo_wait_vm<0>(); else halo_wait_vm<B_IT>(); }",
