@@ -435,31 +435,41 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     // their zeros through a select.  LDS accesses by integer address (see common.h).
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) u32x4_t* lds_u4_ptr;
-    struct TPart { u32x4_t raw; f32x4_t s0, s1, h0, h1; float v[8]; unsigned addr; bool ok; };
+    struct TPart { u32x4_t raw; float v[8]; unsigned addr; bool ok; };
     const unsigned dump_base = (unsigned)(unsigned long long)dump;
-    auto tp_load = [&](TPart& t, int buf, int cc, int k) __attribute__((always_inline)) {
+    // A thread always handles the same LOGICAL channel slot c = tid & 7 of its halo rows (physical 16-byte slot c ^ key(column)), so scale / shift
+    // of its eight channels are read once per chunk into registers (tbl_load) instead of four 16-byte LDS reads per item.
+    f32x4_t gs0, gs1, gh0, gh1;
+    auto tbl_load = [&](int cc) __attribute__((always_inline)) {
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+        const unsigned a_sc = gn_base + ((cc << 6) + ((tid_o & 7) << 3)) * 4;
+        gs0 = *(lds_f4_ptr)a_sc;
+        gs1 = *(lds_f4_ptr)(a_sc + 16);
+        gh0 = *(lds_f4_ptr)(a_sc + GN_MAXC * 4);
+        gh1 = *(lds_f4_ptr)(a_sc + GN_MAXC * 4 + 16);
+    };
+    // the column of the thread's first halo row stays in a register: the column of row r0 + 64 k needs no division that way
+    const unsigned tp_c0 = (unsigned)((tid >> 3) % HW_);
+    auto tp_load = [&](TPart& t, int buf, int k) __attribute__((always_inline)) {
         int tid_o = tid;
         asm volatile("" : "+v"(tid_o));  // opaque: recompute the address values here instead of carrying them through the loop
-        const int item = tid_o + 512 * k;
-        const bool inr = item < HROWS * 8;
-        const int r = inr ? item >> 3 : 0;
-        const int ls = ((item & 7) ^ halo_key<UPS>(r % HW_)) << 3;
+        const bool inr = k < (HROWS * 8) / 512 ? true : tid_o + 512 * k < HROWS * 8;  // (only the last, partial part can leave the halo)
+        const unsigned tp_a0 = a_base + (unsigned)(tid_o >> 3) * 128u;
+        unsigned col = tp_c0 + (unsigned)((64 * k) % HW_);
+        col = min(col, col - (unsigned)HW_);                                         // mod HW_ (the wrapped difference is huge when col < HW_)
+        const unsigned ps = (unsigned)(tid_o & 7) ^ (unsigned)halo_key<UPS>((int)col);
         t.ok = (t_ok >> k) & 1u;
-        t.addr = inr ? a_base + buf * A_BUF + item * 16 : dump_base + (tid_o & 63) * 16;
-        const unsigned a_sc = gn_base + ((cc << 6) + ls) * 4;
+        t.addr = inr ? tp_a0 + (unsigned)(buf * A_BUF + k * 8192) + (ps << 4) : dump_base + (unsigned)(tid_o & 63) * 16u;
         t.raw = *(lds_u4_ptr)t.addr;
-        t.s0 = *(lds_f4_ptr)a_sc;
-        t.s1 = *(lds_f4_ptr)(a_sc + 16);
-        t.h0 = *(lds_f4_ptr)(a_sc + GN_MAXC * 4);
-        t.h1 = *(lds_f4_ptr)(a_sc + GN_MAXC * 4 + 16);
     };
     // arithmetic in two halves so that it can sit under BOTH MFMA batches of the step (one VALU pipe per SIMD, two waves on it: with
     // all of it under the second batch that batch was VALU-bound while the first one had idle VALU slots)
     auto tp_mid = [&](TPart& t) __attribute__((always_inline)) {
-        t.v[0] = h16_lo(t.raw.x) * t.s0.x + t.h0.x; t.v[1] = h16_hi(t.raw.x) * t.s0.y + t.h0.y;
-        t.v[2] = h16_lo(t.raw.y) * t.s0.z + t.h0.z; t.v[3] = h16_hi(t.raw.y) * t.s0.w + t.h0.w;
-        t.v[4] = h16_lo(t.raw.z) * t.s1.x + t.h1.x; t.v[5] = h16_hi(t.raw.z) * t.s1.y + t.h1.y;
-        t.v[6] = h16_lo(t.raw.w) * t.s1.z + t.h1.z; t.v[7] = h16_hi(t.raw.w) * t.s1.w + t.h1.w;
+        t.v[0] = h16_lo(t.raw.x) * gs0.x + gh0.x; t.v[1] = h16_hi(t.raw.x) * gs0.y + gh0.y;
+        t.v[2] = h16_lo(t.raw.y) * gs0.z + gh0.z; t.v[3] = h16_hi(t.raw.y) * gs0.w + gh0.w;
+        t.v[4] = h16_lo(t.raw.z) * gs1.x + gh1.x; t.v[5] = h16_hi(t.raw.z) * gs1.y + gh1.y;
+        t.v[6] = h16_lo(t.raw.w) * gs1.z + gh1.z; t.v[7] = h16_hi(t.raw.w) * gs1.w + gh1.w;
         if (FUSED == 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) t.v[e] = silu_f(t.v[e]);
@@ -707,10 +717,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     halo_wait_vm<B_IT>();
     __builtin_amdgcn_s_barrier();
     if (fused) {  // chunk 0 of the first tile has nothing to hide under
+        tbl_load(0);
 #pragma unroll
         for (int k = 0; k < T_IT; ++k) {
             TPart t;
-            tp_load(t, 0, 0, k);
+            tp_load(t, 0, k);
             tp_mid(t);
             tp_finish(t);
         }
@@ -749,8 +760,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         if constexpr (TAP < 8) {
             TPart tp[NP > 0 ? NP : 1];
             if constexpr (NP > 0) {
+                if constexpr (TAP == 3) tbl_load(fcc);
 #pragma unroll
-                for (int u = 0; u < NP; ++u) tp_load(tp[u], PAR ^ 1, fcc, P0 + u);
+                for (int u = 0; u < NP; ++u) tp_load(tp[u], PAR ^ 1, P0 + u);
             }
             load_half(nxt1, IC<TAP1>{}, IC<PAR1>{}, IC<1>{});
             if constexpr (NP > 0) {
@@ -760,13 +772,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
             mfma16(f0);
             if constexpr (NP == 0) {
                 interleave();
-            } else {  // 16 MFMAs; 8 + 5 NP LDS reads under the first ones, then ~38 NP VALU + 8 NP transcendentals under the rest
-                constexpr int NR = NP == 1 ? 7 : 6;  // MFMAs that carry the reads
+            } else {  // 16 MFMAs; 8 fragment reads + the item (+ the 4 table reads of the chunk in tap 3) under the first five, then ~28 VALU + 8 transcendentals
 #pragma unroll
-                for (int q = 0; q < 6; ++q) { sgb<0x008, 1>(); sgb<0x100, NP == 1 ? 2 : 3>(); }
-                if constexpr (NP == 1) { sgb<0x008, 1>(); sgb<0x100, 1>(); }
+                for (int q = 0; q < 4; ++q) { sgb<0x008, 1>(); sgb<0x100, 2>(); }
+                sgb<0x008, 1>(); sgb<0x100, TAP == 3 ? 5 : 1>();
 #pragma unroll
-                for (int q = NR; q < 16; ++q) { sgb<0x008, 1>(); sgb<0x002, 4 * NP>(); sgb<0x400, NP>(); }
+                for (int q = 5; q < 16; ++q) { sgb<0x008, 1>(); sgb<0x002, 3>(); sgb<0x400, 1>(); }
             }
             __builtin_amdgcn_sched_barrier(0);
             load_half(f0, IC<TAP1>{}, IC<PAR1>{}, IC<0>{});
@@ -786,7 +797,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
                 __builtin_amdgcn_sched_barrier(0);
                 if (wave < T_TAIL_WAVES) {
                     TPart t;
-                    tp_load(t, PAR ^ 1, fcc, T_FULL);
+                    tp_load(t, PAR ^ 1, T_FULL);
                     tp_mid(t);
                     tp_finish(t);
                 }

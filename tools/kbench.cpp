@@ -5,6 +5,7 @@
 //   kbench [iters=N] [cold=0|1] [check=0|1] spec...
 //     gemm:M,N,K[,act[,res[,stats(unused)[,hint...]]]]   act: 0 none 3 geglu; res: 0/1; hints: tile_hint list (default 0)
 //     conv:B,H,W,Cin,Cout[,ups[,hint...]]                 3x3 stride 1 pad 1
+//     convg:B,H,W,Cin,Cout[,silu[,ups]]                   conv3x3 of the GroupNorm(+SiLU)-normalised input, apply fused into the conv
 //     attn:B,T,heads                                      flash_attn64
 //     qkv:M,C[,hint]                                      fused q|k|v^T projection (gp_gemm_qkv), when the library exports it
 //   cold=1: the weight operand rotates through a 1 GiB arena (every launch streams its weights from HBM like the pipeline does),
@@ -248,6 +249,56 @@ static void bench_conv(const std::vector<long long>& a) {
     CK(hipFree(X)); CK(hipFree(O)); CK(hipFree(bias));
 }
 
+__global__ void checksum_kernel(const h16* p, size_t n, float* out) {  // per-block weighted sums (order-independent enough to compare two builds bit for bit)
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += bf2f(p[i]) * (float)(1 + (i % 7));
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+static double checksum(const h16* p, size_t n) {
+    float* d;
+    CK(hipMalloc(&d, 1024 * 4));
+    hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(256), 0, 0, p, n, d);
+    std::vector<float> h(1024);
+    CK(hipMemcpy(h.data(), d, 1024 * 4, hipMemcpyDeviceToHost));
+    CK(hipFree(d));
+    double t = 0;
+    for (float v : h) t += v;
+    return t;
+}
+static void bench_convg(const std::vector<long long>& a) {  // convg:B,H,W,Cin,Cout[,silu[,ups]]  conv3x3(act(GroupNorm(in))) with the apply fused (gp_conv2d_gn: stats pass + conv)
+    const int B = (int)a[0], H = (int)a[1], W = (int)a[2], Cin = (int)a[3], Cout = (int)a[4];
+    const int silu = a.size() > 5 ? (int)a[5] : 1, ups = a.size() > 6 ? (int)a[6] : 0;
+    const int Ho = ups ? 2 * H : H, Wo = ups ? 2 * W : W;
+    const int nrows = gp_packed_rows(Cout);
+    h16 *X, *O;
+    float *bias, *gamma, *beta;
+    CK(hipMalloc(&X, (size_t)B * H * W * Cin * 2));
+    CK(hipMalloc(&O, (size_t)B * Ho * Wo * Cout * 2));
+    CK(hipMalloc(&bias, (size_t)nrows * 4));
+    CK(hipMalloc(&gamma, (size_t)Cin * 4));
+    CK(hipMalloc(&beta, (size_t)Cin * 4));
+    fill(X, (size_t)B * H * W * Cin, 21);
+    fillf(bias, nrows, 7, 0.5f);
+    fillf(gamma, Cin, 9, 1.0f);
+    fillf(beta, Cin, 11, 0.3f);
+    const double flops = 2.0 * B * Ho * Wo * (double)Cout * Cin * 9;
+    auto go = [&](const h16* w) {
+        gp_status st = gp_conv2d_gn(X, w, bias, nullptr, O, B, H, W, Cin, Cout, ups, 0, gamma, beta, 32, 1e-6f, silu, nullptr);
+        if (st != GP_OK) { fprintf(stderr, "gp_conv2d_gn failed (%d)\n", (int)st); exit(3); }
+    };
+    const float hot = time_us([&](int) { go(g_arena); }, g_iters);
+    go(g_arena);
+    CK(hipDeviceSynchronize());
+    printf("convg B=%d %dx%d Cin=%-5d Cout=%-5d silu=%d ups=%d  %8.2f us %7.1f TF/s (statistics pass + fused conv)  checksum %.9e\n", B, H, W, Cin, Cout, silu, ups, hot,
+           flops / hot * 1e-6, checksum(O, (size_t)B * Ho * Wo * Cout));
+    fflush(stdout);
+    CK(hipFree(X)); CK(hipFree(O)); CK(hipFree(bias)); CK(hipFree(gamma)); CK(hipFree(beta));
+}
+
 static void bench_convs(const std::vector<long long>& a) {  // convs:B,H,W,Cin,Cout  conv3x3 whose epilogue leaves GroupNorm statistics (+ finalize launch)
     const int B = (int)a[0], H = (int)a[1], W = (int)a[2], Cin = (int)a[3], Cout = (int)a[4];
     const int nrows = gp_packed_rows(Cout);
@@ -405,6 +456,7 @@ int main(int argc, char** argv) {
         else if (!strncmp(s, "conv:", 5)) bench_conv(parse_nums(s + 5));
         else if (!strncmp(s, "attn:", 5)) bench_attn(parse_nums(s + 5));
         else if (!strncmp(s, "convs:", 6)) bench_convs(parse_nums(s + 6));
+        else if (!strncmp(s, "convg:", 6)) bench_convg(parse_nums(s + 6));
         else if (!strncmp(s, "gn:", 3)) bench_gn(parse_nums(s + 3));
         else if (!strncmp(s, "xfold:", 6)) bench_xfold(parse_nums(s + 6));
 #ifdef KBENCH_HAVE_QKV
