@@ -19,6 +19,9 @@
 // the conv kernels' slot ^ (row & 7) is not for this pattern (checked exhaustively), so the attention tiles keep their own swizzle.
 GP_DEV int attn_off128(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
+#ifndef GP_FLASH_DEFER
+#define GP_FLASH_DEFER 0.f  // rescale threshold in log2 units, see tile(): 0 = the reference is the exact running maximum
+#endif
 // NKB: 32-key blocks per KV tile (2: 64 keys, 4: 128 keys -- one online-softmax update, one barrier and one DMA wait per 128 keys,
 // longer independent MFMA runs)
 // NST: depth of the K / V ring in LDS (16 KiB per stage at NKB = 2).  2 = one tile ahead, a full vmcnt(0) + barrier per tile; 3 = two tiles
@@ -135,25 +138,39 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kb][r]);
         mx = xor32_max(mx);                                // the other half-wave holds this query's other 32 keys (v_permlane32_swap, no LDS trip)
-        const float m_new = fmaxf(m_run, mx);              // raw-score units
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
-        const float nm = -m_new * sc;
-        m_run = m_new;
-        float rs = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s_acc[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][r], sc, nm));
-                rs += s_acc[kb][r];
-            }
-        l_run = l_run * alpha + rs;
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {  // (uniform) some query's maximum moved: rescale the accumulators
+        // The reference m_run of the exponentials moves (and accumulators and row sum are rescaled) only in tiles where some query of the wave
+        // sets a new maximum.  A threshold GP_FLASH_DEFER > 0 would defer that until a maximum outgrows its reference by 2^threshold (exact
+        // in fp32, -2.4 % kernel time at 8) -- measured and NOT used: with the exact maximum as reference the dominant probabilities lie just
+        // below 1.0, where the 16-bit rounding of the P operand is finest; against a stale reference their mantissas are arbitrary and the
+        // error of the output grows by 20 % (bf16: 1.7e-3 -> 2.1e-3 of the mean magnitude).
+        if (__builtin_amdgcn_ballot_w64((mx - m_run) * sc > GP_FLASH_DEFER) != 0ull) {  // (uniform)
+            const float m_new = fmaxf(m_run, mx);          // raw-score units
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+            m_run = m_new;
+            l_run *= alpha;
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
         }
+        // (two scores per instruction where the ISA has a packed form: v_pk_fma_f32 for the scale / reference, v_pk_add_f32 for the row sum;
+        // this loop is the kernel's bound -- 33 quarter-rate v_exp_f32 and ~100 other VALU per 16 MFMAs)
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t sc2 = {sc, sc}, nm2 = {-m_run * sc, -m_run * sc};
+        f32x2_t rs2 = {0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2_t t = {s_acc[kb][r], s_acc[kb][r + 1]};
+                t = __builtin_elementwise_fma(t, sc2, nm2);
+                t.x = __builtin_amdgcn_exp2f(t.x);
+                t.y = __builtin_amdgcn_exp2f(t.y);
+                s_acc[kb][r] = t.x;
+                s_acc[kb][r + 1] = t.y;
+                rs2 += t;
+            }
+        l_run += rs2.x + rs2.y;
         // ---- O^T += V^T P^T: k-steps (kb, j) of 16 keys; this lane's P for its own query is the B operand
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
@@ -163,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
 #pragma unroll
                 for (int e = 0; e < 4; ++e) pf.u[e] = pack_h16x2_ns(s_acc[kb][8 * j + 2 * e], s_acc[kb][8 * j + 2 * e + 1]);  // probabilities: in [0, 1]
                 const int slot = (kb & 1) * 4 + 2 * j + hh;  // keys 8 slot .. 8 slot + 7 of the 64-key half
+                // (requesting all eight V^T fragments ahead of the softmax -- 136 registers, three waves per SIMD instead of four -- measured equal)
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
                     const h16x8_t vf = lds_frag(sb + KBYTES + (kb >> 1) * 8192 + attn_off128(d * 32 + l31, slot), 0);
@@ -176,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
     for (int s0 = 0; s0 < NST - 1; ++s0)
         if (s0 < nt) stage(s0, s0);
     int nxt = NST - 1;
-    for (int kt = 0; kt < nt; ++kt) {
+    auto step = [&](int kt, auto maskc) __attribute__((always_inline)) {
         // my DMAs of tile kt have landed (NST - 2 younger stages may stay in flight) ...
         const int ahead = min(NST - 2, nt - 1 - kt);
         if (ahead >= 1) wait_vm<LPS>(); else wait_vm<0>();
@@ -184,10 +202,16 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
         // ... and after the barrier everybody's have, and everybody is done reading the slot of tile kt - 1, which tile kt + NST - 1 refills
         __builtin_amdgcn_s_barrier();
         if (kt + NST - 1 < nt) stage(nxt, kt + NST - 1);
-        if (kt * KEYS + KEYS > T) tile(kt, IC<1>{}); else tile(kt, IC<0>{});
+        tile(kt, maskc);
         cur = cur + 1 == NST ? 0 : cur + 1;
         nxt = nxt + 1 == NST ? 0 : nxt + 1;
-    }
+    };
+    // Only the last tile can reach past key T - 1.  It runs after the loop: with both tile variants inside the loop body the accumulators
+    // lived in different registers on the two paths and every iteration paid 16 v_mov_b64 of copies at the merge.
+    const bool ragged = nt * KEYS > T;
+    const int nfull = ragged ? nt - 1 : nt;
+    for (int kt = 0; kt < nfull; ++kt) step(kt, IC<0>{});
+    if (ragged) step(nt - 1, IC<1>{});
     // ---- normalise and store O[q][d] (this lane: q = l31, d = 32*blk + 8*(r>>2) + 4*hh + (r&3))
     l_run += __shfl_xor(l_run, 32);
     const float inv = 1.f / l_run;
@@ -207,7 +231,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const h16_t* __res
 void launch_flash_attn64(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t* out, int B, int T, int heads,
                          int ldq, int ldk, int Tpad, int ldo, hipStream_t s) {
     dim3 grid(((T + 127) / 128) * heads * B);
-    // 64-key tiles: 183 VGPRs as hipcc 7.2 allocates them (194 with the FLAT LDS-DMA and its 64-bit addresses), i.e. two waves per SIMD (forcing three, __launch_bounds__(256, 3), spills 38 registers).
+    // r3: 113 VGPRs, four waves per SIMD (LDS: 32 KiB per workgroup), 506 us at T = 9216 / batch 4 / 5 heads (860 TFLOP/s; r2: 183 VGPRs, two waves,
+    // 580 us) -- the whole difference is the masked tile variant moved out of the loop (see the loop).  PMC of the r3 kernel: matrix pipe busy 40 % of
+    // the cycles, VALU-active 61 %: the two do not overlap to speak of, the SIMD is busy issuing ~147 VALU (33 of them quarter-rate v_exp_f32) per 16 MFMAs;
+    // packed fma / add forms (kept) and a deferred rescale (not kept, see tile()) did not change the time.
+    // r2 notes (183-register kernel): forcing three waves, __launch_bounds__(256, 3), spilled 38 registers.
     // Measured alternatives, all slower at T = 9216 (610 us, kernel only): 128-key tiles -8 % (r1); a three-stage K / V ring with counted waits
     // -2 % (stays as a switch, GENPERCEPT_FLASH_RING3: K / V latency is not what the kernel waits for); two 32-query blocks per wave so that each
     // K / V^T fragment read feeds two MFMAs: 1100 us with 256 VGPRs + 42 spilled, 1050 us at one wave per SIMD; one online-softmax update per
@@ -387,7 +415,7 @@ __global__ __launch_bounds__(256) void flash_attn512_kernel(const h16_t* __restr
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_acc[r]);
             mx = fmaxf(mx, other_half(mx));
-            const bool moved = __builtin_amdgcn_ballot_w64((mx - m_run) * sc > 8.f) != 0ull;  // uniform
+            const bool moved = __builtin_amdgcn_ballot_w64((mx - m_run) * sc > GP_FLASH_DEFER) != 0ull;  // uniform
             if (moved) {
                 const float m_new = fmaxf(m_run, mx);
                 alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
