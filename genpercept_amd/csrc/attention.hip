@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void flash_attn512_kernel(const h16_t* __restr
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_acc[r]);
             mx = fmaxf(mx, other_half(mx));
-            const bool moved = __builtin_amdgcn_ballot_w64((mx - m_run) * sc > GP_FLASH_DEFER) != 0ull;  // uniform
+            const bool moved = __builtin_amdgcn_ballot_w64((mx - m_run) * sc > 8.f) != 0ull;  // uniform
             if (moved) {
                 const float m_new = fmaxf(m_run, mx);
                 alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
