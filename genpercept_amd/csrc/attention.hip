@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void flash_attn512_kernel(const h16_t* __restr
         // ---- S^T = K Q^T over d = 512: 32 k-steps alternating between two accumulators (a single chain would wait for its own result)
         auto s_phase = [&](unsigned sb, int kt, bool do_stage, int slot_next, auto maskc) __attribute__((always_inline)) -> bool {
             constexpr bool MASK = decltype(maskc)::value != 0;
-            f32x16_t s0 = zero16, s1 = zero16;
+            f32x16_t s0, s1;  // (first MFMA of each chain takes the inline constant 0 as C: no 32 register writes per tile)
             h16x8_t fr[F5_RD], ql[2];
             auto rd = [&](int ks) __attribute__((always_inline)) {
                 fr[ks % F5_RD] = lds_frag(sb + (ka0 ^ ((ks & 7) << 5)), (ks >> 3) * 256);
@@ -396,8 +396,8 @@ __global__ __launch_bounds__(256) void flash_attn512_kernel(const h16_t* __restr
 #pragma unroll
             for (int ks = 0; ks < 32; ++ks) {
                 const h16x8_t qv = (ks & 3) != 3 ? qf[3 * (ks >> 2) + ((ks & 3) != 3 ? (ks & 3) : 0)] : ql[(ks >> 2) & 1];
-                if (ks & 1) s1 = mfma_32x32x16(fr[ks % F5_RD], qv, s1);
-                else s0 = mfma_32x32x16(fr[ks % F5_RD], qv, s0);
+                if (ks & 1) s1 = mfma_32x32x16(fr[ks % F5_RD], qv, ks == 1 ? zero16 : s1);
+                else s0 = mfma_32x32x16(fr[ks % F5_RD], qv, ks == 0 ? zero16 : s0);
                 if (ks + F5_RD < 32) rd(ks + F5_RD);
                 if (do_stage && (ks & 1)) stage_piece(slot_next, kt + 1, ks >> 1);   // the next tile's 16 DMA pieces, one per two MFMAs
             }
