@@ -58,16 +58,11 @@ void launch_concat(const h16_t* a, int Ca, const h16_t* b, int Cb, h16_t* out, l
 // squares} in the layout of the conv epilogues (mode 0 of gn_finalize_tiles_kernel), so the resnet that consumes the concatenation
 // skips its statistics read pass.  A thread owns one 8-channel slot for the bm pixels of its tile: no cross-thread reduction.
 __global__ __launch_bounds__(256) void concat_stats_kernel(const h16_t* __restrict__ a, int Ca, const h16_t* __restrict__ b, int Cb,
-                                                            h16_t* __restrict__ out, int bm, long long ntiles, float* __restrict__ part) {
+                                                            h16_t* __restrict__ out, int bm, float* __restrict__ part) {
     const int va = Ca >> 3, vt = (Ca + Cb) >> 3, C = Ca + Cb;
-    // up to 128 slots per pixel row (C <= 1024): a workgroup takes 256 / vt pixel tiles side by side instead of leaving 256 - vt threads idle
-    // (C = 640: 80 of 256 lanes worked, 33 us for 94 MB); wider rows: one tile per workgroup, slots over blockIdx.y
-    const int tpb = vt <= 128 ? 256 / vt : 1;
-    const int sub = tpb > 1 ? (int)threadIdx.x / vt : 0;
-    const int v = tpb > 1 ? (int)threadIdx.x - sub * vt : (int)(blockIdx.y * 256 + threadIdx.x);
-    const long long tile = (long long)blockIdx.x * tpb + sub;
-    if (v >= vt || sub >= tpb || tile >= ntiles) return;
-    const long long p0 = tile * bm;
+    const int v = blockIdx.y * 256 + threadIdx.x;
+    if (v >= vt) return;
+    const long long p0 = (long long)blockIdx.x * bm;
     const bool from_a = v < va;
     const h16_t* src = from_a ? a + p0 * Ca + v * 8 : b + p0 * Cb + (v - va) * 8;
     const int ld = from_a ? Ca : Cb;
@@ -75,7 +70,7 @@ __global__ __launch_bounds__(256) void concat_stats_kernel(const h16_t* __restri
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-#pragma unroll 8
+#pragma unroll 4
     for (int r = 0; r < bm; ++r) {
         const uint4 x = *(const uint4*)(src + (long long)r * ld);
         *(uint4*)(dst + (long long)r * C) = x;
@@ -83,7 +78,7 @@ __global__ __launch_bounds__(256) void concat_stats_kernel(const h16_t* __restri
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
     }
-    float* po = part + (tile * C + v * 8) * 2;
+    float* po = part + ((long long)blockIdx.x * C + v * 8) * 2;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { po[2 * e] = s[e]; po[2 * e + 1] = q[e]; }
 }
@@ -93,10 +88,7 @@ int concat_stats_bm(long long hw) {
     return 0;
 }
 void launch_concat_stats(const h16_t* a, int Ca, const h16_t* b, int Cb, h16_t* out, long long pixels, int bm, float* part, hipStream_t s) {
-    const int vt = (Ca + Cb) / 8, tpb = vt <= 128 ? 256 / vt : 1;
-    const long long ntiles = pixels / bm;
-    hipLaunchKernelGGL(concat_stats_kernel, dim3((unsigned)((ntiles + tpb - 1) / tpb), tpb > 1 ? 1 : (vt + 255) / 256), dim3(256), 0, s, a, Ca, b, Cb, out, bm,
-                       ntiles, part);
+    hipLaunchKernelGGL(concat_stats_kernel, dim3((unsigned)(pixels / bm), ((Ca + Cb) / 8 + 255) / 256), dim3(256), 0, s, a, Ca, b, Cb, out, bm, part);
 }
 
 // fp32 NCHW -> bf16 NHWC with zero-padded channels (stage-level entry points: latents / features handed in by the host)
