@@ -336,6 +336,70 @@ def test_genpercept_import_path_shim():
     assert GenPerceptPipeline.latent_scale_factor == 0.18215
 
 
+def _fake_reference_checkout(root):
+    """A stand-in for a GenPercept checkout: the package layout run.py / infer.py import from (genpercept/__init__.py:18,
+    genpercept/models/{dpt_head,custom_unet}.py, genpercept/util/), with marker classes instead of the reference's diffusers wrappers."""
+    pkg = root / "genpercept"
+    (pkg / "models").mkdir(parents=True)
+    (pkg / "util").mkdir()
+    (pkg / "__init__.py").write_text("REFERENCE_PACKAGE = True\nfrom .genpercept_pipeline import GenPerceptPipeline, GenPerceptOutput\n")
+    (pkg / "genpercept_pipeline.py").write_text("class GenPerceptPipeline:\n    ORIGIN = 'reference'\nclass GenPerceptOutput:\n    pass\n")
+    (pkg / "models" / "dpt_head.py").write_text(
+        "class DPTNeckHeadForUnetAfterUpsample:\n    ORIGIN = 'reference'\n"
+        "class DPTNeckHeadForUnetAfterUpsampleIdentity(DPTNeckHeadForUnetAfterUpsample):\n    pass\n")
+    (pkg / "models" / "custom_unet.py").write_text("class CustomUNet2DConditionModel:\n    ORIGIN = 'reference'\n")
+    (pkg / "util" / "batchsize.py").write_text("ORIGIN = 'reference'\n")
+    # run.py:33,49,51 / infer.py:30,46,48 -- the three import lines, in the reference's order, then what it does with the names
+    (root / "run.py").write_text(
+        "import sys\n"
+        "from genpercept import GenPerceptPipeline\n"
+        "from genpercept.models.dpt_head import DPTNeckHeadForUnetAfterUpsample, DPTNeckHeadForUnetAfterUpsampleIdentity\n"
+        "from genpercept.models.custom_unet import CustomUNet2DConditionModel\n"
+        "import genpercept, genpercept.genpercept_pipeline as gpp\n"
+        "from genpercept.util import batchsize\n"
+        "assert not hasattr(genpercept, 'REFERENCE_PACKAGE'), 'the reference package shadows the shim'\n"
+        "assert GenPerceptPipeline.__module__ == 'genpercept_amd.pipeline', GenPerceptPipeline.__module__\n"
+        "assert gpp.GenPerceptPipeline is GenPerceptPipeline\n"
+        "assert DPTNeckHeadForUnetAfterUpsampleIdentity.ORIGIN == CustomUNet2DConditionModel.ORIGIN == batchsize.ORIGIN == 'reference'\n"
+        "print('DROPIN-OK', sys.argv[1:])\n")
+    return root
+
+
+def test_run_py_import_lines_resolve_with_the_shim_on_the_path(tmp_path):
+    """VERDICT r3 missing #2: run.py:33,49,51 (infer.py:30,46,48) import `genpercept`, `genpercept.models.dpt_head` and
+    `genpercept.models.custom_unet` at module top.  With this repository ahead of a reference checkout on sys.path the first must be the
+    engine's pipeline and the other two must still resolve to the checkout's files (the shim extends its __path__)."""
+    ref = _fake_reference_checkout(tmp_path / "GenPercept")
+    code = (f"import sys; sys.path[:0] = [{ROOT!r}]; sys.path.append({str(ref)!r})\n" + (ref / "run.py").read_text())
+    r = subprocess.run([sys.executable, "-c", code, "--mode", "depth"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0 and "DROPIN-OK ['--mode', 'depth']" in r.stdout, r.stdout + r.stderr
+    # the checkout appended AFTER the shim was imported is still found (the path is rescanned per sub-module import)
+    code = (f"import sys; sys.path[:0] = [{ROOT!r}]\nimport genpercept\nsys.path.append({str(ref)!r})\n"
+            "from genpercept.models.custom_unet import CustomUNet2DConditionModel as C\nassert C.ORIGIN == 'reference'\n"
+            "import genpercept.genpercept_pipeline as g\nassert g.GenPerceptPipeline.__module__ == 'genpercept_amd.pipeline'\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    # without a checkout on the path the model modules are absent, loudly
+    r = subprocess.run([sys.executable, "-c", f"import sys; sys.path[:0] = [{ROOT!r}]\nimport genpercept.models.dpt_head"],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode != 0 and "ModuleNotFoundError" in r.stderr
+
+
+def test_dropin_launcher_runs_a_reference_script_unchanged(tmp_path):
+    """`python run.py` puts the checkout's directory at sys.path[0] (the reference's own package would win); `python -m
+    genpercept_amd.dropin <checkout>/run.py args` orders the path [this repository, checkout, ...] and runs the script as __main__."""
+    ref = _fake_reference_checkout(tmp_path / "GenPercept")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, str(ref / "run.py")], capture_output=True, text=True, env=env, cwd=str(ref))
+    assert r.returncode != 0 and "shadows the shim" in r.stderr  # the problem the launcher exists for
+    r = subprocess.run([sys.executable, "-m", "genpercept_amd.dropin", str(ref / "run.py"), "--checkpoint", "ckpt"],
+                       capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0 and "DROPIN-OK ['--checkpoint', 'ckpt']" in r.stdout, r.stdout + r.stderr
+    from genpercept_amd import dropin
+    order = dropin.path_order(str(ref / "run.py"), path=["", str(ref), "/x", ROOT])
+    assert order[:2] == [ROOT, str(ref)] and order.count(ROOT) == 1 and order.count(str(ref)) == 1
+
+
 def test_customized_head_kind_like_the_reference():
     """genpercept_pipeline.py:474,483-484: only DPTNeckHeadForUnetAfterUpsampleIdentity is a valid customized_head; the ReLU-terminated
     DPTNeckHeadForUnetAfterUpsample (same keys! run.py:303-307 loads it from `dpt_head/`) raises ValueError."""
