@@ -71,16 +71,20 @@ def source_build_id() -> str:
 
 
 def parity_vs(ref, out) -> dict:
-    """HIP map vs the fp32 oracle map (both [C,H,W] on the host, values in [0,1]): mean / max |delta| and AbsRel after the reference's
-    least-squares alignment (eval.py protocol: src/util/alignment.py:29-76, metric.py:34-44), channel 0."""
+    """HIP map vs the fp32 oracle map (both [C,H,W] on the host, values in [0,1]) under BOTH readings of north_star's "within 1e-3 rel":
+    mean_abs = mean |delta| on the [0,1] map (max_abs beside it) and rel_rms = rms(out - ref) / rms(ref - mean(ref)), the deviation relative
+    to the map's own signal; plus AbsRel after the reference's least-squares alignment (eval.py protocol: src/util/alignment.py:29-76,
+    metric.py:34-44), channel 0."""
     import numpy as np
     from genpercept_amd.eval_metrics import abs_relative_difference, align_depth_least_square
     r, o = ref.double().numpy(), out.double().numpy()
     d = np.abs(o - r)
     gt = r[0].clip(1e-3, None)
     aligned, _, _ = align_depth_least_square(gt, o[0], np.ones_like(gt, dtype=bool))
-    return {"mean_abs": float(d.mean()), "max_abs": float(d.max()),
-            "absrel_ls": float(abs_relative_difference(np.clip(aligned, 1e-3, None), gt)), "ref": "fp32 oracle (oracle/), image 0 of the benched batch"}
+    rel_rms = float(np.sqrt(((o - r) ** 2).mean()) / (np.sqrt(((r - r.mean()) ** 2).mean()) + 1e-30))
+    return {"mean_abs": float(d.mean()), "max_abs": float(d.max()), "rel_rms": rel_rms,
+            "absrel_ls": float(abs_relative_difference(np.clip(aligned, 1e-3, None), gt)), "ref": "fp32 oracle (oracle/), image 0 of the benched batch",
+            "within_1e-3": {"mean_abs": bool(d.mean() <= 1e-3), "rel_rms": bool(rel_rms <= 1e-3)}}
 
 
 def respawn_under_torchrun(n: int):
@@ -290,14 +294,17 @@ def main():
             ref = opipe.single_infer(vsd, osd.VAECfg(), usd, osd.UNetCfg(), x, ctx, args.mode)
             dt = time.perf_counter() - t0
         if same and out0 is not None:  # the map just timed on the GPU against the map just timed on the CPU: same image, same weights
-            parity = {args.precision: parity_vs(ref[0], out0), "tolerance": "north_star: within 1e-3 (mean |delta| on [0,1] maps)"}
-            parity[args.precision]["within_1e-3"] = parity[args.precision]["mean_abs"] <= 1e-3
+            parity = {args.precision: parity_vs(ref[0], out0),
+                      "tolerance": "north_star: 'within 1e-3 rel of the reference', reported under two metrics per library: mean_abs = mean |HIP - oracle| "
+                                   "on the [0,1] map; rel_rms = rms(HIP - oracle) / rms(oracle - mean(oracle)).  within_1e-3.{mean_abs,rel_rms} per library."}
             if out0_f16 is not None:
                 parity["fp16"] = parity_vs(ref[0], out0_f16)
-                parity["fp16"]["within_1e-3"] = parity["fp16"]["mean_abs"] <= 1e-3
-            if not parity[args.precision]["within_1e-3"]:
-                parity["note"] = (f"the {args.precision} value is OUTSIDE north_star's tolerance (bf16 MFMA operands floor at ~2.3e-3, "
-                                  "DESIGN.md section 4); value_fp16 is the number of the build that meets it")
+            w = parity[args.precision]["within_1e-3"]
+            if not (w["mean_abs"] and w["rel_rms"]):
+                parity["note"] = (f"the benched {args.precision} value is outside 1e-3 under " + " and ".join(k for k, v in w.items() if not v) +
+                                  " (bf16 MFMA operands floor the map at ~2.3e-3 mean_abs; DESIGN.md section 4); value_fp16 is the number of the fp16 "
+                                  "library, which is inside 1e-3 under mean_abs; no engine with 16-bit MFMA operands reaches 1e-3 under rel_rms "
+                                  "(profiles/r04_precision_ablation.json: operands-only-fp16)")
         cpu = {"value": round(1.0 / dt, 5), "unit": f"images/sec at {r}x{r} fp32", "cores": nthr, "cpu_model": cpu_model(), "kind": "port",
                "sample": f"1 image {r}x{r} ({TFLOP_PER_IMAGE_768 * (r / 768.0) ** 2:.3f} TFLOP), torch-CPU fp32 restatement of the diffusers path "
                          f"(oracle/), timed directly at this size: {dt:.1f} s",
@@ -318,7 +325,11 @@ def main():
                                           (", result maps gathered to rank 0 over RCCL inside the step)" if do_gather else ")"),
                            "gather_ms": gather_ms,
                            "weights": "random-init SD2.1 architecture (865.9M + 83.7M params)", "load_s": round(t_load, 1)},
-                "roofline": roofline, "cpu_baseline": cpu, "stages": stages, "parity": parity}
+                "roofline": roofline, "cpu_baseline": cpu, "stages": stages, "parity": parity,
+                # does `value` (the benched dtype) meet north_star's 1e-3 tolerance?  per metric; null when the oracle leg did not run
+                "value_within_tolerance": parity[args.precision]["within_1e-3"] if parity else None}
+        if parity and "fp16" in parity:
+            line["value_fp16_within_tolerance"] = parity["fp16"]["within_1e-3"]
         if fp16:
             line.update(fp16)
         print(json.dumps(line), flush=True)

@@ -3,9 +3,14 @@
 (normal), configs[3] (DPT disparity head) at 768x768 with both element-type libraries, configs[0]'s 384x384 image through the pipeline
 surface, and configs[4]'s rank-local shard (8 images per GPU).
 
-Tolerance (north_star: "within 1e-3"): mean |delta| <= 1e-3 on the [0,1] maps for the fp16 library (the reference's own half precision,
-run.py:273-281).  The bf16 library (BASELINE.json's dtype) is measured against the same maps and gated at its simulated operand-rounding
-floor (profiles/r02_precision_ablation.json: 3.2e-3 depth / 5.1e-3 normal) -- outside the contract, reported as such by bench.py.
+Tolerance (north_star: "within 1e-3 rel of the reference"), measured under BOTH readings for both libraries:
+  mean_abs = mean |HIP - oracle| on the [0,1] map   -- the contract metric: the fp16 library (the reference's own half precision,
+             run.py:273-281) is gated AT 1e-3; the bf16 library (BASELINE.json's dtype) at 1.5x its simulated operand-rounding floor
+             (profiles/r04_precision_ablation.json: 3.2e-3 depth / 5.1e-3 normal), a regression gate -- it is outside the contract and
+             bench.py says so in its own line.
+  rel_rms  = rms(HIP - oracle) / rms(oracle - mean(oracle)) -- the deviation relative to the map's own signal.  NO engine with 16-bit
+             MFMA operands reaches 1e-3 here (simulated floor with fp16 operands and everything else fp32: 3.4e-3 at 128 px):
+             gated as a regression gate only (RELRMS_TOL) and logged (gpurun_out/parity_log.jsonl).
 
 The oracle runs once per module (about 12 s of CPU at 768x768 on the GPU box's host cores: encoder, ONE UNet pass that returns the sample
 and the multi-level features, the 3-channel decode, the DPT head)."""
@@ -22,6 +27,13 @@ pytestmark = pytest.mark.gpu
 # (engine-bf16 row of profiles/r02_precision_ablation.json), i.e. a regression gate, not a parity claim.
 MAP_TOL = {"fp16": {"depth": 1e-3, "normal": 1e-3, "disparity": 2e-3}, "bf16": {"depth": 5e-3, "normal": 8e-3, "disparity": 1.2e-2}}
 ABSREL_TOL = {"fp16": 4e-3, "bf16": 3e-2}
+# rel-RMS of the same maps: regression gates (~1.5x the simulated engine rows of profiles/r04_precision_ablation.json), NOT the contract
+RELRMS_TOL = {"fp16": {"depth": 8e-3, "normal": 8e-3, "disparity": 8e-3}, "bf16": {"depth": 6e-2, "normal": 6e-2, "disparity": 6e-2}}
+
+
+def _rel_rms(out, ref):
+    out, ref = out.astype(np.float64), ref.astype(np.float64)
+    return float(np.sqrt(((out - ref) ** 2).mean()) / (np.sqrt(((ref - ref.mean()) ** 2).mean()) + 1e-30))
 
 
 def _bench_rgb(batch, res, seed=1234):
@@ -95,10 +107,12 @@ def test_768_depth_and_normal_vs_live_oracle(precision, full, metric_log):
             ref = full["ref"][mode]
             out = eng.infer(full["rgb8"][:1].to(d), mode)[0].cpu().numpy()
             err = np.abs(out - ref)
-            rec = dict(mean_abs=float(err.mean()), max_abs=float(err.max()), absrel_ls=_absrel_ls(out[0], ref[0]))
+            rec = dict(mean_abs=float(err.mean()), max_abs=float(err.max()), rel_rms=_rel_rms(out, ref), absrel_ls=_absrel_ls(out[0], ref[0]))
+            rec["within_1e-3_mean_abs"], rec["within_1e-3_rel_rms"] = rec["mean_abs"] <= 1e-3, rec["rel_rms"] <= 1e-3
             metric_log(f"full768_{mode}_vs_oracle[{precision}]", **rec)
             assert out.shape == ref.shape and np.isfinite(out).all()
             assert rec["mean_abs"] <= MAP_TOL[precision][mode], rec
+            assert rec["rel_rms"] <= RELRMS_TOL[precision][mode], rec
             if mode == "depth":
                 assert rec["absrel_ls"] <= ABSREL_TOL[precision], rec
         ref = full["ref"]["depth"]
@@ -127,9 +141,11 @@ def test_768_dpt_disparity_vs_live_oracle(precision, full, metric_log):
         ref = full["ref"]["disparity"]
         out = eng.infer(full["rgb8"][:1].to(d), "disparity")[0].cpu().numpy()
         err = np.abs(out - ref)
-        metric_log(f"full768_disparity_dpt_vs_oracle[{precision}]", mean_abs=float(err.mean()), max_abs=float(err.max()))
+        rr = _rel_rms(out, ref)
+        metric_log(f"full768_disparity_dpt_vs_oracle[{precision}]", mean_abs=float(err.mean()), max_abs=float(err.max()), rel_rms=rr)
         assert out.shape == ref.shape and np.isfinite(out).all() and abs(float(out.min())) < 1e-6 and abs(float(out.max()) - 1) < 1e-6
         assert float(err.mean()) <= MAP_TOL[precision]["disparity"], float(err.mean())
+        assert rr <= RELRMS_TOL[precision]["disparity"], rr
     finally:
         eng.close()
 
@@ -148,7 +164,8 @@ def test_384_image_through_the_pipeline_vs_live_oracle(full, metric_log):
                    show_progress_bar=False, mode="depth")
         ref = full["ref"]["depth384"][0]
         err = np.abs(out.pred_np - ref)
-        metric_log("full384_pipeline_depth_vs_oracle[fp16]", mean_abs=float(err.mean()), max_abs=float(err.max()), absrel_ls=_absrel_ls(out.pred_np, ref))
+        metric_log("full384_pipeline_depth_vs_oracle[fp16]", mean_abs=float(err.mean()), max_abs=float(err.max()), rel_rms=_rel_rms(out.pred_np, ref),
+                   absrel_ls=_absrel_ls(out.pred_np, ref))
         assert out.pred_np.shape == (384, 384) and out.pred_colored.size == (384, 384)
         assert float(err.mean()) <= 1e-3, float(err.mean())
     finally:
