@@ -18,6 +18,9 @@ Fixtures are data (seeds, inputs, expected outputs) — never reference source.
                      its diffusers base class is a stub (the class's own __init__ and _get_variance never call into it).
   ensemble_ref.npz   the REFERENCE's ensemble_depth (genpercept/util/ensemble.py) on seeded affine-distorted maps (inputs below
                      max_res, so torchvision -- stubbed -- is never reached).
+  refexec_tiny.npz   outputs of the REFERENCE's CustomUNet2DConditionModel.forward and GenPerceptPipeline.__call__ / single_infer /
+                     encode_rgb / decode_pred EXECUTED over stub diffusers base classes whose blocks are the oracle's functions (tiny configs,
+                     the inputs of e2e_tiny.npz / e2e_multistep.npz; needs those two files: run after "e2e" and "multistep").
   e2e_multistep.npz  oracle goldens of the multi-step archs (marigold: noise + 8-channel conv_in; rgb_blending) on the tiny configs.
   e2e_tiny.npz       end-to-end goldens of the fp32 oracle (oracle/) on the tiny configs: inputs + expected outputs
                      for every stage (latent, unet out, feats, decode, final) — what the HIP path is checked against
@@ -520,8 +523,324 @@ def make_e2e_tiny():
     print("e2e_tiny.npz", os.path.getsize(os.path.join(HERE, "e2e_tiny.npz")) // 1024, "KiB")
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# refexec_tiny.npz: the REFERENCE's own orchestration code, executed.  diffusers is absent, so the inside of the
+# diffusers blocks stays the oracle's restatement -- but everything the reference's tree itself holds for the hot path now RUNS instead of
+# being restated:  CustomUNet2DConditionModel.forward (custom_unet.py:34-427: time embedding call order, skip stack, popping order
+# `down_block_res_samples[-len(resnets):]`, forward_upsample_size / upsample_size, multi_level_feats, return_feature) on a stub
+# `UNet2DConditionModel` whose blocks call oracle.sd21's resnet_block / transformer_2d;  GenPerceptPipeline.__call__ / single_infer /
+# encode_rgb / decode_pred (genpercept_pipeline.py:146-337,375-526: normalisation, latent scale, [rgb_latent, pred_latent] concat order,
+# `pred_original_sample`, channel mean, clip / shift, `multi_level_feats[::-1]`, `[:, None]`, min-max, squeeze / clip / colourise) on a
+# stub `DiffusionPipeline`, a stub VAE (oracle encoder / decoder halves) and the REAL DPTNeckHeadForUnetAfterUpsampleIdentity.
+# The scheduler's `step` / `set_timesteps` are diffusers' (un-vendored): the stub delegates them to oracle.pipeline.DDIM.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _stub_refexec_modules():
+    """stand-ins for the import lines of custom_unet.py:11-17, genpercept_pipeline.py:22-36, dpt_head.py:20-21, image_util.py:21-22"""
+    import dataclasses
+
+    class BaseOutput(dict):  # diffusers' BaseOutput: an OrderedDict whose items are also attributes (dataclass subclasses AND plain keyword construction)
+        def __init__(self, *a, **k):
+            super().__init__()
+            for key, v in dict(*a, **k).items():
+                self[key] = v
+
+        def __setitem__(self, key, v):
+            super().__setitem__(key, v)
+            object.__setattr__(self, key, v)
+
+    class UNet2DConditionModel(torch.nn.Module):
+        pass
+
+    class DiffusionPipeline:
+        def __init__(self):
+            self._cfg = {}
+
+        def register_modules(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+
+        def register_to_config(self, **kw):
+            self._cfg.update(kw)
+
+        device = property(lambda self: torch.device("cpu"))
+        dtype = property(lambda self: torch.float32)
+
+    class DDIMScheduler:
+        pass
+
+    class LCMScheduler:
+        pass
+
+    class AutoencoderKL:
+        pass
+
+    mods = {n: types.ModuleType(n) for n in (
+        "diffusers", "diffusers.utils", "diffusers.models", "diffusers.models.lora", "diffusers.models.unets",
+        "diffusers.models.unets.unet_2d_condition", "torchvision", "torchvision.transforms", "torchvision.transforms.functional")}
+    d, du = mods["diffusers"], mods["diffusers.utils"]
+    d.AutoencoderKL, d.DDIMScheduler, d.DiffusionPipeline, d.LCMScheduler, d.UNet2DConditionModel = (
+        AutoencoderKL, DDIMScheduler, DiffusionPipeline, LCMScheduler, UNet2DConditionModel)
+    du.BaseOutput, du.USE_PEFT_BACKEND = BaseOutput, True
+    du.deprecate = lambda *a, **k: None
+    du.logging = types.SimpleNamespace(get_logger=lambda *a, **k: None)
+    du.scale_lora_layers = du.unscale_lora_layers = lambda *a, **k: None
+    mods["diffusers.models.lora"].LoRACompatibleConv = torch.nn.Conv2d
+    mods["diffusers.models.unets.unet_2d_condition"].UNet2DConditionOutput = dataclasses.make_dataclass("UNet2DConditionOutput", [("sample", object, None)])
+
+    class InterpolationMode:
+        BILINEAR, BICUBIC, NEAREST_EXACT = "bilinear", "bicubic", "nearest-exact"
+
+    def _no_tv(*a, **k):
+        raise RuntimeError("torchvision is not installed: the fixtures use processing_res=0 / match_input_res=False")
+
+    mods["torchvision.transforms"].InterpolationMode = InterpolationMode
+    mods["torchvision.transforms.functional"].pil_to_tensor = _no_tv
+    mods["torchvision.transforms.functional"].resize = _no_tv
+    mods["torchvision"].transforms = mods["torchvision.transforms"]
+    mods["torchvision.transforms"].functional = mods["torchvision.transforms.functional"]
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    return saved, d
+
+
+def _refexec_import():
+    """import the reference's package (NOT this repository's shim) under the stubs; returns (pipeline module, custom_unet module, dpt module)"""
+    import importlib
+    # transformers probes `torchvision` through importlib.util.find_spec at import time: load everything the reference takes from it first
+    from transformers import CLIPTextModel, CLIPTokenizer, DPTConfig, DPTPreTrainedModel  # noqa: F401
+    import transformers.models.dpt.modeling_dpt  # noqa: F401
+    saved, d = _stub_refexec_modules()
+    path0 = list(sys.path)
+    sys.path[:] = [REF] + [p for p in sys.path if os.path.abspath(p or ".") != ROOT]
+    for name in [m for m in sys.modules if m == "genpercept" or m.startswith("genpercept.")]:
+        del sys.modules[name]
+    try:
+        gpp = importlib.import_module("genpercept.genpercept_pipeline")
+        cu = importlib.import_module("genpercept.models.custom_unet")
+        dh = importlib.import_module("genpercept.models.dpt_head")
+    finally:
+        sys.path[:] = path0
+    assert gpp.__file__.startswith(REF) and cu.__file__.startswith(REF)
+    return gpp, cu, dh, d, saved
+
+
+def _refexec_cleanup(saved):
+    for name in [m for m in sys.modules if m == "genpercept" or m.startswith("genpercept.")]:
+        del sys.modules[name]
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+
+
+def _refexec_unet(cu, sd, cfg):
+    """an instance of the REFERENCE's CustomUNet2DConditionModel whose sub-modules are the oracle's functions over the state dict `sd`"""
+    g = cfg.norm_num_groups
+
+    class Down:
+        def __init__(self, i):
+            self.i, self.has_cross_attention = i, cfg.down_has_attn[i]
+
+        def __call__(self, hidden_states, temb, encoder_hidden_states=None, **kw):
+            x, outs, i = hidden_states, (), self.i
+            for j in range(cfg.layers_per_block):
+                x = osd.resnet_block(x, sd, f"down_blocks.{i}.resnets.{j}", g, cfg.norm_eps, temb)
+                if self.has_cross_attention:
+                    x = osd.transformer_2d(x, sd, f"down_blocks.{i}.attentions.{j}", cfg.num_heads[i], encoder_hidden_states, g)
+                outs += (x,)
+            if i != len(cfg.block_out_channels) - 1:
+                x = osd._conv(x, sd, f"down_blocks.{i}.downsamplers.0.conv", stride=2, padding=1)
+                outs += (x,)
+            return x, outs
+
+    class Mid:
+        has_cross_attention = True
+
+        def __call__(self, x, temb, encoder_hidden_states=None, **kw):
+            x = osd.resnet_block(x, sd, "mid_block.resnets.0", g, cfg.norm_eps, temb)
+            x = osd.transformer_2d(x, sd, "mid_block.attentions.0", cfg.num_heads[-1], encoder_hidden_states, g)
+            return osd.resnet_block(x, sd, "mid_block.resnets.1", g, cfg.norm_eps, temb)
+
+    class Up:
+        def __init__(self, i, blk):
+            self.i, self.blk, self.has_cross_attention = i, blk, blk["attn"]
+            self.resnets = [None] * len(blk["resnets"])  # custom_unet.py:372 takes len() of it
+
+        def __call__(self, hidden_states, temb, res_hidden_states_tuple, encoder_hidden_states=None, upsample_size=None, **kw):
+            x, i = hidden_states, self.i
+            for j in range(len(self.resnets)):
+                res = res_hidden_states_tuple[-1]                     # diffusers' up blocks pop the tuple from the END
+                res_hidden_states_tuple = res_hidden_states_tuple[:-1]
+                x = torch.cat([x, res], dim=1)
+                x = osd.resnet_block(x, sd, f"up_blocks.{i}.resnets.{j}", g, cfg.norm_eps, temb)
+                if self.has_cross_attention:
+                    x = osd.transformer_2d(x, sd, f"up_blocks.{i}.attentions.{j}", self.blk["heads"], encoder_hidden_states, g)
+            if self.blk["upsample"]:
+                x = (torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest") if upsample_size is None
+                     else torch.nn.functional.interpolate(x, size=tuple(upsample_size), mode="nearest"))
+                x = osd._conv(x, sd, f"up_blocks.{i}.upsamplers.0.conv")
+            return x
+
+    m = cu.CustomUNet2DConditionModel()
+    m.config = types.SimpleNamespace(center_input_sample=False, class_embed_type=None, addition_embed_type=None, encoder_hid_dim_type=None,
+                                     class_embeddings_concat=False)
+    m.num_upsamplers = len(cfg.block_out_channels) - 1
+    m.time_proj = lambda t: osd.timestep_embedding(t, cfg.block_out_channels[0])
+    m.time_embedding = lambda te, cond=None: osd._linear(torch.nn.functional.silu(osd._linear(te, sd, "time_embedding.linear_1")), sd, "time_embedding.linear_2")
+    m.class_embedding = m.time_embed_act = m.encoder_hid_proj = None
+    m.conv_in = lambda x: osd._conv(x, sd, "conv_in")
+    m.down_blocks = [Down(i) for i in range(len(cfg.block_out_channels))]
+    m.mid_block = Mid()
+    m.up_blocks = [Up(i, blk) for i, blk in enumerate(osd.unet_up_plan(cfg))]
+    has_out = "conv_out.weight" in sd
+    m.conv_norm_out = (lambda x: osd._gn(x, sd, "conv_norm_out", g, cfg.norm_eps)) if has_out else None
+    m.conv_act = torch.nn.functional.silu
+    m.conv_out = (lambda x: osd._conv(x, sd, "conv_out")) if has_out else None
+    return m
+
+
+def make_refexec_golden():
+    import json
+    gpp, cu, dh, d, saved = _refexec_import()
+    try:
+        uc, vc, dc = osd.UNetCfg.tiny(), osd.VAECfg.tiny(), odpt.DPTCfg.tiny()
+        usd = osd.synth_state_dict(osd.unet_manifest(uc), 1)      # the seeds / inputs of e2e_tiny.npz
+        vsd = osd.synth_state_dict(osd.vae_manifest(vc), 2)
+        dsd = osd.synth_state_dict(odpt.dpt_manifest(dc), 3)
+        usd_noout = {k: v for k, v in usd.items() if not k.startswith(("conv_out", "conv_norm_out"))}
+        e2e = np.load(os.path.join(HERE, "e2e_tiny.npz"))
+
+        class VAE:  # genpercept_pipeline.py:500-501,521-522 call vae.encoder / quant_conv / post_quant_conv / decoder separately
+            @staticmethod
+            def encoder(x):
+                sd_ = dict(vsd)
+                sd_["quant_conv.weight"] = torch.eye(2 * vc.latent_channels)[:, :, None, None]
+                sd_["quant_conv.bias"] = torch.zeros(2 * vc.latent_channels)
+                return osd.vae_encode_moments(sd_, vc, x)          # identity quant_conv: the encoder's own output
+
+            quant_conv = staticmethod(lambda h: osd._conv(h, vsd, "quant_conv", padding=0))
+            post_quant_conv = staticmethod(lambda z: osd._conv(z, vsd, "post_quant_conv", padding=0))
+
+            @staticmethod
+            def decoder(z):
+                sd_ = dict(vsd)
+                sd_["post_quant_conv.weight"] = torch.eye(vc.latent_channels)[:, :, None, None]
+                sd_["post_quant_conv.bias"] = torch.zeros(vc.latent_channels)
+                return osd.vae_decode(sd_, vc, z)
+
+        class Sched(d.DDIMScheduler):  # diffusers' step / set_timesteps are un-vendored: oracle.pipeline.DDIM stands in
+            def __init__(self, **cfg):
+                self.o = opipe.DDIM(**cfg)
+                self.beta_start, self.beta_end = cfg["beta_start"], cfg["beta_end"]
+
+            def set_timesteps(self, n, device=None):
+                self.o.set_timesteps(n)
+                self.timesteps = torch.as_tensor(np.asarray(self.o.timesteps).copy())
+
+            def step(self, model_output, t, sample, generator=None):
+                prev, x0 = self.o.step(model_output, int(t), sample)
+                return types.SimpleNamespace(prev_sample=prev, pred_original_sample=x0)
+
+        with open(os.path.join(REF, "hf_configs/dpt-sd2.1-unet-after-upsample-general/config.json")) as f:
+            from transformers import DPTConfig
+            hc = json.load(f)
+        hc.update(neck_hidden_sizes=list(dc.neck_hidden_sizes), fusion_hidden_size=dc.fusion_hidden_size)
+        import dataclasses
+        if not dataclasses.is_dataclass(dh.DepthEstimatorOutput):  # (the installed transformers wants ModelOutput subclasses decorated; dpt_head.py:24 is not)
+            dataclasses.dataclass(dh.DepthEstimatorOutput)
+        head = dh.DPTNeckHeadForUnetAfterUpsampleIdentity(DPTConfig(**hc)).eval()
+        assert {k: tuple(v.shape) for k, v in head.state_dict().items()} == {k: tuple(v) for k, v in odpt.dpt_manifest(dc).items()}
+        head.load_state_dict(dsd, strict=True)
+
+        beta1 = dict(beta_start=1.0, beta_end=1.0, beta_schedule="linear", clip_sample=False, set_alpha_to_one=False, steps_offset=1,
+                     prediction_type="v_prediction", timestep_spacing="leading")  # hf_configs/scheduler_beta_1.0_1.0
+        out = {}
+        with torch.no_grad():
+            for tag in ("sq", "odd"):
+                rgb_u8 = torch.as_tensor(e2e[f"{tag}_rgb_u8"])
+                ctx = torch.as_tensor(e2e[f"{tag}_ctx"])
+                b = rgb_u8.shape[0]
+                # --- the reference's UNet forward alone (golden latent in) --------------------------------------------------------
+                lat = torch.as_tensor(e2e[f"{tag}_latent"])
+                unet = _refexec_unet(cu, usd, uc)
+                r = unet(lat, 1, encoder_hidden_states=ctx[None].expand(b, -1, -1))
+                out[f"{tag}_unet"] = r.sample.numpy()
+                for i, f_ in enumerate(r.multi_level_feats):
+                    out[f"{tag}_feat{i}"] = f_.numpy().astype(np.float16)
+                rf = _refexec_unet(cu, usd_noout, uc)(lat, torch.tensor([1]), encoder_hidden_states=ctx[None].expand(b, -1, -1), return_feature=True)
+                assert rf.sample is None and all(torch.equal(a, c) for a, c in zip(rf.multi_level_feats, r.multi_level_feats))
+                ov, of = osd.unet_forward(usd, uc, lat, 1, ctx[None].expand(b, -1, -1))
+                assert torch.equal(ov, r.sample) and all(torch.equal(a, c) for a, c in zip(of, r.multi_level_feats)), "oracle.unet_forward != reference forward"
+                # --- the reference's pipeline: single_infer and __call__ ----------------------------------------------------------
+                def pipe(head_=None, unet_sd=usd, sched=beta1, **kw):
+                    p = gpp.GenPerceptPipeline(unet=_refexec_unet(cu, unet_sd, uc), vae=VAE, scheduler=Sched(**sched), text_encoder=None, tokenizer=None,
+                                               customized_head=head_, **kw)
+                    p.text_embed = ctx[None]  # genpercept_pipeline.py:425-429: cached embedding, encode_text is skipped
+                    return p
+                rgb_norm = rgb_u8.float() / 255.0 * 2.0 - 1.0
+                for mode in ("depth", "normal"):
+                    p = pipe()
+                    p.mode = mode
+                    out[f"{tag}_{mode}"] = p.single_infer(rgb_norm, 1, None, False).numpy()
+                    # (not bitwise: the pipeline calls vae.encoder / quant_conv / post_quant_conv / decoder as four modules, the oracle's VAE
+                    #  functions fold them into two calls -- a few fp32 ulps of the [0,1] map)
+                    np.testing.assert_allclose(out[f"{tag}_{mode}"], e2e[f"{tag}_{mode}"], rtol=0, atol=1e-5, err_msg=f"oracle single_infer != reference ({tag}, {mode})")
+                p = pipe(head_=head, unet_sd=usd_noout)
+                p.mode = "disparity"
+                out[f"{tag}_disp"] = torch.cat([p.single_infer(rgb_norm[i:i + 1], 1, None, False) for i in range(b)]).numpy()  # one image per call (F10)
+                np.testing.assert_allclose(out[f"{tag}_disp"], e2e[f"{tag}_disp"], rtol=0, atol=1e-5)  # (reference head = nn modules, oracle = functional)
+                out[f"{tag}_latent"] = p.encode_rgb(rgb_norm).numpy()
+                np.testing.assert_allclose(out[f"{tag}_latent"], e2e[f"{tag}_latent"], rtol=0, atol=1e-5)
+                # __call__ (processing_res=0, match_input_res=False: the two torchvision calls are not reached), image 0
+                for mode, cmap in (("depth", "Spectral"), ("normal", None)):
+                    o = pipe()(rgb_u8[:1], denoising_steps=1, ensemble_size=1, processing_res=0, match_input_res=False, batch_size=1, color_map=cmap,
+                               show_progress_bar=False, mode=mode)
+                    out[f"{tag}_call_{mode}_np"] = o.pred_np
+                    out[f"{tag}_call_{mode}_colored"] = np.asarray(o.pred_colored)
+                o = pipe(head_=head, unet_sd=usd_noout)(rgb_u8[:1], denoising_steps=1, ensemble_size=1, processing_res=0, match_input_res=False, batch_size=1,
+                                                        color_map="Spectral", show_progress_bar=False, mode="disparity")
+                out[f"{tag}_call_disp_np"], out[f"{tag}_call_disp_colored"] = o.pred_np, np.asarray(o.pred_colored)
+                # fix_timesteps (genpercept_pipeline.py:405-408)
+                p = pipe()
+                p.mode = "depth"
+                out[f"{tag}_depth_fix400"] = p.single_infer(rgb_norm, 1, None, False, fix_timesteps=400).numpy()
+            # --- multi-step archs through the reference's loop (:413-422,447-465): marigold (noise + 8-channel conv_in), rgb_blending ------
+            ms = np.load(os.path.join(HERE, "e2e_multistep.npz"))
+            ctx = torch.as_tensor(ms["ctx"])
+            uc8 = osd.UNetCfg(in_channels=8, block_out_channels=uc.block_out_channels, num_heads=uc.num_heads, cross_attention_dim=uc.cross_attention_dim)
+            unet8 = opipe.replace_unet_conv_in(usd)
+            for tag in ("sq", "odd"):
+                rgb_norm = torch.as_tensor(ms[f"{tag}_rgb"]).float() / 255.0 * 2.0 - 1.0
+                noise = torch.as_tensor(ms[f"{tag}_noise"])
+
+                class FixedNoise:  # stands in for torch.randn(..., generator=g) of :416-420: the fixture's noise tensor
+                    pass
+                def run(unet_sd, ucfg, blending, steps):
+                    p = gpp.GenPerceptPipeline(unet=_refexec_unet(cu, unet_sd, ucfg), vae=VAE, scheduler=Sched(**MULTISTEP_SCHED), text_encoder=None,
+                                               tokenizer=None, genpercept_pipeline=False, rgb_blending=blending)
+                    p.text_embed, p.mode = ctx[None], "depth"
+                    if blending:
+                        return p.single_infer(rgb_norm, steps, None, False).numpy()
+                    real_randn = torch.randn
+                    try:
+                        gpp.torch.randn = lambda *a, **k: noise.clone()
+                        return p.single_infer(rgb_norm, steps, None, False).numpy()
+                    finally:
+                        gpp.torch.randn = real_randn
+                for steps in (1, 4):
+                    out[f"{tag}_marigold_{steps}"] = run(unet8, uc8, False, steps)
+                    out[f"{tag}_blend_{steps}"] = run(usd, uc, True, steps)
+                    np.testing.assert_allclose(out[f"{tag}_marigold_{steps}"], ms[f"{tag}_marigold_{steps}"], rtol=0, atol=1e-5)
+                    np.testing.assert_allclose(out[f"{tag}_blend_{steps}"], ms[f"{tag}_blend_{steps}"], rtol=0, atol=1e-5)
+    finally:
+        _refexec_cleanup(saved)
+    np.savez_compressed(os.path.join(HERE, "refexec_tiny.npz"), **out)
+    print("refexec_tiny.npz", os.path.getsize(os.path.join(HERE, "refexec_tiny.npz")) // 1024, "KiB;", len(out), "arrays; oracle == reference-executed on every stage")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dpt", "metrics", "e2e", "batchsize", "infer_eval", "image_util", "datasets", "scheduler", "ensemble", "multistep"]
+    which = sys.argv[1:] or ["dpt", "metrics", "e2e", "batchsize", "infer_eval", "image_util", "datasets", "scheduler", "ensemble", "multistep", "refexec"]
     if "scheduler" in which:
         make_scheduler_golden()
     if "ensemble" in which:
@@ -544,3 +863,5 @@ if __name__ == "__main__":
         make_image_util_golden()
     if "datasets" in which:
         make_datasets_golden()
+    if "refexec" in which:
+        make_refexec_golden()
