@@ -97,7 +97,32 @@ def respawn_under_torchrun(n: int):
     os.execv(sys.executable, cmd)
 
 
-def main():
+def device_sync(dev):
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize()
+
+
+def timed_steps(step, warmup: int, steps: int, dev):
+    """The timing contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + device synchronize on both sides; the
+    elapsed time is the MAX over ranks.  Returns (seconds, last step's result)."""
+    from genpercept_amd import distributed as gd
+    o = None
+    for _ in range(warmup):
+        o = step()
+    device_sync(dev)
+    gd.barrier()
+    device_sync(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o = step()
+    device_sync(dev)
+    gd.barrier()
+    return gd.max_over_ranks(time.perf_counter() - t0, dev), o
+
+
+def main(argv=None, engine_factory=None, device=None):
+    """`engine_factory(local_rank, precision) -> engine` and `device` exist for the CPU (gloo) test of the N > 1 path, which runs this very
+    function with a stub engine (tests/test_host.py); the product run passes neither."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -114,7 +139,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-fp16", action="store_true", help="skip the second timed leg with the fp16 library")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args.gpus)  # does not return
@@ -129,8 +154,11 @@ def main():
     if world != max(args.gpus, 1):
         raise SystemExit(f"bench.py: WORLD_SIZE {world} != --gpus {args.gpus} (the multi-GPU configuration would silently not be measured)")
     n_gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if device is None:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device(device)
 
     if world > 1:  # every rank synthesises the same weights on the host: share the cores instead of oversubscribing them N times
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
@@ -140,12 +168,16 @@ def main():
     ucfg, vcfg = gc.UNetConfig(has_out=not dpt), gc.VAEConfig()
     dcfg = gc.DPTConfig() if dpt else None
     t0 = time.time()
-    usd = gw.synth_state_dict(gw.unet_manifest(ucfg), seed=0)
-    vsd = gw.synth_state_dict(gw.vae_manifest(vcfg), seed=1)
-    dsd = gw.synth_state_dict(gw.dpt_manifest(dcfg), seed=3) if dpt else None
+    usd = vsd = dsd = None
+    if engine_factory is None:
+        usd = gw.synth_state_dict(gw.unet_manifest(ucfg), seed=0)
+        vsd = gw.synth_state_dict(gw.vae_manifest(vcfg), seed=1)
+        dsd = gw.synth_state_dict(gw.dpt_manifest(dcfg), seed=3) if dpt else None
     ctx = torch.randn(2, ucfg.cross_attention_dim, generator=torch.Generator().manual_seed(2))
 
     def build_engine(precision):
+        if engine_factory is not None:
+            return engine_factory(local_rank, precision)
         e = Engine(local_rank, ucfg, vcfg, dcfg, precision=precision)
         e.load_state_dict("vae", vsd)
         e.load_state_dict("unet", usd)
@@ -164,24 +196,13 @@ def main():
     do_gather = n_gpus > 1 and not args.no_gather
 
     def timed(engine):
-        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        """one step = one pass of the hot path over this rank's shard (+ the result gather of configs[4] when N > 1)"""
         def step():
             o = engine.infer(rgb, args.mode)
             if do_gather:
                 return gd.gather_results(o, n_total, dst=0)  # rank 0: [N*B, C, H, W]; others: None
             return o
-        o = None
-        for _ in range(args.warmup):
-            o = step()
-        torch.cuda.synchronize()
-        gd.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            o = step()
-        torch.cuda.synchronize()
-        gd.barrier()
-        el = gd.max_over_ranks(time.perf_counter() - t0, dev)
+        el, o = timed_steps(step, args.warmup, args.steps, dev)
         if o is not None:
             assert torch.isfinite(o).all()
             if do_gather:
@@ -197,13 +218,7 @@ def main():
     gather_ms = None
     if do_gather:  # the gather alone (same tensors), max over ranks
         loc = eng.infer(rgb, args.mode)
-        torch.cuda.synchronize()
-        gd.barrier()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            gd.gather_results(loc, n_total, dst=0)
-        torch.cuda.synchronize()
-        gather_ms = round(gd.max_over_ranks(time.perf_counter() - t0, dev) / 5 * 1e3, 3)
+        gather_ms = round(timed_steps(lambda: gd.gather_results(loc, n_total, dst=0), 0, 5, dev)[0] / 5 * 1e3, 3)
 
     roofline = None
     stages = None
@@ -336,6 +351,7 @@ def main():
     eng.close()
     if world > 1:
         torch.distributed.destroy_process_group()
+    return line if rank == 0 else None
 
 
 if __name__ == "__main__":

@@ -543,3 +543,59 @@ def test_normal_angular_error_matches_reference_angular_loss():
     assert same["mean_deg"] < 1.0  # the clamp at 1 - 1e-4 leaves acos(0.9999) = 0.81 degrees, like the reference
     enc = np.moveaxis((g["normal_gt"][0] + 1.0) / 2.0, 0, -1)  # what the pipeline returns for mode='normal'
     assert np.allclose(em.decode_normals(enc), g["normal_gt"][0], atol=1e-6)
+
+
+_BENCH_WORKER = r"""
+import io, json, os, sys, contextlib, torch
+sys.path.insert(0, {root!r})
+import bench
+from genpercept_amd import distributed as gd
+
+class StubEngine:                      # stands in for genpercept_amd.engine.Engine: infer() marks every image with its GLOBAL index
+    calls = 0
+    def __init__(self, local_rank, precision):
+        self.rank = int(os.environ["RANK"]); self.world = int(os.environ["WORLD_SIZE"])
+    def infer(self, rgb, mode):
+        StubEngine.calls += 1
+        lo, hi = gd.shard_range(4 * self.world, self.rank, self.world)
+        assert rgb.shape[0] == hi - lo and rgb.dtype == torch.uint8
+        return torch.stack([torch.full((1, rgb.shape[2], rgb.shape[3]), float(i)) for i in range(lo, hi)]) / 16.0
+    def close(self):
+        pass
+
+buf = io.StringIO()
+with contextlib.redirect_stdout(buf):
+    line = bench.main(["--gpus", "2", "--steps", "3", "--warmup", "1", "--res", "32", "--no-cpu", "--no-profile", "--no-fp16"],
+                      engine_factory=StubEngine, device="cpu")
+rank = int(os.environ["RANK"])
+ok = StubEngine.calls == 1 + 3 + 1        # warm-up + timed steps + the gather-alone leg's one infer
+if rank == 0:
+    printed = json.loads(buf.getvalue().strip().splitlines()[-1])
+    ok = ok and printed == line and line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    ok = ok and line["config"]["global_batch"] == 8 and line["config"]["gather_ms"] is not None and line["config"]["gather_ms"] >= 0
+    ok = ok and abs(line["value"] - 8 * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-2 * line["value"] and line["higher_is_better"] is True
+else:
+    ok = ok and line is None and buf.getvalue().strip() == ""   # ONE JSON line, from rank 0 only
+sys.stderr.write("<rank%d:%s>\n" % (rank, "OK" if ok else "FAIL " + buf.getvalue()))
+sys.stderr.flush()
+sys.exit(0 if ok else 1)
+"""
+
+
+def test_bench_multi_gpu_path_world_size_2_gloo(tmp_path):
+    """bench.py's own N > 1 code (init_process_group from the torchrun environment, WORLD_SIZE == --gpus check, contiguous shards, the timed
+    loop with barrier + max over ranks, the in-step result gather to rank 0, the gather-alone leg, ONE JSON line from rank 0) executed on
+    CPU with gloo and a stub engine -- VERDICT r3 item 8: that code had never run anywhere."""
+    script = tmp_path / "bench_worker.py"
+    script.write_text(_BENCH_WORKER.format(root=ROOT))
+    port = 31500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "<rank0:OK>" in r.stderr and "<rank1:OK>" in r.stderr, r.stdout + r.stderr
+    # a launcher whose WORLD_SIZE disagrees with --gpus is refused (r1 silently measured one GPU)
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE 1 != --gpus 2" in (r.stdout + r.stderr)
