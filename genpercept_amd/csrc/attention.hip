@@ -241,7 +241,7 @@ void launch_flash_attn64(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t*
     // K / V^T fragment read feeds two MFMAs: 1100 us with 256 VGPRs + 42 spilled, 1050 us at one wave per SIMD; one online-softmax update per
     // 32 keys instead of 64 (165 VGPRs): 644 us.  r2 ablations of the shipped shape: no softmax arithmetic 494 us, no P.V MFMAs 587 us, neither
     // 442 us, additionally no K.Q^T MFMAs 249 us (the LDS fragment reads, DMA and loop alone), no waits / barriers 601 us.
-    static const bool ring2 = getenv("GENPERCEPT_FLASH_RING3") == nullptr;
+    const bool ring2 = !gp_sw().flash_ring3;
     if (ring2) hipLaunchKernelGGL((flash_attn64_kernel<2, 2>), grid, dim3(256), 2 * 16384, s, q, k, vt, out, T, heads, ldq, ldk, Tpad, ldo);
     else hipLaunchKernelGGL((flash_attn64_kernel<2, 3>), grid, dim3(256), 3 * 16384, s, q, k, vt, out, T, heads, ldq, ldk, Tpad, ldo);
 }
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void flash512_combine_kernel(const float* __re
         *(uint2*)(ob + 32 * i) = pack_h16x4(acc[4 * i] * inv, acc[4 * i + 1] * inv, acc[4 * i + 2] * inv, acc[4 * i + 3] * inv);
 }
 
-bool flash_attn512_supported(int C) { return C == 512 && getenv("GENPERCEPT_NO_FLASH512") == nullptr; }
+bool flash_attn512_supported(int C) { return C == 512 && !gp_sw().no_flash512; }
 // Workgroups to launch: the CU count, or -- when the query blocks would leave half of the chip idle (one image at 768^2 is 72 blocks on
 // 256 CUs) -- a multiple of the block count, so that EVERY block is cut along the keys into G / blocks parts.
 static int flash512_grid(int nblocks, int ncu, int T) {
@@ -572,7 +572,7 @@ void launch_flash_attn512(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t
     const int rounds = nblocks / G, L = nblocks - rounds * G, S = L ? G / L : 0;
     float* part_o = ws;
     float* part_ml = ws ? ws + (long long)S * L * 128 * 512 : nullptr;
-    static const int dbg = getenv("GENPERCEPT_F5_DBG") ? atoi(getenv("GENPERCEPT_F5_DBG")) : 0;  // timing ablations only: 1 no K DMA, 2 no V DMA
+    const int dbg = gp_sw().f5_dbg;  // timing ablations only: 1 no K DMA, 2 no V DMA
     hipLaunchKernelGGL(flash_attn512_kernel, dim3(G), dim3(256), F5_LDS, s, q, k, vt, out, part_o, part_ml, B, T, ldq, ldk, Tpad,
                        ldo, scale, dbg);
     if (L) hipLaunchKernelGGL(flash512_combine_kernel, dim3(L * 4), dim3(256), 0, s, part_o, part_ml, out, T, nqb, rounds * G, (L % B == 0) ? L / B : 0,

@@ -154,22 +154,23 @@ GP_DEV float wave_sum(float x) {
 
 // x[l] + x[l ^ 32] / x[l] + x[l ^ 16] in every lane: v_permlane32_swap / v_permlane16_swap (gfx950) exchange half-waves / odd-even rows of 16
 // between two registers (semantics probed on the chip, tools/probe/permlane_probe.cpp: vdst' = [a.lo, b.lo], src' = [a.hi, b.hi]; rows
-// [a0, b0, a2, b2] / [a1, b1, a3, b3]); with both registers holding x their sum is the pairwise total.  The two wait states a VALU write
-// needs before a permlane reads it are inside the string.
+// [a0, b0, a2, b2] / [a1, b1, a3, b3]); with both registers holding x their sum is the pairwise total.  Through the BUILTINS, so that the
+// compiler's hazard recognizer owns both sides (the wait states a VALU write needs before a permlane reads it, and whatever the
+// consumer of the result needs): r3 issued them from inline asm with a hand-placed s_nop on the producer side only.
 GP_DEV float xor32_sum(float x) {
-    float a = x, b = x;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return a + b;
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
 }
 GP_DEV float xor16_sum(float x) {
-    float a = x, b = x;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return a + b;
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
 }
 GP_DEV float xor32_max(float x) {
-    float a = x, b = x;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return fmaxf(a, b);
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
 }
 // sum over the lanes l' == l (mod SLW), SLW = 4, 8 or 16, valid in lanes 0 .. SLW-1 (every row's first SLW lanes): row_shl inside the rows of 16
 // (lane i += lane i + 8, then + 4), then the two cross-row exchanges.  Replaces `for (off = 32; off >= SLW; off >>= 1) x += __shfl_xor(x, off)`,

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512) void conv_few_kernel(const ConvFewParams p) {
 }
 
 bool conv_few_applicable(int Cin, int Cout, int H, int W) {
-    static const bool off = getenv("GENPERCEPT_NO_CONV_FEW") != nullptr;  // A/B switch
+    const bool off = gp_sw().no_conv_few;  // A/B switch
     return !off && Cin == 64 * CF_CPT && Cout == 3 && H >= 1 && W >= 1;
 }
 

@@ -225,7 +225,7 @@ static int conv_img_nb(int B, int H, int W) {
 }
 
 bool conv_img_applicable(const IGemmParams& p) {
-    static const bool off = getenv("GENPERCEPT_NO_CONV_IMG") != nullptr;  // A/B switch
+    const bool off = gp_sw().no_conv_img;  // A/B switch
     if (off || p.ks != 3 || p.stride != 1 || p.ups || p.pad_t != 1 || p.pad_l != 1 || p.batch > 1 || p.in_scale || p.out_fp32) return false;
     if (p.act == GP_ACT_GEGLU || p.bias_mode == GP_BIAS_ROW || p.Ho != p.Hi || p.Wo != p.Wi) return false;
     if ((p.Cin & 31) || (p.N & 63) || p.N != p.n_store || p.n_store != p.ldo || (p.ldo & 3) || p.Cin < 64) return false;
@@ -240,7 +240,7 @@ int conv_img_ksplit(const IGemmParams& p) {
     const int nc = p.Cin >> 5;
     if (S > nc / 2) S = nc / 2;           // at least two 32-channel chunks (six steps) per slice
     if (S > 16) S = 16;
-    static const int s_env = getenv("GENPERCEPT_CONV_IMG_S") ? atoi(getenv("GENPERCEPT_CONV_IMG_S")) : 0;  // tuning switch
+    const int s_env = gp_sw().conv_img_s;  // tuning switch
     if (s_env > 0 && s_env <= nc / 2 && s_env <= 16) S = s_env;
     return S < 1 ? 1 : S;
 }

@@ -462,7 +462,7 @@ struct gp_engine {
             t.kc = upload(kc.data(), kc.size());
             t.vc = upload(vc.data(), vc.size());
             t.fU = t.fu0 = t.fG = t.fc0 = nullptr;
-            if (L == 2 && cross_attn_fold_supported(C, t.heads) && !getenv("GENPERCEPT_NO_CROSS_FOLD")) {
+            if (L == 2 && cross_attn_fold_supported(C, t.heads) && !gp_sw().no_cross_fold) {
                 // softmax over two keys = sigmoid of the logit difference; see cross_fold_kernel (norm.hip) for the algebra
                 const int hd = 64, nh = t.heads;
                 std::vector<float> U((size_t)nh * C), u0(nh), G((size_t)nh * C), c0(C);
@@ -498,10 +498,11 @@ struct gp_engine {
     void finalize() {
         if (finalized) throw std::logic_error("gp_finalize called twice");
         HIPCHK(hipSetDevice(cfg.device));
-        fuse_gn = getenv("GENPERCEPT_NO_GN_FUSION") == nullptr;
-        if (const char* ms = getenv("GENPERCEPT_GN_FUSE_MAX_SLICES")) gn_fuse_max_slices = atoi(ms);
-        if (const char* px = getenv("GENPERCEPT_GN_FUSE_BELOW_PX")) gn_fuse_always_below_px = atoi(px);
-        fuse_stats = getenv("GENPERCEPT_NO_STATS_FUSION") == nullptr;
+        gp_switches_reload();  // the A/B switches of this process as of now (never read again on the launch path)
+        fuse_gn = !gp_sw().no_gn_fusion;
+        if (gp_sw().gn_fuse_max_slices >= 0) gn_fuse_max_slices = gp_sw().gn_fuse_max_slices;
+        if (gp_sw().gn_fuse_below_px >= 0) gn_fuse_always_below_px = gp_sw().gn_fuse_below_px;
+        fuse_stats = !gp_sw().no_stats_fusion;
         {
             std::vector<h16_t> z(2048, 0);
             zero = upload(z.data(), z.size());
@@ -770,7 +771,7 @@ struct gp_engine {
         // rows = channels (320 ... 1280), columns = tokens: 64x64 tiles when there are few tokens or the channel count is not a multiple of 128
         // (320 rows leave a 128-row tile half empty), 128x64 tiles otherwise -- measured per shape with GENPERCEPT_VT_TILE (igemm.hip: tile_hint),
         // 0.77 -> 0.67 ms per pass over the 18 projections
-        static const int vt_tile = getenv("GENPERCEPT_VT_TILE") ? atoi(getenv("GENPERCEPT_VT_TILE")) : -1;
+        const int vt_tile = gp_sw().vt_tile;
         run_igemm(p, vt_tile >= 0 ? vt_tile : (T <= 1024 || (C % 128)) ? 2 : 6);
         return vt;
     }
@@ -789,7 +790,7 @@ struct gp_engine {
         }
     }
     // one-launch GroupNorm for small maps whose producer left no statistics behind (split-K convs of the 12x12 level, ...)
-    bool gn_small(const Act& x) const { return !x.st && groupnorm_small_applicable(x.B, x.H * x.W, x.C, cfg.norm_groups) && !getenv("GENPERCEPT_NO_GN_SMALL"); }
+    bool gn_small(const Act& x) const { return !x.st && groupnorm_small_applicable(x.B, x.H * x.W, x.C, cfg.norm_groups) && !gp_sw().no_gn_small; }
     Act groupnorm_small(const Act& x, const NormW& n, float eps, bool silu) {
         if (x.C != n.C) throw std::logic_error("groupnorm: channel mismatch");
         Act y = new_act(x.B, x.H, x.W, x.C);
@@ -875,7 +876,7 @@ struct gp_engine {
         // item of this path.  They are the SCALED logits (1/sqrt(C) is folded into the query projection, build_vae_attn) and the fp16
         // conversion saturates at +-65504 (epilogue.h), so an outlier row degrades to a one-hot softmax instead of inf - inf = NaN.
         // GENPERCEPT_FP32_SCORES=1 keeps fp32 (A/B)
-        static const bool f32_scores = getenv("GENPERCEPT_FP32_SCORES") != nullptr;
+        const bool f32_scores = gp_sw().fp32_scores;
         const bool half_scores = !f32_scores && softmax_rows_f16_supported(Tpad);
         float* S = (float*)pool.alloc((size_t)B * T * Tpad * (half_scores ? 2 : 4));
         {
@@ -947,7 +948,7 @@ struct gp_engine {
         Act qk;
         h16_t* vt = nullptr;
         {   // q | k | V^T in ONE launch when the persistent GEMM takes it (T % 16 == 0 ...), else the q | k GEMM + the transposed V GEMM
-            static const bool no_fuse = getenv("GENPERCEPT_NO_QKV_FUSE") != nullptr;  // A/B switch
+            const bool no_fuse = gp_sw().no_qkv_fuse;  // A/B switch
             IGemmParams p{};
             p.in = l1.p; p.wt = t.qkv.w; p.zero = zero;
             p.M = (int)l1.pixels(); p.N = 3 * C; p.Cin = t.qkv.cin_pad; p.n_rows = t.qkv.n_rows; p.ks = 1;
@@ -960,7 +961,7 @@ struct gp_engine {
             // 4 x 9216 tokens, C = 320 the transposed stores of the V third (16 bytes per channel row and lane) eat the saving: 55 vs 29 + 25
             // (same-box pipeline A/B, tools/gpu_ab_r03.sh: fusing every level is 0.1-0.2 ms per pass ahead of fusing none, the 4 x 9216 level
             // included: one launch and one pass over the LayerNorm output less outweigh the slower V slices)
-            static const int fuse_max_rows = getenv("GENPERCEPT_QKV_FUSE_MAX_ROWS") ? atoi(getenv("GENPERCEPT_QKV_FUSE_MAX_ROWS")) : (1 << 30);
+            const int fuse_max_rows = gp_sw().qkv_fuse_max_rows;
             if (!no_fuse && p.M <= fuse_max_rows && !t.qkv.bias && l1.C == t.qkv.cin_pad && igemm_uses_pgemm(p, 0)) {
                 qk = new_act(x.B, x.H, x.W, 2 * C);
                 vt = (h16_t*)pool.alloc((size_t)x.B * C * Tpad * sizeof(h16_t));
@@ -1017,7 +1018,7 @@ struct gp_engine {
     Act vae_encode(const void* rgb, int is_u8, int B, int Hh, int Ww) {
         const PackedW& win = convs.at("vae.encoder.conv_in");
         Act h;
-        if (win.cout % 32 == 0 && win.cin_pad == 64 && !getenv("GENPERCEPT_NO_RGB_CONV")) {
+        if (win.cout % 32 == 0 && win.cin_pad == 64 && !gp_sw().no_rgb_conv) {
             // u8 image -> conv_in output in one kernel (K = 27), statistics for the first resnet's norm1 included
             h = new_act(B, Hh, Ww, win.cout);
             if (fuse_stats) {
@@ -1363,6 +1364,11 @@ struct DevScratch {
     size_t floats[3] = {0, 0, 0};
 };
 static std::mutex g_scratch_mu;
+// what every per-kernel (test / tool) entry point opens with: the scratch lock, and the A/B switches as the environment has them NOW
+struct KernelEntry {
+    std::lock_guard<std::mutex> g;
+    KernelEntry() : g(g_scratch_mu) { gp_switches_reload(); }
+};
 static std::map<int, DevScratch> g_scratch;
 static DevScratch& dev_scratch() {  // call with g_scratch_mu held
     int dev = 0;
@@ -1414,6 +1420,7 @@ void gp_default_config(gp_config* c) {
 
 gp_status gp_create(const gp_config* cfg, gp_engine** out) {
     if (!cfg || !out) return GP_ERR_INVALID;
+    gp_switches_reload();
     gp_engine* e = new gp_engine();
     e->cfg = *cfg;
     *out = e;
@@ -1766,7 +1773,7 @@ gp_status gp_conv2d(const void* in, const void* w_packed, const float* bias, con
                     int out_fp32, int tile_hint, void* stream) {
     if (!in || !w_packed || !out || (Cin % 64) || (ks != 1 && ks != 3)) return GP_ERR_INVALID;
     try {
-        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        KernelEntry lk;
         IGemmParams p{};
         p.in = (const h16_t*)in; p.wt = (const h16_t*)w_packed; p.bias = bias; p.res = (const h16_t*)residual; p.out = out; p.zero = zero_page();
         p.M = B * Ho * Wo; p.N = Cout; p.Cin = Cin; p.n_rows = gp_packed_rows(Cout); p.ks = ks;
@@ -1776,7 +1783,7 @@ gp_status gp_conv2d(const void* in, const void* w_packed, const float* bias, con
         const int nst = n_store > 0 ? n_store : nout;
         p.lda = Cin; p.ldo = nst; p.ldres = nst; p.ldw = (ks == 3 ? 9 : 1) * Cin; p.n_store = nst; p.out_fp32 = out_fp32; p.act = act;
         p.bias_mode = bias ? GP_BIAS_COL : GP_BIAS_NONE; p.batch = 1;
-        if (const char* dbg = getenv("GENPERCEPT_IGEMM_DBG")) p.dbg = atoi(dbg);  // profiling ablations (tools/conv_bench.py)
+        p.dbg = gp_sw().igemm_dbg;  // profiling ablations (tools/conv_bench.py)
         attach_splitk_scratch(p, tile_hint);
         launch_igemm(p, tile_hint, (hipStream_t)stream);
         HIPCHK(hipGetLastError());
@@ -1788,7 +1795,7 @@ gp_status gp_conv2d_gn(const void* in, const void* w_packed, const float* bias, 
                        int Cout, int ups, int act, const float* gamma, const float* beta, int groups, float eps, int silu, void* stream) {
     if (!in || !w_packed || !out || !gamma || !beta || (Cin % 64) || (Cin % groups)) return GP_ERR_INVALID;
     try {
-        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        KernelEntry lk;
         const int Ho = ups ? 2 * H : H, Wo = ups ? 2 * W : W;
         IGemmParams p{};
         p.in = (const h16_t*)in; p.wt = (const h16_t*)w_packed; p.bias = bias; p.res = (const h16_t*)residual; p.out = out; p.zero = zero_page();
@@ -1827,7 +1834,7 @@ gp_status gp_conv2d_stats(const void* in, const void* w_packed, const float* bia
     if (!in || !w_packed || !out || !gamma || !beta || !scale_out || !shift_out || (Cin % 64) || (ks != 1 && ks != 3) || groups < 1 || (Cout % groups))
         return GP_ERR_INVALID;
     try {
-        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        KernelEntry lk;
         const int Ho = ups ? 2 * H : H, Wo = ups ? 2 * W : W;
         IGemmParams p{};
         p.in = (const h16_t*)in; p.wt = (const h16_t*)w_packed; p.bias = bias; p.res = (const h16_t*)residual; p.out = out; p.zero = zero_page();
@@ -1836,7 +1843,7 @@ gp_status gp_conv2d_stats(const void* in, const void* w_packed, const float* bia
         p.ups = ups ? 1 : 0; p.Hu = ups ? Ho : 0; p.Wu = ups ? Wo : 0;
         p.lda = Cin; p.ldo = Cout; p.ldres = Cout; p.ldw = (ks == 3 ? 9 : 1) * Cin; p.n_store = Cout;
         p.bias_mode = bias ? GP_BIAS_COL : GP_BIAS_NONE; p.batch = 1;
-        if (const char* dbg = getenv("GENPERCEPT_IGEMM_DBG")) p.dbg = atoi(dbg);
+        p.dbg = gp_sw().igemm_dbg;
         int mode = 0, bm = 0;
         const int nt = igemm_tile_info(p, tile_hint, &mode, &bm);
         if (nt <= 0) return GP_ERR_INVALID;
@@ -1855,13 +1862,13 @@ gp_status gp_gemm(const void* a, int lda, const void* bt, int ldb, const float* 
                   long long out_bs, int tile_hint, void* stream) {
     if (!a || !bt || !out || (K % 64)) return GP_ERR_INVALID;
     try {
-        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        KernelEntry lk;
         IGemmParams p{};
         p.in = (const h16_t*)a; p.wt = (const h16_t*)bt; p.bias = bias; p.res = (const h16_t*)residual; p.out = out; p.zero = zero_page();
         p.M = M; p.N = N; p.Cin = K; p.n_rows = n_rows_bt; p.ks = 1; p.stride = 1;
         p.lda = lda; p.ldw = ldb; p.ldo = ldo; p.ldres = ldres; p.n_store = n_store > 0 ? n_store : N; p.out_fp32 = out_fp32; p.act = act;
         p.bias_mode = bias ? bias_mode : GP_BIAS_NONE; p.batch = batch > 0 ? batch : 1; p.in_bs = a_bs; p.wt_bs = bt_bs; p.out_bs = out_bs;
-        if (const char* dbg = getenv("GENPERCEPT_IGEMM_DBG")) p.dbg = atoi(dbg);  // profiling ablations (tools/kbench)
+        p.dbg = gp_sw().igemm_dbg;  // profiling ablations (tools/kbench)
         attach_splitk_scratch(p, tile_hint);
         launch_igemm(p, tile_hint, (hipStream_t)stream);
         HIPCHK(hipGetLastError());
@@ -1873,7 +1880,7 @@ gp_status gp_decoder_tail(const void* in, const void* w_packed, const float* bia
                           int B, int H, int W, int Cin, int mean3, int raw, float* out, void* stream) {
     if (!in || !w_packed || !gamma || !beta || !out || B < 1 || !conv_few_applicable(Cin, 3, H, W) || (Cin % groups)) return GP_ERR_INVALID;
     try {
-        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        KernelEntry lk;
         const size_t need = (size_t)groupnorm_ws_floats(B, H * W, Cin, groups) + 2 * (size_t)B * Cin;
         float* ws = scratch_floats(0, need);
         float* scale = ws + groupnorm_ws_floats(B, H * W, Cin, groups);
@@ -1889,13 +1896,13 @@ gp_status gp_gemm_qkv(const void* a, int lda, const void* w_packed, int ldw, int
                       int Tpad, void* stream) {
     if (!a || !w_packed || !qk_out || !vt_out || (K % 64) || B < 1 || T < 1 || C < 1 || Tpad < T) return GP_ERR_INVALID;
     try {
-        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        KernelEntry lk;
         IGemmParams p{};
         p.in = (const h16_t*)a; p.wt = (const h16_t*)w_packed; p.out = qk_out; p.zero = zero_page();
         p.M = B * T; p.N = 3 * C; p.Cin = K; p.n_rows = n_rows_w; p.ks = 1; p.stride = 1;
         p.lda = lda; p.ldw = ldw; p.ldo = 2 * C; p.ldres = 2 * C; p.n_store = 2 * C; p.act = GP_ACT_NONE; p.bias_mode = GP_BIAS_NONE; p.batch = 1;
         p.vt_out = (h16_t*)vt_out; p.vt_col0 = 2 * C; p.vt_T = T; p.vt_Tpad = Tpad;
-        if (const char* dbg = getenv("GENPERCEPT_IGEMM_DBG")) p.dbg = atoi(dbg);
+        p.dbg = gp_sw().igemm_dbg;
         if (!igemm_uses_pgemm(p, 0)) return GP_ERR_INVALID;  // only the persistent GEMM has the transposed epilogue
         if (Tpad != T) HIPCHK(hipMemsetAsync(vt_out, 0, (size_t)B * C * Tpad * sizeof(h16_t), (hipStream_t)stream));
         launch_igemm(p, 0, (hipStream_t)stream);
@@ -1907,7 +1914,7 @@ gp_status gp_gemm_qkv(const void* a, int lda, const void* w_packed, int ldw, int
 gp_status gp_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int silu, void* stream) {
     if (!x || !y || !gamma || !beta || (C % 8) || (C % G)) return GP_ERR_INVALID;
     try {
-        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        KernelEntry lk;
         const size_t need = (size_t)groupnorm_ws_floats(B, HW, C, G) + 2 * (size_t)B * C;
         float* g_gn_ws = scratch_floats(0, need);
         if (groupnorm_small_applicable(B, HW, C, G)) launch_groupnorm_small((const h16_t*)x, (h16_t*)y, gamma, beta, B, HW, C, G, eps, silu, (hipStream_t)stream);
@@ -1927,7 +1934,7 @@ gp_status gp_flash_attention(const void* q, const void* k, const void* vt, void*
                              void* stream) {
     if (!q || !k || !vt || !out || (Tpad % 64) || Tpad < T) return GP_ERR_INVALID;
     try {
-        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        KernelEntry lk;
         launch_flash_attn64((const h16_t*)q, (const h16_t*)k, (const h16_t*)vt, (h16_t*)out, B, T, heads, ldq, ldk, Tpad, ldo,
                             (hipStream_t)stream);
         HIPCHK(hipGetLastError());
@@ -1939,7 +1946,7 @@ gp_status gp_flash_attention_hd512(const void* q, const void* k, const void* vt,
                                    float scale, int ncu, void* stream) {
     if (!q || !k || !vt || !out || (Tpad % 64) || Tpad < T || B < 1 || T < 1 || ncu < 0) return GP_ERR_INVALID;
     try {
-        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        KernelEntry lk;
         if (ncu == 0) {
             int dev = 0;
             hipDeviceProp_t pr;
@@ -1965,6 +1972,7 @@ gp_status gp_cross_attention(const void* q, const float* kc, const float* vc, vo
 gp_status gp_cross_attention_fold(const void* y, void* y_out, void* n3_out, const float* U, const float* u0, const float* G, const float* c0,
                                   const float* g3, const float* b3, int rows, int C, int heads, float eps, void* stream) {
     if (!y || !y_out || !U || !u0 || !G || !c0 || !cross_attn_fold_supported(C, heads) || (n3_out && (!g3 || !b3))) return GP_ERR_INVALID;
+    gp_switches_reload();
     launch_cross_attn_fold((const h16_t*)y, (h16_t*)y_out, (h16_t*)n3_out, U, u0, G, c0, g3, b3, rows, C, heads, eps, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
 }

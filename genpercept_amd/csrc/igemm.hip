@@ -30,6 +30,45 @@ std::mutex& gp_attr_mutex() {
     return m;
 }
 
+static GpSwitches g_switches = [] {
+    GpSwitches s{};
+    s.gn_fuse_max_slices = s.gn_fuse_below_px = s.vt_tile = s.xfold_lds = -1;
+    s.qkv_fuse_max_rows = 1 << 30;
+    return s;
+}();
+const GpSwitches& gp_sw() { return g_switches; }
+void gp_switches_reload() {
+    auto flag = [](const char* n) { return getenv(n) != nullptr ? 1 : 0; };
+    auto num = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
+    GpSwitches s{};
+    s.flash_ring3 = flag("GENPERCEPT_FLASH_RING3");
+    s.no_flash512 = flag("GENPERCEPT_NO_FLASH512");
+    s.f5_dbg = num("GENPERCEPT_F5_DBG", 0);              // timing ablations only: 1 no K DMA, 2 no V DMA
+    s.no_conv_few = flag("GENPERCEPT_NO_CONV_FEW");
+    s.no_conv_img = flag("GENPERCEPT_NO_CONV_IMG");
+    s.conv_img_s = num("GENPERCEPT_CONV_IMG_S", 0);
+    s.no_cross_fold = flag("GENPERCEPT_NO_CROSS_FOLD");
+    s.no_gn_fusion = flag("GENPERCEPT_NO_GN_FUSION");
+    s.gn_fuse_max_slices = num("GENPERCEPT_GN_FUSE_MAX_SLICES", -1);
+    s.gn_fuse_below_px = num("GENPERCEPT_GN_FUSE_BELOW_PX", -1);
+    s.no_stats_fusion = flag("GENPERCEPT_NO_STATS_FUSION");
+    s.vt_tile = num("GENPERCEPT_VT_TILE", -1);
+    s.no_gn_small = flag("GENPERCEPT_NO_GN_SMALL");
+    s.fp32_scores = flag("GENPERCEPT_FP32_SCORES");
+    s.no_qkv_fuse = flag("GENPERCEPT_NO_QKV_FUSE");
+    s.qkv_fuse_max_rows = num("GENPERCEPT_QKV_FUSE_MAX_ROWS", 1 << 30);
+    s.no_rgb_conv = flag("GENPERCEPT_NO_RGB_CONV");
+    s.igemm_dbg = num("GENPERCEPT_IGEMM_DBG", 0);        // profiling ablations (tools/conv_bench.py, tools/kbench)
+    s.no_splitk = flag("GENPERCEPT_NO_SPLITK");
+    s.no_halo = flag("GENPERCEPT_NO_HALO");              // generic implicit GEMM everywhere
+    s.no_pgemm = flag("GENPERCEPT_NO_PGEMM");
+    s.gn_apply_old = flag("GENPERCEPT_GN_APPLY_OLD");
+    s.xfold_lds = num("GENPERCEPT_XFOLD_LDS", -1);       // 0 = the r2 cross-attention fold kernel
+    s.no_halo4 = flag("GENPERCEPT_NO_HALO4");            // 512-pixel-tile conv off: conv3x3_halo3_kernel everywhere
+    s.no_fin_fuse = flag("GENPERCEPT_NO_FIN_FUSE");      // GroupNorm statistics finalised by their own launch again
+    g_switches = s;
+}
+
 constexpr bool PRIO = true;   // s_setprio around the MFMA cluster made hipcc wait lgkmcnt(0) before the first MFMA
 template <int N>
 GP_DEV void wait_vm_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -279,7 +318,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // number of K slices launch_igemm will use (1 = none): 3x3 convs on tiny maps (M = 576 for 12x12 x 4 images, K = 11520 .. 23040) leave
 // 180 workgroups of 4 waves on 256 CUs with 180+ dependent K-steps each -- 200 TFLOP/s; slicing K fills the machine.
 int igemm_ksplit(const IGemmParams& p, int tile_hint) {
-    static const bool no_split = getenv("GENPERCEPT_NO_SPLITK") != nullptr;
+    const bool no_split = gp_sw().no_splitk;
     if (tile_hint == 0 && !no_split && conv_img_applicable(p)) return conv_img_ksplit(p);  // whole-image tiles (conv_img.hip)
     if (tile_hint != 0 && tile_hint != 2) return 1;
     if (no_split || p.ks != 3 || p.ups || p.batch > 1 || p.out_fp32 || p.act == GP_ACT_GEGLU || p.bias_mode == GP_BIAS_ROW || p.in_scale) return 1;
@@ -320,9 +359,9 @@ static void launch_cfg(const IGemmParams& p, hipStream_t s) {
 //            4 = 256x128 (8 waves, 3-deep ring: the large-problem configuration), 5 = conv_halo.hip, 6 = 128x64 (4 waves, 2-deep)
 // true when launch_igemm(p, hint) hands the problem to conv_halo.hip (the only kernel that fuses IGemmParams::in_scale)
 bool conv_uses_halo(const IGemmParams& p, int tile_hint) {
-    static const bool no_halo = getenv("GENPERCEPT_NO_HALO") != nullptr;  // A/B switch: generic implicit GEMM everywhere
+    const bool no_halo = gp_sw().no_halo;  // A/B switch: generic implicit GEMM everywhere
     if (no_halo && tile_hint != 5) return false;
-    if (tile_hint == 0 && getenv("GENPERCEPT_NO_SPLITK") == nullptr && conv_img_applicable(p)) return false;  // 24x24 / 12x12 maps: conv_img.hip
+    if (tile_hint == 0 && !gp_sw().no_splitk && conv_img_applicable(p)) return false;  // 24x24 / 12x12 maps: conv_img.hip
     if (!(tile_hint == 5 || tile_hint == 0) || !conv_halo_applicable(p)) return false;
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
     const long long tiles = (long long)((p.Wo + 15) / 16) * ((p.Ho + 15) / 16) * p.B * ((ncols + 127) / 128);
@@ -330,7 +369,7 @@ bool conv_uses_halo(const IGemmParams& p, int tile_hint) {
 }
 
 bool igemm_uses_pgemm(const IGemmParams& p, int tile_hint) {
-    static const bool no_pgemm = getenv("GENPERCEPT_NO_PGEMM") != nullptr;  // A/B switch
+    const bool no_pgemm = gp_sw().no_pgemm;  // A/B switch
     if (tile_hint == 7) return pgemm_applicable(p);
     // fewer than 1024 rows (the UNet mid block at 768x768: 4 x 144 tokens): five 128-row tiles per column slice leave the persistent kernel's
     // workgroups one tile each, 64x64 tiles on three workgroups per CU are 20-25 % faster (tools/kbench: 11.6 vs 15.3 us at N = K = 1280,

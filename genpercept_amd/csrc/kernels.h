@@ -55,6 +55,17 @@ struct IGemmParams {
     int vt_col0, vt_T, vt_Tpad;
 };
 
+// A/B and profiling switches (GENPERCEPT_* environment variables).  Read from the environment in ONE place, gp_switches_reload(), which
+// the C-ABI calls when an engine is created / finalised and at the per-kernel test entry points -- never on the launch path: launchers and
+// the engine only read the cached struct (r3 had 27 getenv sites, several per conv launch, some cached per process and some not).
+struct GpSwitches {
+    int flash_ring3, no_flash512, f5_dbg, no_conv_few, no_conv_img, conv_img_s, no_cross_fold, no_gn_fusion, gn_fuse_max_slices,
+        gn_fuse_below_px, no_stats_fusion, vt_tile, no_gn_small, fp32_scores, no_qkv_fuse, qkv_fuse_max_rows, no_rgb_conv, igemm_dbg, no_splitk,
+        no_halo, no_pgemm, gn_apply_old, xfold_lds, no_halo4, no_fin_fuse;
+};
+const GpSwitches& gp_sw();
+void gp_switches_reload();
+
 // tile_hint: 0 auto (halo conv / persistent GEMM / split-K / generic tile by heuristic), 1 = 128x128, 2 = 64x64, 3 = 256x32, 4 = 256x128,
 //            5 = conv_halo.hip, 6 = 128x64, 7 = pgemm.hip
 void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s);

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void gn_apply2_kernel(const h16_t* __restrict_
 }
 
 void launch_groupnorm_apply(const h16_t* x, h16_t* y, const float* scale, const float* shift, int B, int HW, int C, int silu, hipStream_t s) {
-    static const bool old_kernel = getenv("GENPERCEPT_GN_APPLY_OLD") != nullptr;  // A/B switch
+    const bool old_kernel = gp_sw().gn_apply_old;  // A/B switch
     if (old_kernel) {
         const int nchunk = gn_nchunk(HW);
         hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(256), (size_t)2 * C * sizeof(float), s, x, y, scale, shift, HW, C, nchunk, silu);
@@ -643,7 +643,7 @@ bool cross_attn_fold_supported(int C, int heads) {
 template <int VPT, int R, int HEADS>
 static void launch_cross_fold_one(const h16_t* y, h16_t* y_out, h16_t* n3_out, const float* U, const float* u0, const float* G, const float* c0,
                                   const float* g3, const float* b3, int rows, int C, float eps, hipStream_t s) {
-    static const int mode_env = getenv("GENPERCEPT_XFOLD_LDS") ? atoi(getenv("GENPERCEPT_XFOLD_LDS")) : -1;  // A/B switch: 0 = the r2 kernel
+    const int mode_env = gp_sw().xfold_lds;  // A/B switch: 0 = the r2 kernel
     const int blocks = (rows + 4 * R - 1) / (4 * R);
     const size_t tab = (size_t)HEADS * C * 4, vec = (size_t)3 * C * 4;
     int mode = 2 * tab + vec <= 64 * 1024 ? 2 : (tab + vec <= 120 * 1024 ? 1 : 0);  // tables in LDS when >= 2 (mode 2) / 1 (mode 1) workgroups fit a CU

@@ -224,6 +224,7 @@ class GenPerceptPipeline:
         if kw.get("scheduler") is None and os.path.isfile(os.path.join(checkpoint, "scheduler", "scheduler_config.json")):
             from .scheduler import DDIMSchedulerCustomized
             kw["scheduler"] = DDIMSchedulerCustomized.from_pretrained(checkpoint, subfolder="scheduler")
+            logging.info("GenPerceptPipeline.from_pretrained: no scheduler= argument, loaded %s", os.path.join(checkpoint, "scheduler", "scheduler_config.json"))
         # ... and the registered config values (register_to_config, genpercept_pipeline.py:128-132) from model_index.json
         mi = os.path.join(checkpoint, "model_index.json")
         if os.path.isfile(mi):
@@ -335,6 +336,11 @@ class GenPerceptPipeline:
         if t != self._timestep:
             eng.set_timestep(t)
             self._timestep = t
+            # announced once per change: which timestep the one UNet pass runs at and where it came from, and which path follows
+            src = "fix_timesteps" if fix_timesteps else ("scheduler.set_timesteps(1)" if self.scheduler is not None else "no scheduler: the shipped default")
+            path = ("fused one-step path (gp_infer: x0 = -v)" if self.genpercept_pipeline and (self._x0_is_neg_v or self.customized_head is not None)
+                    else "scheduler plan path (gp_infer_steps: DDIM update per step)")
+            logging.info("GenPerceptPipeline: UNet timestep %d (%s); %s", t, src, path)
         return eng
 
     # ---- reference methods -------------------------------------------------------------------------------------------

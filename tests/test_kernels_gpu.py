@@ -78,7 +78,11 @@ CONV_CASES = [
     (4, 12, 12, 1280, 1280, 0), (1, 12, 12, 2560, 1280, 0), (2, 12, 12, 640, 320, 0), (1, 9, 11, 1280, 200, 2),
     # whole-image tiles (conv_img.hip): 24x24 maps (one image per 576-pixel unit) and 12x12 maps (four per unit), K slices of uneven length,
     # one and several units, odd chunk counts; (4, 12, 12, 1280, 1280, 0) above takes this path too
-    (4, 24, 24, 128, 128, 0), (1, 24, 24, 640, 64, 0), (2, 24, 24, 1280, 320, 0), (8, 12, 12, 192, 192, 0), (4, 12, 12, 64, 64, 0), (4, 6, 24, 320, 128, 0),
+    (4, 24, 24, 128, 128, 0), (1, 24, 24, 640, 64, 0), (2, 24, 24, 1280, 320, 0), (8, 12, 12, 192, 192, 0),
+    # ((4, 12, 12, 64, 64) and (4, 6, 24, 320, 128) did not qualify -- one chunk per slice forces S = 1, 4 x 8 x 26 halo rows exceed
+    #  CI_HROWS_MAX -- and fell back to the generic path; kept as fall-back cases, with two shapes that DO reach conv_img: the minimum of two
+    #  chunks per K slice, and a non-square map with two images per unit)
+    (4, 12, 12, 64, 64, 0), (4, 6, 24, 320, 128, 0), (4, 12, 12, 128, 64, 0), (2, 12, 24, 320, 128, 0),
 ]
 
 
