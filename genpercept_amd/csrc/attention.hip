@@ -734,3 +734,5 @@ void launch_softmax_rows_f16(const void* in, h16_t* out, int rows, int T, int ld
     else if (ld <= 9216) hipLaunchKernelGGL((softmax_rows_reg_kernel<9, _Float16>), dim3(rows), dim3(256), 0, s, x, out, T, ld, scale);
     else hipLaunchKernelGGL((softmax_rows_reg_kernel<16, _Float16>), dim3(rows), dim3(256), 0, s, x, out, T, ld, scale);
 }
+
+GP_SAT_TU(attention)  // fp16 build: address of this translation unit's saturation flag (common.h)

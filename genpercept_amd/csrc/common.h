@@ -32,11 +32,35 @@ GP_DEV unsigned pack_h16x2_ns(float lo, float hi) {
     f32x2_t v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2n_t));
 }
-GP_DEV unsigned pack_h16x2(float lo, float hi) { return pack_h16x2_ns(h16_sat(lo), h16_sat(hi)); }
-GP_DEV uint2 pack_h16x4(float a, float b, float c, float d) {
+// Saturation is never silent: a saturating conversion that actually clips sets this TRANSLATION UNIT's flag word (one
+// plain store on the clipping path only); the engine collects the flags of every translation unit into its counter at the end of each call
+// (engine.hip: collect_saturation_kernel; gp_saturation_events / gp_timings.sat_events; the pipeline logs a warning).  Hot epilogues carry
+// the running max |value| of what they pack in a register (sat_track: one v_max3_f32 per pair, no branch) and report once per tile.
+static __device__ unsigned gp_sat_flag;
+GP_DEV float sat_track(float m, float a, float b) { return __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b))); }
+GP_DEV void sat_report(float m) {
+    if (m > 65504.f) *(volatile unsigned*)&gp_sat_flag = 1u;  // (NaN compares false: a NaN stays a NaN in the output, visible by itself)
+}
+GP_DEV unsigned pack_h16x2_t(float lo, float hi, float& m) {  // tracked: the caller reports m
+    m = sat_track(m, lo, hi);
+    return pack_h16x2_ns(h16_sat(lo), h16_sat(hi));
+}
+GP_DEV unsigned pack_h16x2(float lo, float hi) {
+    sat_report(sat_track(0.f, lo, hi));
+    return pack_h16x2_ns(h16_sat(lo), h16_sat(hi));
+}
+GP_DEV uint2 pack_h16x4_t(float a, float b, float c, float d, float& m) {
+    m = sat_track(sat_track(m, a, b), c, d);
     f32x4_t v = {h16_sat(a), h16_sat(b), h16_sat(c), h16_sat(d)};
     return __builtin_bit_cast(uint2, __builtin_convertvector(v, f16x4n_t));
 }
+GP_DEV uint2 pack_h16x4(float a, float b, float c, float d) {
+    float m = 0.f;
+    const uint2 r = pack_h16x4_t(a, b, c, d, m);
+    sat_report(m);
+    return r;
+}
+#define GP_SAT_TU(name) void* gp_sat_flag_addr_##name() { void* q = nullptr; (void)hipGetSymbolAddress(&q, HIP_SYMBOL(gp_sat_flag)); return q; }
 GP_DEV f32x4_t mfma_16x16x32(h16x8_t a, h16x8_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8n_t, a), __builtin_bit_cast(f16x8n_t, b), c, 0, 0, 0);
 }
@@ -60,6 +84,12 @@ GP_DEV uint2 pack_h16x4(float a, float b, float c, float d) {
     f32x4_t v = {a, b, c, d};
     return __builtin_bit_cast(uint2, __builtin_convertvector(v, bf16x4n_t));
 }
+// (bf16 has the fp32 range: the saturation tracking of the fp16 build compiles to nothing)
+GP_DEV float sat_track(float m, float, float) { return m; }
+GP_DEV void sat_report(float) {}
+GP_DEV unsigned pack_h16x2_t(float lo, float hi, float&) { return pack_h16x2(lo, hi); }
+GP_DEV uint2 pack_h16x4_t(float a, float b, float c, float d, float&) { return pack_h16x4(a, b, c, d); }
+#define GP_SAT_TU(name) void* gp_sat_flag_addr_##name() { return nullptr; }
 GP_DEV f32x4_t mfma_16x16x32(h16x8_t a, h16x8_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8n_t, a), __builtin_bit_cast(bf16x8n_t, b), c, 0, 0, 0);
 }
@@ -157,20 +187,24 @@ GP_DEV float wave_sum(float x) {
 // [a0, b0, a2, b2] / [a1, b1, a3, b3]); with both registers holding x their sum is the pairwise total.  Through the BUILTINS, so that the
 // compiler's hazard recognizer owns both sides (the wait states a VALU write needs before a permlane reads it, and whatever the
 // consumer of the result needs): r3 issued them from inline asm with a hand-placed s_nop on the producer side only.
+// (hipcc 7.2 miscompiles the direct form `r[0] + r[1]` of the builtin's result pair -- it emits v_add v1, v1, v1, dropping the second
+//  register, also with distinct operands; seen in the ISA and as 81 failing GPU tests.  An empty asm over the two results pins them.)
+#define GP_PERMLANE_PAIR(OP, x, r0, r1)                                             \
+    const unsigned u_ = __builtin_bit_cast(unsigned, (x));                         \
+    const auto rr_ = __builtin_amdgcn_##OP(u_, u_, false, false);                  \
+    unsigned r0 = rr_[0], r1 = rr_[1];                                              \
+    asm volatile("" : "+v"(r0), "+v"(r1))
 GP_DEV float xor32_sum(float x) {
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    GP_PERMLANE_PAIR(permlane32_swap, x, a, b);
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
 GP_DEV float xor16_sum(float x) {
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    GP_PERMLANE_PAIR(permlane16_swap, x, a, b);
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
 GP_DEV float xor32_max(float x) {
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    GP_PERMLANE_PAIR(permlane32_swap, x, a, b);
+    return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
 }
 // sum over the lanes l' == l (mod SLW), SLW = 4, 8 or 16, valid in lanes 0 .. SLW-1 (every row's first SLW lanes): row_shl inside the rows of 16
 // (lane i += lane i + 8, then + 4), then the two cross-row exchanges.  Replaces `for (off = 32; off >= SLW; off >>= 1) x += __shfl_xor(x, off)`,

@@ -213,3 +213,5 @@ void launch_conv_few(const h16_t* in, const h16_t* wt, const float* bias, const 
     if (silu) hipLaunchKernelGGL(conv_few_kernel<1>, dim3(grid), dim3(512), CF_LDS, s, p);
     else hipLaunchKernelGGL(conv_few_kernel<0>, dim3(grid), dim3(512), CF_LDS, s, p);
 }
+
+GP_SAT_TU(conv_few)  // fp16 build: address of this translation unit's saturation flag (common.h)

@@ -610,6 +610,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
                 }
             }
         float st_s[8], st_q[8];
+        float satm = 0.f;  // fp16 build: max |value| this thread packs in this tile (common.h: sat_track / sat_report)
 #pragma unroll
         for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
 #pragma unroll
@@ -641,8 +642,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
                         }
                     }
                     uint4 pk;
-                    pk.x = pack_h16x2(v[0], v[1]) & tmask[0]; pk.y = pack_h16x2(v[2], v[3]) & tmask[1];
-                    pk.z = pack_h16x2(v[4], v[5]) & tmask[2]; pk.w = pack_h16x2(v[6], v[7]) & tmask[3];
+                    pk.x = pack_h16x2_t(v[0], v[1], satm) & tmask[0]; pk.y = pack_h16x2_t(v[2], v[3], satm) & tmask[1];
+                    pk.z = pack_h16x2_t(v[4], v[5], satm) & tmask[2]; pk.w = pack_h16x2_t(v[6], v[7], satm) & tmask[3];
                     if (!(ABL & 4)) *(uint4*)(outp + m * p.ldo + col) = pk;
                     else asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
                     if (STATS) {
@@ -653,6 +654,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
                 }
             }
         }
+        sat_report(satm);
         if (STATS) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { st_s[e] = slot_sum<8>(st_s[e]); st_q[e] = slot_sum<8>(st_q[e]); }
@@ -960,3 +962,5 @@ void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
     if (p.ups) hipLaunchKernelGGL((conv3x3_halo2_kernel<true>), dim3(tiles), dim3(512), HaloGeom<true>::LDS, s, p);
     else hipLaunchKernelGGL((conv3x3_halo2_kernel<false>), dim3(tiles), dim3(512), HaloGeom<false>::LDS, s, p);
 }
+
+GP_SAT_TU(conv_halo)  // fp16 build: address of this translation unit's saturation flag (common.h)

@@ -484,3 +484,5 @@ void launch_rgb_conv_in(const void* rgb, int is_u8, const h16_t* w27, const floa
     const int tiles = ((W + 15) / 16) * ((H + 15) / 16) * B;
     hipLaunchKernelGGL(rgb_conv_in_kernel, dim3(tiles, (Cout + 127) / 128), dim3(256), 0, s, rgb, is_u8, w27, bias, out, stats, B, H, W, Cout);
 }
+
+GP_SAT_TU(elementwise)  // fp16 build: address of this translation unit's saturation flag (common.h)

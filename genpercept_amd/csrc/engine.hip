@@ -166,6 +166,19 @@ struct VaeAttnW {
 
 }  // namespace
 
+struct SatFlags { unsigned* f[16]; int n; };
+// one lane per translation unit: a set flag becomes one event of the engine's counter and is cleared for the next call
+__global__ void collect_saturation_kernel(SatFlags fl, unsigned* counter) {
+    const int i = threadIdx.x;
+    if (i < fl.n) {
+        const unsigned v = __hip_atomic_load(fl.f[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v) {
+            __hip_atomic_store(fl.f[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(counter, 1u);
+        }
+    }
+}
+
 struct gp_engine {
     gp_config cfg;
     std::string err;
@@ -204,6 +217,12 @@ struct gp_engine {
     float* pq_b_dev = nullptr;
     float* dpt_w_dev = nullptr;  // head.head.4 weight [32]
     float dpt_b = 0.f;
+    // fp16 build: saturating conversions that clipped (common.h: gp_sat_flag per translation unit), collected at the end of every call
+    SatFlags sat_flags{};
+    unsigned* sat_dev = nullptr;          // [1] events since the last reset
+    void collect_saturation() {
+        if (sat_dev && sat_flags.n > 0) hipLaunchKernelGGL(collect_saturation_kernel, dim3(1), dim3(64), 0, st, sat_flags, sat_dev);
+    }
 
     // profiling
     int prof = 0;
@@ -1432,6 +1451,17 @@ gp_status gp_create(const gp_config* cfg, gp_engine** out) {
         hipDeviceProp_t pr;
         HIPCHK(hipGetDeviceProperties(&pr, cfg->device));
         if (pr.multiProcessorCount > 0) e->ncu = pr.multiProcessorCount;
+        {   // saturation flags of every translation unit on THIS device (nullptr in the bf16 build: nothing to collect)
+            void* (*const tus[])() = GP_SAT_TUS;
+            for (auto fn : tus) {
+                void* a = fn();
+                if (a && e->sat_flags.n < 16) e->sat_flags.f[e->sat_flags.n++] = (unsigned*)a;
+            }
+            if (e->sat_flags.n > 0) {
+                HIPCHK(hipMalloc((void**)&e->sat_dev, 2 * sizeof(unsigned)));
+                HIPCHK(hipMemset(e->sat_dev, 0, 2 * sizeof(unsigned)));
+            }
+        }
         for (int i = 0; i < 4; ++i) {
             if (cfg->unet_block_out[i] % 64 || cfg->vae_block_out[i] % 64) throw std::invalid_argument("block_out_channels must be multiples of 64");
             if (cfg->unet_down_attn[i] && cfg->unet_block_out[i] != 64 * cfg->unet_num_heads[i]) throw std::invalid_argument("attention head_dim must be 64");
@@ -1445,6 +1475,7 @@ void gp_destroy(gp_engine* e) {
     hipSetDevice(e->cfg.device);
     hipDeviceSynchronize();
     for (void* p : e->weights_dev) hipFree(p);
+    if (e->sat_dev) hipFree(e->sat_dev);
     e->pool.destroy();
     for (auto& pr : e->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto& m : e->marks) hipEventDestroy(m.ev);
@@ -1508,7 +1539,31 @@ gp_status gp_get_timings(gp_engine* e, gp_timings* out) {
     if (!e || !out) return GP_ERR_INVALID;
     return guard(e, [&] {
         e->collect_profile();
+        e->tm.sat_events = 0;
+        if (e->sat_dev) {
+            unsigned n = 0;
+            HIPCHK(hipStreamSynchronize(e->st));
+            HIPCHK(hipMemcpy(&n, e->sat_dev, sizeof(n), hipMemcpyDeviceToHost));
+            e->tm.sat_events = (long long)n;
+        }
         *out = e->tm;
+    });
+}
+
+/* fp16 library: number of (call, translation unit) pairs in which a saturating fp32 -> fp16 conversion actually clipped since the last reset
+ * (0 = every stored activation was inside the fp16 range: the output is not silently clipped).  Always 0 in the bf16 library.  Synchronises
+ * the engine's stream. */
+gp_status gp_saturation_events(gp_engine* e, long long* events, int reset) {
+    if (!e || !events) return GP_ERR_INVALID;
+    return guard(e, [&] {
+        *events = 0;
+        if (!e->sat_dev) return;
+        HIPCHK(hipSetDevice(e->cfg.device));
+        unsigned n = 0;
+        HIPCHK(hipStreamSynchronize(e->st));
+        HIPCHK(hipMemcpy(&n, e->sat_dev, sizeof(n), hipMemcpyDeviceToHost));
+        *events = (long long)n;
+        if (reset) HIPCHK(hipMemset(e->sat_dev, 0, sizeof(unsigned)));
     });
 }
 
@@ -1602,6 +1657,7 @@ gp_status gp_infer(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, i
             HIPCHK(hipEventElapsedTime(&e->tm.ms_head, e->ev[2], e->ev[3]));
             HIPCHK(hipEventElapsedTime(&e->tm.ms_total, e->ev[0], e->ev[3]));
         }
+        e->collect_saturation();
         HIPCHK(hipGetLastError());
     });
 }
@@ -1668,6 +1724,7 @@ gp_status gp_infer_steps(gp_engine* e, const void* rgb_dev, int is_u8, int B, in
             HIPCHK(hipEventElapsedTime(&e->tm.ms_head, e->ev[2], e->ev[3]));
             HIPCHK(hipEventElapsedTime(&e->tm.ms_total, e->ev[0], e->ev[3]));
         }
+        e->collect_saturation();
         HIPCHK(hipGetLastError());
     });
 }
@@ -1679,6 +1736,7 @@ gp_status gp_vae_encode(gp_engine* e, const void* rgb_dev, int is_u8, int B, int
         Act lat = e->vae_encode(rgb_dev, is_u8, B, H, W);
         e->to_nchw_f32(lat, e->cfg.vae_latent_channels, latent_out);
         e->drop(lat);
+        e->collect_saturation();
         HIPCHK(hipGetLastError());
     });
 }
@@ -1701,6 +1759,7 @@ gp_status gp_unet(gp_engine* e, const float* latent_in, int B, int h, int w, flo
                 if (feats_out[i]) e->to_nchw_f32(feats[i], feats[i].C, feats_out[i]);
                 e->drop(feats[i]);
             }
+        e->collect_saturation();
         HIPCHK(hipGetLastError());
     });
 }
@@ -1718,6 +1777,7 @@ gp_status gp_vae_decode(gp_engine* e, const float* pred_latent, int B, int h, in
             launch_decode_epilogue(dec.p, out, B, h * 8, w * 8, dec.C, mean3, 1, e->st);
             e->drop(dec);
         }
+        e->collect_saturation();
         HIPCHK(hipGetLastError());
     });
 }
@@ -1733,6 +1793,7 @@ gp_status gp_vae_mid_attention(gp_engine* e, int decoder, const float* x, int B,
         e->drop(a);
         e->to_nchw_f32(y, C, out);
         e->drop(y);
+        e->collect_saturation();
         HIPCHK(hipGetLastError());
     });
 }
@@ -1748,6 +1809,7 @@ gp_status gp_dpt_head(gp_engine* e, const float* const* feats, int B, int h, int
         for (int i = 0; i < 4; ++i) f[i] = e->from_nchw_f32(feats[i], B, e->cfg.dpt_neck[i], hs[i], ws[i], e->cfg.dpt_neck[i]);
         e->dpt_head(f, out);
         for (int i = 0; i < 4; ++i) e->drop(f[i]);
+        e->collect_saturation();
         HIPCHK(hipGetLastError());
     });
 }

@@ -52,6 +52,7 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
         static_assert(NTHREADS % SL == 0, "stats: a thread must keep its channel slot");
         const bool want_stats = p.stats_out != nullptr;
         float st_s[8], st_q[8];
+        float satm = 0.f;  // fp16 build: max |value| packed by this thread (sat_report below)
 #pragma unroll
         for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
         for (int idx = threadIdx.x; idx < BM * SL; idx += NTHREADS) {
@@ -82,7 +83,7 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
             }
             h16_t* o = outp + (long long)m * p.ldo + col;
             uint4 pk;
-            pk.x = pack_h16x2(v[0], v[1]); pk.y = pack_h16x2(v[2], v[3]); pk.z = pack_h16x2(v[4], v[5]); pk.w = pack_h16x2(v[6], v[7]);
+            pk.x = pack_h16x2_t(v[0], v[1], satm); pk.y = pack_h16x2_t(v[2], v[3], satm); pk.z = pack_h16x2_t(v[4], v[5], satm); pk.w = pack_h16x2_t(v[6], v[7], satm);
             if (col + 7 < p.n_store) {
                 *(uint4*)o = pk;
             } else {
@@ -96,6 +97,7 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
                 for (int e = 0; e < 8; ++e) { st_s[e] += r[e]; st_q[e] += r[e] * r[e]; }
             }
         }
+        sat_report(satm);
         if (want_stats) {
             // deterministic tree: lanes of a wave sharing a slot (xor-shuffles), then the waves through LDS (the staging area is
             // free once everybody has left the store loop), then one thread per channel writes this tile's partial

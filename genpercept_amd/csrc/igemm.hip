@@ -461,3 +461,5 @@ void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s) {
     else if (cfg == 6) launch_cfg<128, 64, 2, 2, 2>(p, s);   // 48 KiB of LDS -> 3 workgroups per CU
     else launch_cfg<256, 128, 4, 2, 3>(p, s);
 }
+
+GP_SAT_TU(igemm)  // fp16 build: address of this translation unit's saturation flag (common.h)

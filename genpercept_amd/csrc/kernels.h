@@ -66,6 +66,16 @@ struct GpSwitches {
 const GpSwitches& gp_sw();
 void gp_switches_reload();
 
+// fp16 build: device address of each translation unit's saturation flag word (nullptr in the bf16 build); engine.hip collects them
+void* gp_sat_flag_addr_igemm();
+void* gp_sat_flag_addr_conv_halo();
+void* gp_sat_flag_addr_pgemm();
+void* gp_sat_flag_addr_conv_few();
+void* gp_sat_flag_addr_norm();
+void* gp_sat_flag_addr_attention();
+void* gp_sat_flag_addr_elementwise();
+#define GP_SAT_TUS {gp_sat_flag_addr_igemm, gp_sat_flag_addr_conv_halo, gp_sat_flag_addr_pgemm, gp_sat_flag_addr_conv_few, gp_sat_flag_addr_norm, gp_sat_flag_addr_attention, gp_sat_flag_addr_elementwise}
+
 // tile_hint: 0 auto (halo conv / persistent GEMM / split-K / generic tile by heuristic), 1 = 128x128, 2 = 64x64, 3 = 256x32, 4 = 256x128,
 //            5 = conv_halo.hip, 6 = 128x64, 7 = pgemm.hip
 void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s);

@@ -698,3 +698,5 @@ void launch_cross_attn_fold(const h16_t* y, h16_t* y_out, h16_t* n3_out, const f
     }
 #undef GP_CF
 }
+
+GP_SAT_TU(norm)  // fp16 build: address of this translation unit's saturation flag (common.h)

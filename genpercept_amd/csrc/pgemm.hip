@@ -207,6 +207,7 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
             bv[ip][1] = *(lds_f4_ptr)(bias_base + (wn * TN + 32 * ip + 8 * q) * 4 + 16);
         }
         float st_s[8], st_q[8];
+        float satm = 0.f;  // fp16 build: max |value| this thread packs in this tile (common.h: sat_track / sat_report)
 #pragma unroll
         for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.f;
 #pragma unroll
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
                             if (col + e >= n_out) v[e] = 0.f;
                     }
                     uint4 pk;
-                    pk.x = pack_h16x2(v[0], v[1]); pk.y = pack_h16x2(v[2], v[3]); pk.z = pack_h16x2(v[4], v[5]); pk.w = pack_h16x2(v[6], v[7]);
+                    pk.x = pack_h16x2_t(v[0], v[1], satm); pk.y = pack_h16x2_t(v[2], v[3], satm); pk.z = pack_h16x2_t(v[4], v[5], satm); pk.w = pack_h16x2_t(v[6], v[7], satm);
                     if (!(ABL & 4)) *(uint4*)(outp + m * p.ldo + col) = pk;
                     else asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
                     if (STATS) {
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
                 }
             }
         }
+        sat_report(satm);
         if (STATS) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { st_s[e] = slot_sum<SLW>(st_s[e]); st_q[e] = slot_sum<SLW>(st_q[e]); }
@@ -286,6 +288,7 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
         const int n_half = p.N >> 1;
         h16_t* outp = (h16_t*)p.out;
         const unsigned win = smem_base + S * STAGE + wave * 1024;
+        float satm = 0.f;
 #pragma unroll
         for (int ip = 0; ip < FP; ++ip) {
             const f32x4_t bl = *(lds_f4_ptr)(bias_base + (wn * TN + 32 * ip + 8 * q) * 4);
@@ -298,12 +301,13 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (col + r >= n_half) v[r] = 0.f;
-                const uint2 pk = pack_h16x4(v[0], v[1], v[2], v[3]);
+                const uint2 pk = pack_h16x4_t(v[0], v[1], v[2], v[3], satm);
                 const int r16 = 16 * j + a;    // staged row; 8-byte slot ip * 4 + q, XORed with an even key of the row (2-way on ds_write_b64 at most)
                 const unsigned d = win + (r16 / RPP) * 8192 + (r16 % RPP) * RB + (((ip * 4 + q) ^ (((r16 >> 1) & (UPR - 1)) << 1)) << 3);
                 asm volatile("ds_write_b64 %0, %1" ::"v"(d), "v"(pk) : "memory");
             }
         }
+        sat_report(satm);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int t = 0; t < NIT; ++t) {
@@ -331,6 +335,7 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
         const int q = lane_o >> 4, a = lane_o & 15;
         const unsigned win = smem_base + S * STAGE + wave * 1024;
         const int nv = p.N - p.vt_col0;       // channels of V
+        float satm = 0.f;
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
 #pragma unroll
@@ -354,13 +359,14 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
                 if (m < p.M && ch < nv) {
                     const int b = m / p.vt_T, tt = m - b * p.vt_T;
                     uint4 pk;
-                    pk.x = pack_h16x2(v[0], v[1]); pk.y = pack_h16x2(v[2], v[3]); pk.z = pack_h16x2(v[4], v[5]); pk.w = pack_h16x2(v[6], v[7]);
+                    pk.x = pack_h16x2_t(v[0], v[1], satm); pk.y = pack_h16x2_t(v[2], v[3], satm); pk.z = pack_h16x2_t(v[4], v[5], satm); pk.w = pack_h16x2_t(v[6], v[7], satm);
                     if (!(ABL & 4)) *(uint4*)(p.vt_out + ((long long)b * nv + ch) * p.vt_Tpad + tt) = pk;
                     else asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the next pass overwrites the window)
         }
+        sat_report(satm);
     };
     const bool vt_slice = p.vt_out != nullptr && n0 >= p.vt_col0;  // workgroup-uniform
     const int ep_variant = vt_slice ? 16 : p.act == GP_ACT_GEGLU ? 8 : (p.act != GP_ACT_NONE ? 4 : 0) | (p.res ? 2 : 0) | (want_stats ? 1 : 0);
@@ -520,3 +526,5 @@ void launch_pgemm(const IGemmParams& p, hipStream_t s) {
         else launch_pgemm_one<128, 0>(p, ncu, s);
     }
 }
+
+GP_SAT_TU(pgemm)  // fp16 build: address of this translation unit's saturation flag (common.h)

@@ -66,7 +66,7 @@ class GpTimings(C.Structure):
         ("flops_igemm", C.c_double), ("flops_attn", C.c_double),
         ("ms_igemm", C.c_float), ("ms_attn", C.c_float),
         ("n_igemm", C.c_int), ("n_attn", C.c_int), ("n_launches", C.c_int),
-        ("flops_halo", C.c_double), ("ms_halo", C.c_float), ("n_halo", C.c_int),
+        ("flops_halo", C.c_double), ("ms_halo", C.c_float), ("n_halo", C.c_int), ("sat_events", C.c_longlong),
     ]
 
 
@@ -100,6 +100,7 @@ SYMBOLS = {
     "gp_set_profile": (_i, [_vp, _i]),
     "gp_get_timings": (_i, [_vp, C.POINTER(GpTimings)]),
     "gp_reset_timings": (_i, [_vp]),
+    "gp_saturation_events": (_i, [_vp, C.POINTER(C.c_longlong), _i]),
     "gp_get_launch_log": (_i, [_vp, C.c_char_p, _i]),
     "gp_packed_rows": (_i, [_i]),
     "gp_latent_size": (_i, [_i]),
@@ -358,6 +359,13 @@ class Engine:
         t = GpTimings()
         self._check(self.lib.gp_get_timings(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in GpTimings._fields_}
+
+    def saturation_events(self, reset: bool = False) -> int:
+        """fp16 library: (call, kernel file) pairs since the last reset in which a saturating fp32 -> fp16 conversion actually clipped
+        (`gp_saturation_events`); 0 = nothing left the fp16 range.  Always 0 for the bf16 library.  Synchronises the engine's stream."""
+        n = C.c_longlong(0)
+        self._check(self.lib.gp_saturation_events(self._h, C.byref(n), 1 if reset else 0))
+        return int(n.value)
 
 
 def _up(x: int, levels: int, ups: int) -> int:

@@ -198,6 +198,7 @@ class GenPerceptPipeline:
         self._timestep = None
         self._device = torch.device("cuda", 0) if device is None else torch.device(device if not isinstance(device, int) else f"cuda:{device}")
         self.mode = None
+        self.last_saturation_events = 0  # fp16 engine: saturation events of the last __call__ (see _warn_if_saturated)
 
     # ---- diffusers-like conveniences ---------------------------------------------------------------------------------
     @classmethod
@@ -426,6 +427,19 @@ class GenPerceptPipeline:
         if n_step < 10:
             logging.warning(f"Too few denoising steps: {n_step}. Recommended to use the LCM checkpoint for few-step inference.")
 
+    def _warn_if_saturated(self):
+        """fp16 engine only: saturation is never silent.  The reference's own half precision (run.py --half_precision) turns an activation
+        beyond 65504 into inf / NaN; this engine clips it and COUNTS the call (`gp_saturation_events`): the map just produced is then not the
+        fp32 path's map, and the caller is told so."""
+        eng = self._engine
+        if eng is None or eng.precision != "fp16":
+            return
+        n = eng.saturation_events(reset=True)
+        self.last_saturation_events = n
+        if n:
+            logging.warning("GenPerceptPipeline: %d kernel group(s) of the last call clipped activations at the fp16 range (+-65504): the result "
+                            "deviates from the fp32 path.  Use torch_dtype=torch.bfloat16 (fp32 range) for this checkpoint / input.", n)
+
     def _predict(self, x: torch.Tensor, fix_timesteps, prompt, opts: Optional[dict]) -> torch.Tensor:
         """The batched prediction + test-time ensembling of __call__ (genpercept_pipeline.py:250-297), per image of `x`."""
         o = opts or {}
@@ -476,6 +490,7 @@ class GenPerceptPipeline:
         if processing_res > 0:
             x = ge.preprocess(x, ge.resize_max_res_size(int(input_size[-2]), int(input_size[-1]), int(processing_res)), resample)
         pred = self._predict(x, fix_timesteps, prompt, opts)
+        self._warn_if_saturated()
         size = tuple(int(v) for v in input_size[-2:]) if match_input_res else tuple(pred.shape[-2:])
         one_ch = pred.shape[1] == 1
         pred_out, col, q8 = ge.postprocess(pred, size, resample, cmap=color_map if one_ch else None, q_bits=0 if color_map is not None else 8)
@@ -508,6 +523,7 @@ class GenPerceptPipeline:
             rgb_in = rgb.float() / 255.0 * 2.0 - 1.0
             assert rgb_in.min() >= -1.0 and rgb_in.max() <= 1.0
         pred = self._predict(rgb_in, fix_timesteps, prompt, opts)
+        self._warn_if_saturated()
         if match_input_res:
             pred = resize_to(pred, input_size[-2:], resample)
         pred = pred.cpu().numpy().clip(0, 1)

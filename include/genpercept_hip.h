@@ -76,6 +76,7 @@ typedef struct gp_timings {
     double flops_halo;                             /* the dominant kernel alone: conv3x3_halo3_kernel (a subset of the igemm figures) */
     float ms_halo;
     int n_halo;
+    long long sat_events;                          /* fp16 library: see gp_saturation_events (same counter, not reset by reading it here) */
 } gp_timings;
 
 void gp_default_config(gp_config* cfg);                                  /* SD2.1 values */
@@ -134,6 +135,11 @@ gp_status gp_dpt_head(gp_engine* e, const float* const* feats /* reversed multi_
 /* Profiling: level 0 off, 1 per-stage hipEvents, 2 additionally per-launch events on the MFMA kernels. */
 gp_status gp_set_profile(gp_engine* e, int level);
 gp_status gp_get_timings(gp_engine* e, gp_timings* out);
+/* Saturation is never silent in the fp16 library (libgenpercept_hip_f16.so; the reference's --half_precision, run.py:273-281, overflows to
+ * inf / NaN on the same activations): conversions saturate at +-65504, and every call in which one actually clipped is counted here --
+ * events = (call, kernel file) pairs since the last reset; 0 means no stored activation left the fp16 range.  The bf16 library (fp32
+ * range) always reports 0.  Synchronises the engine's stream.  The Python pipeline logs a warning when a call raised events. */
+gp_status gp_saturation_events(gp_engine* e, long long* events, int reset);
 gp_status gp_reset_timings(gp_engine* e);
 /* Profiling level 3: text log of the last gp_infer, one line "ms<TAB>algorithmic flops<TAB>description" per kernel launch
  * (ms = start-to-next-start on the stream: kernel time plus the gap behind it).  Returns the bytes needed (incl. NUL). */
