@@ -936,18 +936,38 @@ static bool halo_persistent(const IGemmParams& p) {
     const bool slots_ok = (p.n_store & 7) == 0 && (p.ldo & 7) == 0 && (!p.res || ((p.ldres & 7) == 0 && p.ldres >= p.n_store));
     return slots_ok && !(p.dbg & 256);
 }
+// Which persistent kernel takes this problem, and with how many workgroups per image (a multiple of tiles_n): conv3x3_halo4_kernel (32 x 16
+// tiles, conv_halo4.hip) where it applies and fills the grid as well as the 16 x 16 tiling, else conv3x3_halo3_kernel.  One function for the
+// launch AND for the statistics-row count the engine allocates.  p.dbg bits 20-21 (kbench / tests): 1 forces halo4 where it applies, 2 forbids it.
+static int halo_plan(const IGemmParams& p, bool* use4) {
+    const int ncols = p.N > p.n_store ? p.N : p.n_store;
+    const int tiles_n = (ncols + 127) / 128;
+    int J = halo3_wgs_per_image(p, halo_ncu());
+    const int h4 = (p.dbg >> 20) & 3;
+    *use4 = false;
+    if (h4 != 2 && conv_halo4_applicable(p)) {
+        const int t4 = ((p.Wo + 31) / 32) * ((p.Ho + 15) / 16);
+        if (h4 == 1) {
+            *use4 = true;
+            if (J > t4 * tiles_n) J = t4 * tiles_n;  // (every workgroup needs at least one tile)
+        } else if (conv_halo4_preferred(p, J)) {
+            *use4 = true;
+        }
+    }
+    return J;
+}
 // statistics rows per image the halo kernel will write for this problem (per-workgroup partials + counts, "mode 2"); 0 = one row per
 // 16x16 tile ("mode 1", conv3x3_halo2_kernel)
 int conv_halo_stat_rows(const IGemmParams& p) {
     if (!halo_persistent(p)) return 0;
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
-    return halo3_wgs_per_image(p, halo_ncu()) / ((ncols + 127) / 128);
+    bool use4;
+    return halo_plan(p, &use4) / ((ncols + 127) / 128);
 }
 
 void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
     const int tiles_n = (ncols + 127) / 128, tiles_sp = ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
-    const int ncu = halo_ncu();
     static unsigned long long attr_mask = 0;
     gp_once_per_device(&attr_mask, [&] {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<false>::LDS);
@@ -955,7 +975,10 @@ void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
     });
     // (conv_halo_applicable guarantees whole 128-row weight tiles)
     if (halo_persistent(p)) {
-        launch_halo3(p, p.B * halo3_wgs_per_image(p, ncu), s);
+        bool use4;
+        const int J = halo_plan(p, &use4);
+        if (use4) launch_conv_halo4(p, p.B * J, s);
+        else launch_halo3(p, p.B * J, s);
         return;
     }
     const int tiles = tiles_sp * p.B * tiles_n;

@@ -74,7 +74,8 @@ void* gp_sat_flag_addr_conv_few();
 void* gp_sat_flag_addr_norm();
 void* gp_sat_flag_addr_attention();
 void* gp_sat_flag_addr_elementwise();
-#define GP_SAT_TUS {gp_sat_flag_addr_igemm, gp_sat_flag_addr_conv_halo, gp_sat_flag_addr_pgemm, gp_sat_flag_addr_conv_few, gp_sat_flag_addr_norm, gp_sat_flag_addr_attention, gp_sat_flag_addr_elementwise}
+void* gp_sat_flag_addr_conv_halo4();
+#define GP_SAT_TUS {gp_sat_flag_addr_igemm, gp_sat_flag_addr_conv_halo, gp_sat_flag_addr_pgemm, gp_sat_flag_addr_conv_few, gp_sat_flag_addr_norm, gp_sat_flag_addr_attention, gp_sat_flag_addr_elementwise, gp_sat_flag_addr_conv_halo4}
 
 // tile_hint: 0 auto (halo conv / persistent GEMM / split-K / generic tile by heuristic), 1 = 128x128, 2 = 64x64, 3 = 256x32, 4 = 256x128,
 //            5 = conv_halo.hip, 6 = 128x64, 7 = pgemm.hip
@@ -105,6 +106,10 @@ bool conv_halo_applicable(const IGemmParams& p);   // includes the Cin <= 2560 l
 void launch_conv_halo(const IGemmParams& p, hipStream_t s);
 bool conv_uses_halo(const IGemmParams& p, int tile_hint);
 int conv_halo_stat_rows(const IGemmParams& p);     // > 0: statistics rows per image (per-workgroup partials + pixel counts, mode 2)
+// conv_halo4.hip: the same convs on 32 x 16-pixel tiles (plain input, no activation); chosen inside launch_conv_halo
+bool conv_halo4_applicable(const IGemmParams& p);
+bool conv_halo4_preferred(const IGemmParams& p, int wgs_per_image);
+void launch_conv_halo4(const IGemmParams& p, int grid, hipStream_t s);
 // Statistics layout launch_igemm(p, tile_hint) will write: mode 0 = rows of BM consecutive pixels, mode 1 = 16x16 halo tiles per image,
 // mode 2 = *bm rows per image, each with its own pixel count appended after the [rows][N][2] sums; returns the number of rows (callers
 // allocate rows * (2 N + 1) floats), or 0 when that kernel path cannot produce stats_out (direct epilogue, GEGLU, fp32 output, ...).

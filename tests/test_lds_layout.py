@@ -126,3 +126,42 @@ def test_hd512_attention_tiles_are_conflict_free():
     for hh in (0, 1):
         for r in range(16):
             assert pi((r & 3) + 4 * hh + 8 * (r >> 2)) == 8 * hh + (r & 7) + 16 * (r >> 3)
+
+
+# ds_write_b128: served in contiguous groups of 8 lanes; bank = (a / 4) % 32, i.e. a 128-byte bank row of eight 16-byte units
+def write_conflicts(addr16_of_lane):
+    extra = 0
+    for g0 in range(0, 64, 8):
+        by_bank = {}
+        for lane in range(g0, g0 + 8):
+            a = addr16_of_lane(lane)
+            by_bank.setdefault(a % 8, set()).add(a)
+        extra += sum(len(v) - 1 for v in by_bank.values())
+    return extra
+
+
+def test_conv_halo4_layouts_are_conflict_free():
+    """conv_halo4.hip: 64-byte LDS rows (four 16-byte slots) read by the 32x32x16 MFMA (lane = row l & 31, k-half l >> 5)."""
+    s = src("conv_halo4.hip")
+    assert "GP_DEV int h4_key(int hx) { return (hx >> 2) & 3; }" in s
+    assert "GP_DEV int h4_stg_key(int px) { return ((px >> 1) & 3) | ((px & 1) << 2); }" in s
+    key = lambda hx: (hx >> 2) & 3  # noqa: E731
+    # halo: LDS row = hy * 34 + hx, hx = (l & 31) + kx, logical slot 2 kk + (l >> 5)
+    for hy in range(18):
+        for kx in range(3):
+            for kk in (0, 1):
+                assert conflicts(lambda l: (hy * 34 + (l & 31) + kx) * 4 + ((2 * kk + (l >> 5)) ^ key((l & 31) + kx))) == 0, (hy, kx, kk)
+    # (an unswizzled 64-byte-row image would be 4-way: the reason the key exists)
+    assert conflicts(lambda l: ((l & 31)) * 4 + (l >> 5)) > 0
+    # weight tile: 32-row blocks at multiples of 32 rows, key of the row
+    for base in range(0, 128, 32):
+        for kk in (0, 1):
+            assert conflicts(lambda l: (base + (l & 31)) * 4 + ((2 * kk + (l >> 5)) ^ key(base + (l & 31)))) == 0
+    # epilogue staging block [32 px][8 units]: accumulator writes (lane = pixel l & 31, unit 2 g + (l >> 5)) and the row read-back
+    # (lane = pixel (l >> 2) (+ 16), units 2 (l & 3) and 2 (l & 3) + 1)
+    f = lambda px: ((px >> 1) & 3) | ((px & 1) << 2)  # noqa: E731
+    for g in range(4):
+        assert write_conflicts(lambda l: (l & 31) * 8 + ((2 * g + (l >> 5)) ^ f(l & 31))) == 0
+    for add in (0, 16):
+        for h in (0, 1):
+            assert conflicts(lambda l: ((l >> 2) + add) * 8 + ((2 * (l & 3) + h) ^ f((l >> 2) + add))) == 0
