@@ -49,6 +49,7 @@ GP_DEV int h4_lane_now() {
 GP_DEV int h4_key(int hx) { return (hx >> 2) & 3; }
 GP_DEV int h4_stg_key(int px) { return ((px >> 1) & 3) | ((px & 1) << 2); }
 
+template <bool X3>
 __global__ __launch_bounds__(512) void conv3x3_halo4_kernel(const IGemmParams p) {
     constexpr int BN = 128, NW = 8, A_IT = H4_A_IT, A_BUF = H4_A_BUF, B_STAGE = H4_B_STAGE, HW_ = H4_HW, B_IT = 1;
     constexpr int FC = 2, FJ = 4;  // accumulator tiles per wave: 2 blocks of 32 channels x 4 pixel rows
@@ -345,12 +346,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo4_kernel(const IGemmParams p)
     stage_w(1, w_step);
     stage_w(2, w_step);
     WHalf w0, w1a, w1b;  // w0: k-half 0 of the current step; w1a / w1b ping-pong: k-half 1 of the current / next step
-    XHalf x0, x1;        // pixel fragments of k-half 0 / 1 of the current step (x1 is read during the step's first MFMA batch)
+    XHalf x0, x1;        // pixel fragments of k-half 0 / 1 of the current step (X3 = false: x1 is read during the step's first MFMA batch)
+    XHalf x1b;           // X3: x1 / x1b ping-pong like w1a / w1b (k-half 1 of the current / next step), a full step ahead
     wait_vm<B_IT>();     // halo 0 and the tiles of taps 0, 1 have landed
     __builtin_amdgcn_s_barrier();
     load_w(w0, IC<0>{}, IC<0>{});
     load_w(w1a, IC<0>{}, IC<1>{});
     load_x(x0, IC<0>{}, IC<0>{}, IC<0>{});
+    if constexpr (X3) load_x(x1, IC<0>{}, IC<0>{}, IC<1>{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everybody holds its step-0 fragments: ring slot 0 may be refilled (3-deep ring)
 
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo4_kernel(const IGemmParams p)
     int cc = 0;
     bool tile_end = cpt == 1;                                    // this chunk is the last of its tile
     bool final_ = tile_end && sp_cur + sp_stride >= tiles_sp;    // ... and of the workgroup
-    auto kstep = [&](auto tapc, auto parc, WHalf& cur1, WHalf& nxt1) __attribute__((always_inline)) {
+    auto kstep = [&](auto tapc, auto parc, WHalf& cur1, WHalf& nxt1, XHalf& xcur1, XHalf& xnxt1) __attribute__((always_inline)) {
         constexpr int TAP = decltype(tapc)::value, PAR = decltype(parc)::value;
         constexpr int TAP1 = (TAP + 1) % 9, PAR1 = TAP == 8 ? PAR ^ 1 : PAR;
         const bool issue_w = !(final_ && TAP >= 6), issue_h = TAP == 0 && !final_;
@@ -376,21 +379,22 @@ __global__ __launch_bounds__(512) void conv3x3_halo4_kernel(const IGemmParams p)
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (TAP < 8) {
-            load_x(x1, IC<TAP>{}, IC<PAR>{}, IC<1>{});
+            if constexpr (X3) load_x(xnxt1, IC<TAP1>{}, IC<PAR1>{}, IC<1>{});
+            else load_x(xcur1, IC<TAP>{}, IC<PAR>{}, IC<1>{});
             load_w(nxt1, IC<TAP1>{}, IC<1>{});
             mfma8(w0, x0);
             interleave(6);
             __builtin_amdgcn_sched_barrier(0);
             load_x(x0, IC<TAP1>{}, IC<PAR1>{}, IC<0>{});
             load_w(w0, IC<TAP1>{}, IC<0>{});
-            mfma8(cur1, x1);
+            mfma8(cur1, xcur1);
             interleave(6);
         } else {
-            load_x(x1, IC<TAP>{}, IC<PAR>{}, IC<1>{});
+            if constexpr (!X3) load_x(xcur1, IC<TAP>{}, IC<PAR>{}, IC<1>{});
             mfma8(w0, x0);
-            interleave(4);
+            if constexpr (!X3) interleave(4);
             __builtin_amdgcn_sched_barrier(0);
-            mfma8(cur1, x1);
+            mfma8(cur1, xcur1);
             __builtin_amdgcn_sched_barrier(0);
             if (tile_end) {
                 wait_vm<0>();  // everything this wave has in flight has landed: stores issued below cannot delay a certification
@@ -400,6 +404,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo4_kernel(const IGemmParams p)
                 load_x(x0, IC<TAP1>{}, IC<PAR1>{}, IC<0>{});
                 load_w(w0, IC<TAP1>{}, IC<0>{});
                 load_w(nxt1, IC<TAP1>{}, IC<1>{});
+                if constexpr (X3) load_x(xnxt1, IC<TAP1>{}, IC<PAR1>{}, IC<1>{});
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -417,11 +422,16 @@ __global__ __launch_bounds__(512) void conv3x3_halo4_kernel(const IGemmParams p)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // next step's fragments are in registers
         __builtin_amdgcn_s_barrier();
     };
-    auto chunk = [&](auto parc, WHalf& fa, WHalf& fb) __attribute__((always_inline)) {
+    auto chunk = [&](auto parc, WHalf& fa, WHalf& fb, XHalf& xa, XHalf& xb2) __attribute__((always_inline)) {
         if (tile_end && !final_) setup_fetch(sp_cur + sp_stride);  // from here on halo staging belongs to the next tile
-        kstep(IC<0>{}, parc, fa, fb); kstep(IC<1>{}, parc, fb, fa); kstep(IC<2>{}, parc, fa, fb);
-        kstep(IC<3>{}, parc, fb, fa); kstep(IC<4>{}, parc, fa, fb); kstep(IC<5>{}, parc, fb, fa);
-        kstep(IC<6>{}, parc, fa, fb); kstep(IC<7>{}, parc, fb, fa); kstep(IC<8>{}, parc, fa, fb);
+        // (X3 = false: both pixel k-half-1 references name the same register set)
+        auto step = [&](auto tapc, WHalf& c1, WHalf& n1, XHalf& xc, XHalf& xn) __attribute__((always_inline)) {
+            if constexpr (X3) kstep(tapc, parc, c1, n1, xc, xn);
+            else kstep(tapc, parc, c1, n1, x1, x1);
+        };
+        step(IC<0>{}, fa, fb, xa, xb2); step(IC<1>{}, fb, fa, xb2, xa); step(IC<2>{}, fa, fb, xa, xb2);
+        step(IC<3>{}, fb, fa, xb2, xa); step(IC<4>{}, fa, fb, xa, xb2); step(IC<5>{}, fb, fa, xb2, xa);
+        step(IC<6>{}, fa, fb, xa, xb2); step(IC<7>{}, fb, fa, xb2, xa); step(IC<8>{}, fa, fb, xa, xb2);
         if (tile_end) {
             if (want_stats) {
                 if (final_) __syncthreads();  // (nothing in flight any more)
@@ -437,9 +447,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo4_kernel(const IGemmParams p)
         final_ = tile_end && sp_cur + sp_stride >= tiles_sp;
     };
     while (true) {
-        chunk(IC<0>{}, w1a, w1b);
+        chunk(IC<0>{}, w1a, w1b, x1, x1b);
         if (sp_cur >= tiles_sp) break;
-        chunk(IC<1>{}, w1b, w1a);
+        chunk(IC<1>{}, w1b, w1a, x1b, x1);
         if (sp_cur >= tiles_sp) break;
     }
 }
@@ -455,6 +465,7 @@ bool conv_halo4_applicable(const IGemmParams& p) {
 // Does the 32 x 16 tiling fill a persistent grid of J workgroups per image at least as well as the 16 x 16 tiling (within `slack`)?
 // The per-tile speed advantage (~10 %, kbench) is lost when the last round of tiles is mostly empty (96 x 96 maps: 18 tiles on 16 slots).
 bool conv_halo4_preferred(const IGemmParams& p, int J) {
+    if (!gp_sw().halo4_auto) return false;
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
     const int tiles_n = (ncols + 127) / 128;
     const int slots = J / tiles_n;
@@ -468,9 +479,11 @@ bool conv_halo4_preferred(const IGemmParams& p, int J) {
 void launch_conv_halo4(const IGemmParams& p, int grid, hipStream_t s) {
     static unsigned long long attr_mask = 0;
     gp_once_per_device(&attr_mask, [&] {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H4_LDS);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, H4_LDS);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, H4_LDS);
     });
-    hipLaunchKernelGGL(conv3x3_halo4_kernel, dim3(grid), dim3(512), H4_LDS, s, p);
+    if ((p.dbg >> 22) & 1) hipLaunchKernelGGL(conv3x3_halo4_kernel<true>, dim3(grid), dim3(512), H4_LDS, s, p);   // A/B: three pixel-fragment sets
+    else hipLaunchKernelGGL(conv3x3_halo4_kernel<false>, dim3(grid), dim3(512), H4_LDS, s, p);
 }
 
 GP_SAT_TU(conv_halo4)  // fp16 build: address of this translation unit's saturation flag (common.h)
