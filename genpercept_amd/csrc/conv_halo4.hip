@@ -379,16 +379,31 @@ __global__ __launch_bounds__(512) void conv3x3_halo4_kernel(const IGemmParams p)
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (TAP < 8) {
-            if constexpr (X3) load_x(xnxt1, IC<TAP1>{}, IC<PAR1>{}, IC<1>{});
-            else load_x(xcur1, IC<TAP>{}, IC<PAR>{}, IC<1>{});
-            load_w(nxt1, IC<TAP1>{}, IC<1>{});
-            mfma8(w0, x0);
-            interleave(6);
+            // first batch: only the four pixel fragments the SECOND batch needs, requested between its first MFMAs (four MFMAs of cover before
+            // they are used); everything for the next step -- eight fragments -- goes under the second batch and is waited for at the barrier
+            if constexpr (X3) {
+                load_x(xnxt1, IC<TAP1>{}, IC<PAR1>{}, IC<1>{});
+                load_w(nxt1, IC<TAP1>{}, IC<1>{});
+                mfma8(w0, x0);
+                interleave(6);
+            } else {
+                load_x(xcur1, IC<TAP>{}, IC<PAR>{}, IC<1>{});
+                mfma8(w0, x0);
+                interleave(4);
+            }
             __builtin_amdgcn_sched_barrier(0);
             load_x(x0, IC<TAP1>{}, IC<PAR1>{}, IC<0>{});
             load_w(w0, IC<TAP1>{}, IC<0>{});
+            if constexpr (!X3) load_w(nxt1, IC<TAP1>{}, IC<1>{});
             mfma8(cur1, xcur1);
-            interleave(6);
+            if constexpr (X3) interleave(6);
+            else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
         } else {
             if constexpr (!X3) load_x(xcur1, IC<TAP>{}, IC<PAR>{}, IC<1>{});
             mfma8(w0, x0);
