@@ -233,6 +233,7 @@ def main(argv=None, engine_factory=None, device=None):
         tm = eng.timings()
         eng.set_profile(0)
         peak_meas = ge.mfma_peak_tflops(local_rank, args.precision) if rank == 0 else None
+        peak_meas16 = ge.mfma_peak_tflops_shape(local_rank, 1, args.precision) if rank == 0 else None  # the dominant kernel's own MFMA shape
         scale = (args.res / 768.0) ** 2 * ((TFLOP_PER_IMAGE_768_DPT / TFLOP_PER_IMAGE_768) if dpt else 1.0)
         if tm["ms_halo"] > 0:
             ach = tm["flops_halo"] / (tm["ms_halo"] * 1e-3) / 1e12
@@ -256,6 +257,7 @@ def main(argv=None, engine_factory=None, device=None):
                         "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                         "peak_measured": round(peak_meas, 1) if peak_meas and peak_meas > 0 else None,
                         "frac_of_measured_peak": round(ach / peak_meas, 4) if peak_meas and peak_meas > 0 else None,
+                        "peak_measured_16x16x32": round(peak_meas16, 1) if peak_meas16 and peak_meas16 > 0 else None,
                         "traffic": traffic, "traffic_note": traffic_note,
                         "launches": tm["n_halo"], "flops_per_launch_avg": tm["flops_halo"] / max(tm["n_halo"], 1),
                         "avg_launch_ms": tm["ms_halo"] / max(tm["n_halo"], 1), "sum_ms": round(tm["ms_halo"], 3),

@@ -2072,6 +2072,10 @@ double gp_mfma_peak_tflops(int device, void* stream) {
     if (hipSetDevice(device) != hipSuccess) return -1.0;
     return mfma_peak_tflops(20, (hipStream_t)stream);
 }
+double gp_mfma_peak_tflops_shape(int device, int shape, void* stream) {
+    if (hipSetDevice(device) != hipSuccess || (shape != 0 && shape != 1)) return -1.0;
+    return mfma_peak_tflops(20, (hipStream_t)stream, shape);
+}
 
 gp_status gp_softmax_rows(const float* in, void* out, int rows, int T, int ld, float scale, void* stream) {
     if (!in || !out || ld < T) return GP_ERR_INVALID;

@@ -203,4 +203,4 @@ void launch_colorize_lut(const float* x, const unsigned char* lut, unsigned char
 void launch_quantize(const float* x, void* q, long long n, int bits, hipStream_t s);
 
 // microbench.hip: sustained TFLOP/s of back-to-back v_mfma_f32_32x32x16 on this chip (register operands, all CUs), or < 0 on error
-double mfma_peak_tflops(int ms_target, hipStream_t s);
+double mfma_peak_tflops(int ms_target, hipStream_t s, int shape = 0);  // shape 0: v_mfma_f32_32x32x16, 1: 16x16x32

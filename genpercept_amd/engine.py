@@ -122,6 +122,7 @@ SYMBOLS = {
     "gp_preprocess": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "gp_postprocess": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "gp_mfma_peak_tflops": (C.c_double, [_i, _vp]),
+    "gp_mfma_peak_tflops_shape": (C.c_double, [_i, _i, _vp]),
     "gp_cross_attention_fold": (_i, [_vp] * 9 + [_i, _i, _i, _f, _vp]),
     "gp_softmax_rows": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "gp_softmax_rows_f16": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
@@ -630,6 +631,11 @@ def postprocess(pred: torch.Tensor, size, resample: str = "bilinear", cmap: Opti
 def mfma_peak_tflops(device: int = 0, precision: Optional[str] = None) -> float:
     """Measured MFMA peak of this chip (TFLOP/s, dense, the library's 16-bit element type)."""
     return float(load_library(precision).gp_mfma_peak_tflops(device, _stream_ptr()))
+
+
+def mfma_peak_tflops_shape(device: int = 0, shape: int = 0, precision: Optional[str] = None) -> float:
+    """the same for one MFMA shape: 0 = v_mfma_f32_32x32x16, 1 = v_mfma_f32_16x16x32 (the conv / GEMM kernels' instruction)"""
+    return float(load_library(precision).gp_mfma_peak_tflops_shape(device, shape, _stream_ptr()))
 
 
 def cross_attention_fold(y: torch.Tensor, U: torch.Tensor, u0: torch.Tensor, G: torch.Tensor, c0: torch.Tensor, g3: torch.Tensor, b3: torch.Tensor,

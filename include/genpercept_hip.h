@@ -161,6 +161,10 @@ gp_status gp_postprocess(const float* pred, int B, int C, int h, int w, float* p
 /* Sustained TFLOP/s of back-to-back v_mfma_f32_32x32x16 (this library's element type) on every CU of `device`: the chip's own MFMA
  * peak under load, reported by bench.py beside the nominal 2.5 PFLOP/s.  < 0 on error. */
 double gp_mfma_peak_tflops(int device, void* stream);
+/* The same for one MFMA shape: 0 = v_mfma_f32_32x32x16 (the attention kernels), 1 = v_mfma_f32_16x16x32 (the conv / GEMM kernels; K = 32 per
+ * instruction moves a quarter of the accumulator registers per flop).  The chip runs against its power budget, so the two sustain different
+ * clocks on the same data. */
+double gp_mfma_peak_tflops_shape(int device, int shape, void* stream);
 
 /* ---- per-kernel entry points (DEVICE pointers, bf16 NHWC activations) -------------------------------------------- */
 /* Pack an OIHW fp32 HOST weight into the device layout [n_rows][taps][cin_pad] bf16 (n_rows = gp_packed_rows(cout)). */
