@@ -357,35 +357,24 @@ void launch_minmax_norm(float* x, int B, long long n, float* ws, hipStream_t s) 
 // (302 MB written and read back) and a K = 576 conv of which 27/576 was real work; here K = 27 (padded to 32) is ONE
 // v_mfma_f32_16x16x32_bf16 per 16 pixels x 16 channels, the image is read as uint8 and the layer is bound by its 2 B/element output.
 //   workgroup: 4 waves, 16x16 output pixels x 128 channels; halo 18x18x3 normalised to bf16 in LDS ([pixel][4]); k = 3 * tap + c.
+//   r4: PERSISTENT -- grid = (B x J, channel slices): a workgroup walks the tiles jw, jw + J, ... of one image with its weights, bias and
+//   fragments loaded once, and leaves ONE statistics row (+ its pixel count: the "mode 2" layout of the persistent convs) instead of one per
+//   16x16 tile: at 768x768 that is 128 rows per image for the finalize kernel instead of 2304 (its first launch cost 40 us, and the one-tile
+//   workgroups spent as long on weights / bias / launch as on their 16 MFMA k-steps).
 __global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict__ rgb, int is_u8, const h16_t* __restrict__ w27,
                                                            const float* __restrict__ bias, h16_t* __restrict__ out, float* __restrict__ stats,
-                                                           int B, int H, int W, int Cout) {
+                                                           int B, int H, int W, int Cout, int J) {
     __shared__ h16_t s_h[18 * 18 * 4];
     __shared__ float s_red[4 * 128 * 2];
     __shared__ __attribute__((aligned(16))) h16_t s_w[128 * 32];  // this slice's weights, [channel][k = 3 tap + c, zero for k >= 27]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int a = lane & 15, q = lane >> 4;
-    const int tiles_x = (W + 15) >> 4, tiles_y = (H + 15) >> 4;
-    int sp = blockIdx.x;
-    const int tx = sp % tiles_x;
-    sp /= tiles_x;
-    const int ty = sp % tiles_y, b = sp / tiles_y;
+    const int tiles_x = (W + 15) >> 4, tiles_y = (H + 15) >> 4, tiles_sp = tiles_x * tiles_y;
+    const int b = blockIdx.x / J, jw = blockIdx.x - b * J;
     const int n0 = blockIdx.y * 128;
     const int npair = min(4, (Cout - n0) >> 5);  // 32-channel pairs of fragments handled here
     const long long HW = (long long)H * W;
 
-    // halo: (pixel, channel) items, zero outside the image (the reference pads the NORMALISED image)
-    for (int i = tid; i < 18 * 18 * 4; i += 256) {
-        const int c = i & 3, pix = i >> 2;
-        const int hy = pix / 18, hx = pix - hy * 18;
-        const int iy = ty * 16 - 1 + hy, ix = tx * 16 - 1 + hx;
-        float v = 0.f;
-        if (c < 3 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-            const long long src = ((long long)b * 3 + c) * HW + (long long)iy * W + ix;
-            v = is_u8 ? ((float)((const unsigned char*)rgb)[src] / 255.0f * 2.0f - 1.0f) : ((const float*)rgb)[src];
-        }
-        s_h[i] = f_to_h16(v);
-    }
     // weights: compact [Cout][32] matrix (pack_k27_kernel) -> LDS (two 16-byte pieces per thread), then 16 bytes per fragment and lane.
     // (Gathering the 27 taps per lane from the [rows][9][64] conv layout cost more than the whole rest of the kernel: ~32 cache lines
     //  per load instruction, 64 instructions per lane and workgroup.)
@@ -413,37 +402,56 @@ __global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict
 #pragma unroll
         for (int e = 0; e < 8; ++e) st_s[ip][e] = st_q[ip][e] = 0.f;
     const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int py = 4 * wave + j;
-        h16x8_t xf;  // B operand: pixel a of row py, k = 8 q + e
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = 8 * q + e;
-            const int tap = k / 3, c = k - 3 * tap, ky = tap / 3, kx = tap - 3 * ky;
-            xf[e] = k < 27 ? (short)s_h[((py + ky) * 18 + a + kx) * 4 + c] : (short)0;
+    int run_px = 0;
+    for (int sp = jw; sp < tiles_sp; sp += J) {
+        const int ty = sp / tiles_x, tx = sp - ty * tiles_x;
+        run_px += min(16, H - 16 * ty) * min(16, W - 16 * tx);
+        __syncthreads();  // (the previous tile's fragment gathers are over)
+        // halo: (pixel, channel) items, zero outside the image (the reference pads the NORMALISED image)
+        for (int i = tid; i < 18 * 18 * 4; i += 256) {
+            const int c = i & 3, pix = i >> 2;
+            const int hy = pix / 18, hx = pix - hy * 18;
+            const int iy = ty * 16 - 1 + hy, ix = tx * 16 - 1 + hx;
+            float v = 0.f;
+            if (c < 3 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                const long long src = ((long long)b * 3 + c) * HW + (long long)iy * W + ix;
+                v = is_u8 ? ((float)((const unsigned char*)rgb)[src] / 255.0f * 2.0f - 1.0f) : ((const float*)rgb)[src];
+            }
+            s_h[i] = f_to_h16(v);
         }
-        const int oy = ty * 16 + py, ox = tx * 16 + a;
-        const bool ok = oy < H && ox < W;
-        h16_t* o = out + (((long long)b * H + oy) * W + ox) * Cout + n0 + 8 * q;
+        __syncthreads();
 #pragma unroll
-        for (int ip = 0; ip < 4; ++ip) {
-            if (ip >= npair) break;
-            const f32x4_t lo = mfma_16x16x32(wf[2 * ip], xf, zero4);
-            const f32x4_t hi = mfma_16x16x32(wf[2 * ip + 1], xf, zero4);
-            const float v[8] = {lo.x + bv[ip][0], lo.y + bv[ip][1], lo.z + bv[ip][2], lo.w + bv[ip][3],
-                                hi.x + bv[ip][4], hi.y + bv[ip][5], hi.z + bv[ip][6], hi.w + bv[ip][7]};
-            uint4 pk;
-            pk.x = pack_h16x2(v[0], v[1]); pk.y = pack_h16x2(v[2], v[3]); pk.z = pack_h16x2(v[4], v[5]); pk.w = pack_h16x2(v[6], v[7]);
-            if (ok) {
-                *(uint4*)(o + 32 * ip) = pk;
-                const float r[8] = {h16_lo(pk.x), h16_hi(pk.x), h16_lo(pk.y), h16_hi(pk.y), h16_lo(pk.z), h16_hi(pk.z), h16_lo(pk.w), h16_hi(pk.w)};
+        for (int j = 0; j < 4; ++j) {
+            const int py = 4 * wave + j;
+            h16x8_t xf;  // B operand: pixel a of row py, k = 8 q + e
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { st_s[ip][e] += r[e]; st_q[ip][e] += r[e] * r[e]; }
+            for (int e = 0; e < 8; ++e) {
+                const int k = 8 * q + e;
+                const int tap = k / 3, c = k - 3 * tap, ky = tap / 3, kx = tap - 3 * ky;
+                xf[e] = k < 27 ? (short)s_h[((py + ky) * 18 + a + kx) * 4 + c] : (short)0;
+            }
+            const int oy = ty * 16 + py, ox = tx * 16 + a;
+            const bool ok = oy < H && ox < W;
+            h16_t* o = out + (((long long)b * H + oy) * W + ox) * Cout + n0 + 8 * q;
+#pragma unroll
+            for (int ip = 0; ip < 4; ++ip) {
+                if (ip >= npair) break;
+                const f32x4_t lo = mfma_16x16x32(wf[2 * ip], xf, zero4);
+                const f32x4_t hi = mfma_16x16x32(wf[2 * ip + 1], xf, zero4);
+                const float v[8] = {lo.x + bv[ip][0], lo.y + bv[ip][1], lo.z + bv[ip][2], lo.w + bv[ip][3],
+                                    hi.x + bv[ip][4], hi.y + bv[ip][5], hi.z + bv[ip][6], hi.w + bv[ip][7]};
+                uint4 pk;
+                pk.x = pack_h16x2(v[0], v[1]); pk.y = pack_h16x2(v[2], v[3]); pk.z = pack_h16x2(v[4], v[5]); pk.w = pack_h16x2(v[6], v[7]);
+                if (ok) {
+                    *(uint4*)(o + 32 * ip) = pk;
+                    const float r[8] = {h16_lo(pk.x), h16_hi(pk.x), h16_lo(pk.y), h16_hi(pk.y), h16_lo(pk.z), h16_hi(pk.z), h16_lo(pk.w), h16_hi(pk.w)};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { st_s[ip][e] += r[e]; st_q[ip][e] += r[e] * r[e]; }
+                }
             }
         }
     }
-    if (stats) {  // per (tile, channel) sums of the stored values: 16 pixel lanes -> lane a == 0, 4 waves -> LDS -> one thread per channel
+    if (stats) {  // per (workgroup, channel) sums of the stored values: 16 pixel lanes -> lane a == 0, 4 waves -> LDS -> one thread per channel
 #pragma unroll
         for (int ip = 0; ip < 4; ++ip)
 #pragma unroll
@@ -458,14 +466,16 @@ __global__ __launch_bounds__(256) void rgb_conv_in_kernel(const void* __restrict
                 }
         }
         __syncthreads();
+        const long long row = blockIdx.x;  // = b * J + jw: J rows per image
         if (tid < 128 && n0 + tid < Cout) {
             float ss = 0.f, qq = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { ss += s_red[(w * 128 + tid) * 2]; qq += s_red[(w * 128 + tid) * 2 + 1]; }
-            float* so = stats + ((long long)blockIdx.x * Cout + n0 + tid) * 2;
+            float* so = stats + (row * Cout + n0 + tid) * 2;
             so[0] = ss;
             so[1] = qq;
         }
+        if (tid == 0 && blockIdx.y == 0) stats[(long long)B * J * Cout * 2 + row] = (float)run_px;
     }
 }
 // compact conv_in weights: [Cout][32] bf16 with k = 3 * tap + c (c < 3), zero for k >= 27, from the packed conv layout [rows][9][64]
@@ -478,11 +488,24 @@ __global__ __launch_bounds__(256) void pack_k27_kernel(const h16_t* __restrict__
 void launch_pack_k27(const h16_t* wt, int ldw, int Cout, h16_t* w27, hipStream_t s) {
     hipLaunchKernelGGL(pack_k27_kernel, dim3((Cout * 32 + 255) / 256), dim3(256), 0, s, wt, ldw, Cout, w27);
 }
-// Cout % 32 == 0; w27 = launch_pack_k27 output; stats (optional): [B * tiles][Cout][2], 16x16 tiles (mode 1)
+// workgroups (= statistics rows) per image of the persistent conv_in: ~2 per CU over the batch, at most one per tile
+int rgb_conv_in_rows(int B, int H, int W) {
+    static int ncu = 0;  // (queried once: hipGetDeviceProperties is not a launch-path call)
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    const int tiles_sp = ((W + 15) / 16) * ((H + 15) / 16);
+    int J = (2 * ncu + B - 1) / B;
+    if (J > tiles_sp) J = tiles_sp;
+    return J < 1 ? 1 : J;
+}
+// Cout % 32 == 0; w27 = launch_pack_k27 output; stats (optional): [B * J][Cout][2] sums + [B * J] pixel counts, J = rgb_conv_in_rows() ("mode 2")
 void launch_rgb_conv_in(const void* rgb, int is_u8, const h16_t* w27, const float* bias, h16_t* out, float* stats, int B, int H, int W, int Cout,
                         hipStream_t s) {
-    const int tiles = ((W + 15) / 16) * ((H + 15) / 16) * B;
-    hipLaunchKernelGGL(rgb_conv_in_kernel, dim3(tiles, (Cout + 127) / 128), dim3(256), 0, s, rgb, is_u8, w27, bias, out, stats, B, H, W, Cout);
+    const int J = rgb_conv_in_rows(B, H, W);
+    hipLaunchKernelGGL(rgb_conv_in_kernel, dim3(B * J, (Cout + 127) / 128), dim3(256), 0, s, rgb, is_u8, w27, bias, out, stats, B, H, W, Cout, J);
 }
 
 GP_SAT_TU(elementwise)  // fp16 build: address of this translation unit's saturation flag (common.h)

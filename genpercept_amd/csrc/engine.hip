@@ -1041,10 +1041,10 @@ struct gp_engine {
             // u8 image -> conv_in output in one kernel (K = 27), statistics for the first resnet's norm1 included
             h = new_act(B, Hh, Ww, win.cout);
             if (fuse_stats) {
-                const int nt = ((Ww + 15) / 16) * ((Hh + 15) / 16) * B;
-                h.st = (float*)pool.alloc((size_t)nt * win.cout * 2 * sizeof(float));
-                h.st_mode = 1;
-                h.st_bm = 256;
+                const int rows = rgb_conv_in_rows(B, Hh, Ww);  // persistent conv_in: one row per workgroup + its pixel count ("mode 2")
+                h.st = (float*)pool.alloc((size_t)B * rows * (2 * win.cout + 1) * sizeof(float));
+                h.st_mode = 2;
+                h.st_bm = rows;
             }
             tm.flops_igemm += 2.0 * (double)h.pixels() * win.cout * 27.0;
             mark("rgb_conv_in " + dims(h), 2.0 * (double)h.pixels() * win.cout * 27.0);

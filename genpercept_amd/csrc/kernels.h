@@ -162,6 +162,7 @@ void launch_softmax_rows_f16(const void* in_f16, h16_t* out, int rows, int T, in
 // Elementwise / layout kernels
 void launch_rgb_prologue(const void* rgb, int is_u8, h16_t* out, int B, int H, int W, int Cpad, hipStream_t s);  // NCHW -> NHWC, x/255*2-1
 // fused RGB prologue + VAE-encoder conv_in (3 -> Cout, Cout % 32 == 0) + GroupNorm partial statistics (16x16 tiles) of the output
+int rgb_conv_in_rows(int B, int H, int W);  // statistics rows per image launch_rgb_conv_in writes (mode 2: sums + pixel counts)
 void launch_pack_k27(const h16_t* wt, int ldw, int Cout, h16_t* w27, hipStream_t s);  // [rows][9][64] conv layout -> compact [Cout][32]
 void launch_rgb_conv_in(const void* rgb, int is_u8, const h16_t* w27, const float* bias, h16_t* out, float* stats, int B, int H, int W, int Cout,
                         hipStream_t s);
