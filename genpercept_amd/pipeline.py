@@ -432,7 +432,7 @@ class GenPerceptPipeline:
         beyond 65504 into inf / NaN; this engine clips it and COUNTS the call (`gp_saturation_events`): the map just produced is then not the
         fp32 path's map, and the caller is told so."""
         eng = self._engine
-        if eng is None or eng.precision != "fp16":
+        if eng is None or getattr(eng, "precision", None) != "fp16" or not hasattr(eng, "saturation_events"):
             return
         n = eng.saturation_events(reset=True)
         self.last_saturation_events = n
