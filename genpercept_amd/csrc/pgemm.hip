@@ -18,21 +18,24 @@
 
 constexpr int PG_BN = 128;
 
-template <int BM>
+template <int BM, int NB = 3>
 struct PGemmGeom {
     static constexpr int WM = BM / 64, WN = 8 / WM;      // 8 waves: 4 x 2 (BM 256) or 2 x 4 (BM 128); wave tile 64 rows x TN columns
     static constexpr int TN = PG_BN / WN, FM = 4, FN = TN / 16, FP = FN / 2;
     static constexpr int A_IT = BM / 64, B_IT = 2, LPS = A_IT + B_IT;
     static constexpr int A_BYTES = BM * 128, STAGE = (BM + PG_BN) * 128;
-    static constexpr int ST_OFF = 3 * STAGE;              // [8 waves][TN][2] partial statistics (<= 4 KiB)
+    static constexpr int ST_OFF = NB * STAGE;             // [8 waves][TN][2] partial statistics (<= 4 KiB)
     static constexpr int BIAS_OFF = ST_OFF + 4096;        // [128] bias of the column slice
     static constexpr int LDS = BIAS_OFF + 512;
 };
 
+// NB: ring depth (stages in flight ahead of the compute).  3 everywhere in r2 / r3; r4: 4 for the 128-row tile (4 x 32 KiB), whose launches are the
+// latency-bound ones -- M = 2304 / 9216 with one or two tiles per workgroup and 10-40 K-steps each, ~1.5 us per K-step against 0.2 us of MFMA work:
+// with a prefetch distance of three steps a stage has 1.5x as long to arrive.
 // ABL: compile-time ablations for profiling (2: no MFMA, 4: no output stores, 8: no DMA)
-template <int BM, int ABL = 0>
+template <int BM, int ABL = 0, int NB = 3>
 __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
-    using G = PGemmGeom<BM>;
+    using G = PGemmGeom<BM, NB>;
     constexpr int WN = G::WN, TN = G::TN, FM = G::FM, FN = G::FN, FP = G::FP;
     constexpr int A_IT = G::A_IT, B_IT = G::B_IT, LPS = G::LPS, A_BYTES = G::A_BYTES, STAGE = G::STAGE;
     constexpr int SLW = TN / 8;          // 8-channel slots per staged row
@@ -407,8 +410,10 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
     if (total > 0) stage(0);
     if (total > 1) stage(1);
     if (total > 2) stage(2);
+    if (NB > 3 && total > 3) stage(3);
     Half f0, f1a, f1b;
-    if (total > 2) wait_vm<LPS>(); else wait_vm<0>();  // stages 0 and 1 have landed
+    // stages 0 and 1 have landed: whatever was issued behind them may stay in flight
+    if (NB > 3 && total > 3) wait_vm<2 * LPS>(); else if (total > 2) wait_vm<LPS>(); else wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     load_half(f0, IC<0>{}, IC<0>{});
     load_half(f1a, IC<0>{}, IC<1>{});
@@ -416,14 +421,14 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
     __builtin_amdgcn_s_barrier();  // everybody holds its step-0 fragments: slot 0 may be refilled
 
     // ---- main loop -------------------------------------------------------------------------------------------------------------------
-    // Invariant at the top of step gs (slot S = gs % 3): the barrier certifying stage gs+1 has been passed, f0 / cur1 hold both k-halves
-    // of step gs, stages up to gs+2 are issued.  The step issues stage gs+3 into slot S (read during step gs-1) and reads the fragments of
+    // Invariant at the top of step gs (slot S = gs % NB): the barrier certifying stage gs+1 has been passed, f0 / cur1 hold both k-halves
+    // of step gs, stages up to gs+NB-1 are issued.  The step issues stage gs+NB into slot S (read during step gs-1) and reads the fragments of
     // step gs+1 (unconditionally: past the end they are stale LDS bytes nobody uses).
     int gs = 0, kt = 0;
     auto kstep = [&](auto slotc, Half& cur1, Half& nxt1) __attribute__((always_inline)) {
-        constexpr int S = decltype(slotc)::value, S1 = (S + 1) % 3;
+        constexpr int S = decltype(slotc)::value, S1 = (S + 1) % NB;
         const bool tile_end = kt == nk - 1;
-        const bool issue = gs + 3 < total, more = gs + 1 < total;
+        const bool issue = gs + NB < total, more = gs + 1 < total;
         const bool dma_first = second_half && !tile_end;  // role split; at a tile end the slot is the epilogue's window first
         if (dma_first && issue) stage(S);
         __builtin_amdgcn_sched_barrier(0);
@@ -445,23 +450,40 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
         if (tile_end) { cm0 += tile_adv; kt = 0; } else ++kt;
         ++gs;
         if (!more) return;
-        if (!tile_end) { if (issue) wait_vm<LPS>(); else wait_vm<0>(); }
+        // stage gs+2 (ring position of the NEW gs: +1) must have landed; the stages issued behind it may stay in flight
+        if (!tile_end) {
+            if (NB == 3) { if (issue) wait_vm<LPS>(); else wait_vm<0>(); }
+            else {
+                const int behind = total - 2 - gs;  // stages issued behind the one needed (gs already advanced): min(NB - 2, total - 1 - (gs + 1))
+                if (behind >= 2) wait_vm<2 * LPS>(); else if (behind == 1) wait_vm<LPS>(); else wait_vm<0>();
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (tile_end && want_stats) flush_stats(done_row);
     };
     while (gs < total) {
-        kstep(IC<0>{}, f1a, f1b);
-        if (gs >= total) break;
-        kstep(IC<1>{}, f1b, f1a);
-        if (gs >= total) break;
-        kstep(IC<2>{}, f1a, f1b);
-        if (gs >= total) break;
-        kstep(IC<0>{}, f1b, f1a);
-        if (gs >= total) break;
-        kstep(IC<1>{}, f1a, f1b);
-        if (gs >= total) break;
-        kstep(IC<2>{}, f1b, f1a);
+        if constexpr (NB == 3) {
+            kstep(IC<0>{}, f1a, f1b);
+            if (gs >= total) break;
+            kstep(IC<1>{}, f1b, f1a);
+            if (gs >= total) break;
+            kstep(IC<2>{}, f1a, f1b);
+            if (gs >= total) break;
+            kstep(IC<0>{}, f1b, f1a);
+            if (gs >= total) break;
+            kstep(IC<1>{}, f1a, f1b);
+            if (gs >= total) break;
+            kstep(IC<2>{}, f1b, f1a);
+        } else {
+            kstep(IC<0>{}, f1a, f1b);
+            if (gs >= total) break;
+            kstep(IC<1>{}, f1b, f1a);
+            if (gs >= total) break;
+            kstep(IC<2>{}, f1a, f1b);
+            if (gs >= total) break;
+            kstep(IC<3>{}, f1b, f1a);
+        }
     }
     if (want_stats && total > 0) {  // the last tile's partials
         __syncthreads();
@@ -490,17 +512,17 @@ int pgemm_bm(const IGemmParams& p) {
     return t256 >= 3 * groups ? 256 : 128;
 }
 
-template <int BM, int ABL>
+template <int BM, int ABL, int NB = 3>
 static void launch_pgemm_one(const IGemmParams& p, int ncu, hipStream_t s) {
-    using G = PGemmGeom<BM>;
+    using G = PGemmGeom<BM, NB>;
     static unsigned long long attr_mask = 0;
-    gp_once_per_device(&attr_mask, [&] { (void)hipFuncSetAttribute((const void*)pgemm_kernel<BM, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS); });
+    gp_once_per_device(&attr_mask, [&] { (void)hipFuncSetAttribute((const void*)pgemm_kernel<BM, ABL, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS); });
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
     const int tiles_n = (ncols + PG_BN - 1) / PG_BN, tiles_m = (p.M + BM - 1) / BM;
     int groups = ncu / tiles_n;
     if (groups < 1) groups = 1;
     if (groups > tiles_m) groups = tiles_m;
-    hipLaunchKernelGGL((pgemm_kernel<BM, ABL>), dim3(groups * tiles_n), dim3(512), G::LDS, s, p);
+    hipLaunchKernelGGL((pgemm_kernel<BM, ABL, NB>), dim3(groups * tiles_n), dim3(512), G::LDS, s, p);
 }
 
 void launch_pgemm(const IGemmParams& p, hipStream_t s) {
@@ -523,7 +545,8 @@ void launch_pgemm(const IGemmParams& p, hipStream_t s) {
         else if (abl == 8) launch_pgemm_one<128, 8>(p, ncu, s);
         else if (abl == 10) launch_pgemm_one<128, 10>(p, ncu, s);
         else if (abl == 14) launch_pgemm_one<128, 14>(p, ncu, s);
-        else launch_pgemm_one<128, 0>(p, ncu, s);
+        else if (((p.dbg >> 23) & 1) || gp_sw().pgemm_ring3) launch_pgemm_one<128, 0>(p, ncu, s);   // A/B: the 3-deep ring of r2 / r3
+        else launch_pgemm_one<128, 0, 4>(p, ncu, s);
     }
 }
 

@@ -148,7 +148,7 @@ def test_model_matches_source():
 
 
 # ---- persistent GEMM (pgemm.hip): 3-deep ring over the (tile, k) step stream ----------------------------------------------------------
-def simulate_pgemm(nk, ntiles, lps=6):
+def simulate_pgemm(nk, ntiles, lps=6, nb=3):
     total = nk * ntiles
     fifo = [[] for _ in range(NW)]
     done = [set() for _ in range(NW)]
@@ -156,7 +156,7 @@ def simulate_pgemm(nk, ntiles, lps=6):
     last_read = {}
 
     def issue(w, stage, step, after_own_epilogue):
-        prev = stage - 3
+        prev = stage - nb
         if prev in last_read:
             assert last_read[prev] < step, f"stage {stage} issued in step {step} while stage {prev} is still read in step {last_read[prev]}"
         fifo[w].extend([stage] * lps)
@@ -176,20 +176,20 @@ def simulate_pgemm(nk, ntiles, lps=6):
         last_read[stage] = max(last_read.get(stage, -1), step)
 
     for w in range(NW):
-        for st in range(min(3, total)):
+        for st in range(min(nb, total)):
             issue(w, st, -1, False)
-        wait(w, lps if total > 2 else 0)
+        wait(w, 2 * lps if (nb > 3 and total > 3) else lps if total > 2 else 0)
     barrier()
     read(0, -1)
     barrier()
     for gs in range(total):
         kt = gs % nk
         tile_end = kt == nk - 1
-        issue_ok, more = gs + 3 < total, gs + 1 < total
+        issue_ok, more = gs + nb < total, gs + 1 < total
         dma_first = [w >= 4 and not tile_end for w in range(NW)]
         for w in range(NW):
             if dma_first[w] and issue_ok:
-                issue(w, gs + 3, gs, False)
+                issue(w, gs + nb, gs, False)
         if more:
             read(gs + 1, gs)          # (past the end the kernel reads stale bytes nobody uses)
         if tile_end:
@@ -197,28 +197,35 @@ def simulate_pgemm(nk, ntiles, lps=6):
                 wait(w, 0)
         for w in range(NW):
             if not dma_first[w] and issue_ok:
-                issue(w, gs + 3, gs, tile_end)   # at a tile end: after this wave's own epilogue (its window = its own DMA pieces of the slot)
+                issue(w, gs + nb, gs, tile_end)   # at a tile end: after this wave's own epilogue (its window = its own DMA pieces of the slot)
         if not more:
             break
         for w in range(NW):
             if not tile_end:
-                wait(w, lps if issue_ok else 0)
+                if nb == 3:
+                    wait(w, lps if issue_ok else 0)
+                else:  # (the kernel computes this after ++gs: behind = total - 2 - gs_new)
+                    behind = total - 2 - (gs + 1)
+                    wait(w, 2 * lps if behind >= 2 else lps if behind == 1 else 0)
         barrier()
 
 
 @pytest.mark.parametrize("nk", [1, 2, 3, 5, 10, 40])
 @pytest.mark.parametrize("ntiles", [1, 2, 4])
 @pytest.mark.parametrize("lps", [6, 4])
-def test_pgemm_ring_protocol_is_safe(nk, ntiles, lps):
-    simulate_pgemm(nk, ntiles, lps)
+@pytest.mark.parametrize("nb", [3, 4])
+def test_pgemm_ring_protocol_is_safe(nk, ntiles, lps, nb):
+    simulate_pgemm(nk, ntiles, lps, nb)
 
 
 def test_pgemm_model_matches_source():
     s = open(os.path.join(ROOT, "genpercept_amd", "csrc", "pgemm.hip")).read()
-    for line in ["const bool issue = gs + 3 < total, more = gs + 1 < total;",
+    for line in ["const bool issue = gs + NB < total, more = gs + 1 < total;",
                  "const bool dma_first = second_half && !tile_end;",
-                 "if (!tile_end) { if (issue) wait_vm<LPS>(); else wait_vm<0>(); }",
-                 "if (total > 2) wait_vm<LPS>(); else wait_vm<0>();",
+                 "if (NB == 3) { if (issue) wait_vm<LPS>(); else wait_vm<0>(); }",
+                 "const int behind = total - 2 - gs;",
+                 "if (behind >= 2) wait_vm<2 * LPS>(); else if (behind == 1) wait_vm<LPS>(); else wait_vm<0>();",
+                 "if (NB > 3 && total > 3) wait_vm<2 * LPS>(); else if (total > 2) wait_vm<LPS>(); else wait_vm<0>();",
                  'asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");']:
         assert line in s, line
 
