@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void concat_stats_kernel(const h16_t* __restri
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-#pragma unroll 4
-    for (int r = 0; r < bm; ++r) {
+#pragma unroll 8
+    for (int r = 0; r < bm; ++r) {  // (eight 16-byte loads in flight per thread: r3's four left the pass at half the HBM rate)
         const uint4 x = *(const uint4*)(src + (long long)r * ld);
         *(uint4*)(dst + (long long)r * C) = x;
         const float f[8] = {h16_lo(x.x), h16_hi(x.x), h16_lo(x.y), h16_hi(x.y), h16_lo(x.z), h16_hi(x.z), h16_lo(x.w), h16_hi(x.w)};
@@ -82,10 +82,17 @@ __global__ __launch_bounds__(256) void concat_stats_kernel(const h16_t* __restri
 #pragma unroll
     for (int e = 0; e < 8; ++e) { po[2 * e] = s[e]; po[2 * e + 1] = q[e]; }
 }
-int concat_stats_bm(long long hw) {
+// pixels per statistics tile: the largest divisor of an image's pixel count among {64, 48, 32, 16} that still gives the launch ~2 workgroups
+// per CU (r3 always took the largest: the UNet's 24x24 maps then ran on 72 workgroups and the pass was latency-bound, 34 us for 24 MB)
+int concat_stats_bm(long long hw, long long pixels, int channels) {
+    const long long slices = (channels / 8 + 255) / 256;
+    int best = 0;
     for (int bm : {64, 48, 32, 16})
-        if (hw % bm == 0) return bm;
-    return 0;
+        if (hw % bm == 0) {
+            best = bm;  // (the smallest valid one if none reaches the target)
+            if ((pixels / bm) * slices >= 512) return bm;
+        }
+    return best;
 }
 void launch_concat_stats(const h16_t* a, int Ca, const h16_t* b, int Cb, h16_t* out, long long pixels, int bm, float* part, hipStream_t s) {
     hipLaunchKernelGGL(concat_stats_kernel, dim3((unsigned)(pixels / bm), ((Ca + Cb) / 8 + 255) / 256), dim3(256), 0, s, a, Ca, b, Cb, out, bm, part);

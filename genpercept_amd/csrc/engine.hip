@@ -1139,7 +1139,7 @@ struct gp_engine {
                 Act skip = skips.back();
                 skips.pop_back();
                 Act cat = new_act(h.B, h.H, h.W, h.C + skip.C);
-                const int cbm = fuse_stats ? concat_stats_bm((long long)h.H * h.W) : 0;
+                const int cbm = fuse_stats ? concat_stats_bm((long long)h.H * h.W, h.pixels(), h.C + skip.C) : 0;
                 mark("concat " + dims(cat));
                 if (cbm) {  // the copy also leaves the statistics the resnet's first GroupNorm needs
                     cat.st = (float*)pool.alloc((size_t)(h.pixels() / cbm) * cat.C * 2 * sizeof(float));

@@ -167,7 +167,7 @@ void launch_pack_k27(const h16_t* wt, int ldw, int Cout, h16_t* w27, hipStream_t
 void launch_rgb_conv_in(const void* rgb, int is_u8, const h16_t* w27, const float* bias, h16_t* out, float* stats, int B, int H, int W, int Cout,
                         hipStream_t s);
 void launch_concat(const h16_t* a, int Ca, const h16_t* b, int Cb, h16_t* out, long long pixels, hipStream_t s);
-int concat_stats_bm(long long hw);  // pixels per statistics tile launch_concat_stats can use for an image of hw pixels (0: none)
+int concat_stats_bm(long long hw, long long pixels, int channels);  // pixels per statistics tile launch_concat_stats can use for an image of hw pixels (0: none)
 void launch_concat_stats(const h16_t* a, int Ca, const h16_t* b, int Cb, h16_t* out, long long pixels, int bm, float* part, hipStream_t s);
 struct DdimCoef { float x0_sample, x0_model, eps_sample, eps_model, prev_x0, prev_eps, clip; };
 void launch_ddim_init(const float* noise_nchw, h16_t* lat, float* sample, int B, int H, int W, int L, int ld, int off, hipStream_t s);
