@@ -548,6 +548,16 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
             for (int j = 0; j < FM; ++j) acc[i][j] = mfma_16x16x32(f.w[i], f.x[j], acc[i][j]);
     };
     auto interleave = [&]() __attribute__((always_inline)) {
+        if (ABL & 2048) {  // r4 experiment: the eight fragment reads under the FIRST eight MFMAs (the last one then has eight MFMAs of cover
+                           // before the step's lgkmcnt(0) + barrier instead of none)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -735,6 +745,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+    if ((ABL & 4096) && second_half) __builtin_amdgcn_s_setprio(1);  // r4 experiment: static priority for the later-dispatched half (guide T5)
     // ---- main loop over (tile, chunk), nine unrolled taps each --------------------------------------------------------------------------
     int cc = 0;
     bool tile_end = cpt == 1;                                    // this chunk is the last of its tile
@@ -896,7 +907,10 @@ static void launch_halo3(const IGemmParams& p, int grid, hipStream_t s) {
     else if (fused == 1) launch_halo3_one<false, 1, 0>(p, grid, s);
     else if (abl == 2) launch_halo3_one<false, 0, 2>(p, grid, s);
     else if (abl == 24) launch_halo3_one<false, 0, 24>(p, grid, s);
-#ifdef GP_HALO_ABLATIONS  // the other r3 experiments: hipcc ... -DGP_HALO_ABLATIONS=1
+#ifdef GP_HALO_ABLATIONS  // the other r3 / r4 experiments (profiles/HISTORY.md): hipcc ... -DGP_HALO_ABLATIONS=1
+    else if (((p.dbg >> 24) & 3) == 1) launch_halo3_one<false, 0, 2048>(p, grid, s);   // r4 (IGemmParams::dbg bits 24-25): front-loaded fragment
+    else if (((p.dbg >> 24) & 3) == 2) launch_halo3_one<false, 0, 4096>(p, grid, s);   // reads / static wave priority / both: all neutral
+    else if (((p.dbg >> 24) & 3) == 3) launch_halo3_one<false, 0, 6144>(p, grid, s);   // (profiles/r04_halo3_schedule_ab.json)
     else if (abl == 4) launch_halo3_one<false, 0, 4>(p, grid, s);
     else if (abl == 8) launch_halo3_one<false, 0, 8>(p, grid, s);
     else if (abl == 16) launch_halo3_one<false, 0, 16>(p, grid, s);
