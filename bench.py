@@ -278,7 +278,7 @@ def main(argv=None, engine_factory=None, device=None):
     # ---- second timed leg: the fp16 library (the build that meets north_star's 1e-3), same steps / barriers ---------------------------
     fp16 = None
     out0_f16 = None
-    if args.precision == "bf16" and not args.no_fp16:
+    if args.precision == "bf16" and not args.no_fp16 and n_gpus == 1:  # (N > 1 measures scaling of the headline dtype only: no second engine build per rank)
         eng.close()
         eng = build_engine("fp16")
         el16, o16 = timed(eng)
