@@ -530,11 +530,25 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         constexpr int TAP = decltype(tapc)::value, PAR = decltype(parc)::value, KK = decltype(kkc)::value;
         constexpr int KY = TAP / 3, KX = TAP % 3, SLOT = TAP % 3;
 #pragma unroll
-        for (int i = 0; i < FN; ++i) f.w[i] = lds_frag(wb[KK], SLOT * B_STAGE + (i >> 1) * 4096 + (i & 1) * 512);
+        for (int i = 0; i < FN; ++i) {
+            if (ABL & 8192) asm volatile("" : "+v"(f.w[i]));  // r4 diagnostic: no weight-fragment reads (registers keep whatever they hold: garbage results)
+            else f.w[i] = lds_frag(wb[KK], SLOT * B_STAGE + (i >> 1) * 4096 + (i & 1) * 512);
+            typedef const volatile __attribute__((address_space(3))) h16x8_t* lds_frag_vptr;
+            if (ABL & 32768) {  // r4 diagnostic: every fragment read issued TWICE (the copy is discarded): is LDS array time additive to the MFMA time?
+                const h16x8_t t = *(lds_frag_vptr)(wb[KK] + (unsigned)(SLOT * B_STAGE + (i >> 1) * 4096 + (i & 1) * 512));
+                asm volatile("" ::"v"(t));
+            }
+        }
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
             const int hy = UPS ? ((j + KY - 1) >> 1) + 1 : j + KY;
-            f.x[j] = lds_frag(xb[KX][KK], PAR * A_BUF + hy * HW_ * 128);
+            if (ABL & 16384) asm volatile("" : "+v"(f.x[j]));  // ... no pixel-fragment reads
+            else f.x[j] = lds_frag(xb[KX][KK], PAR * A_BUF + hy * HW_ * 128);
+            typedef const volatile __attribute__((address_space(3))) h16x8_t* lds_frag_vptr;
+            if (ABL & 32768) {
+                const h16x8_t t = *(lds_frag_vptr)(xb[KX][KK] + (unsigned)(PAR * A_BUF + hy * HW_ * 128));
+                asm volatile("" ::"v"(t));
+            }
         }
     };
     auto mfma16 = [&](const Half& f) __attribute__((always_inline)) {
@@ -911,6 +925,10 @@ static void launch_halo3(const IGemmParams& p, int grid, hipStream_t s) {
     else if (((p.dbg >> 24) & 3) == 1) launch_halo3_one<false, 0, 2048>(p, grid, s);   // r4 (IGemmParams::dbg bits 24-25): front-loaded fragment
     else if (((p.dbg >> 24) & 3) == 2) launch_halo3_one<false, 0, 4096>(p, grid, s);   // reads / static wave priority / both: all neutral
     else if (((p.dbg >> 24) & 3) == 3) launch_halo3_one<false, 0, 6144>(p, grid, s);   // (profiles/r04_halo3_schedule_ab.json)
+    else if (((p.dbg >> 26) & 3) == 1) launch_halo3_one<false, 0, 8192>(p, grid, s);    // r4 (bits 26-27): how much of the K loop is the LDS fragment
+    else if (((p.dbg >> 26) & 3) == 2) launch_halo3_one<false, 0, 16384>(p, grid, s);   // traffic -- no weight fragments / no pixel fragments / neither
+    else if (((p.dbg >> 26) & 3) == 3) launch_halo3_one<false, 0, 24576>(p, grid, s);   // (MFMAs, DMA, waits, barriers, epilogue unchanged; garbage results)
+    else if ((p.dbg >> 30) & 1) launch_halo3_one<false, 0, 32768>(p, grid, s);          // r4 (bit 30): every fragment read issued twice
     else if (abl == 4) launch_halo3_one<false, 0, 4>(p, grid, s);
     else if (abl == 8) launch_halo3_one<false, 0, 8>(p, grid, s);
     else if (abl == 16) launch_halo3_one<false, 0, 16>(p, grid, s);
@@ -950,22 +968,35 @@ static bool halo_persistent(const IGemmParams& p) {
     const bool slots_ok = (p.n_store & 7) == 0 && (p.ldo & 7) == 0 && (!p.res || ((p.ldres & 7) == 0 && p.ldres >= p.n_store));
     return slots_ok && !(p.dbg & 256);
 }
-// Which persistent kernel takes this problem, and with how many workgroups per image (a multiple of tiles_n): conv3x3_halo4_kernel (32 x 16
-// tiles, conv_halo4.hip) where it applies and fills the grid as well as the 16 x 16 tiling, else conv3x3_halo3_kernel.  One function for the
-// launch AND for the statistics-row count the engine allocates.  p.dbg bits 20-21 (kbench / tests): 1 forces halo4 where it applies, 2 forbids it.
-static int halo_plan(const IGemmParams& p, bool* use4) {
+// Which persistent kernel takes this problem (*kind = 3, 4 or 5), and with how many workgroups per image (a multiple of tiles_n):
+// conv3x3_halo3_kernel by default; conv3x3_halo4_kernel (32 x 16 tiles, conv_halo4.hip) where it applies, is enabled and fills the grid as well as
+// the 16 x 16 tiling; conv3x3_halo5_kernel (conv_halo5.hip: 16 x 16 tiles, TWO workgroups per CU) where it applies and is enabled.  One function for
+// the launch AND for the statistics-row count the engine allocates.  p.dbg (kbench / tests): bits 20-21 = 1 forces halo4 where it applies, 2 forbids
+// it; bits 28-29 the same for halo5.
+static int halo_plan(const IGemmParams& p, int* kind) {
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
-    const int tiles_n = (ncols + 127) / 128;
+    const int tiles_n = (ncols + 127) / 128, tiles_sp = ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
     int J = halo3_wgs_per_image(p, halo_ncu());
-    const int h4 = (p.dbg >> 20) & 3;
-    *use4 = false;
+    const int h4 = (p.dbg >> 20) & 3, h5 = (p.dbg >> 28) & 3;
+    *kind = 3;
+    if (h5 != 2 && (h5 == 1 || gp_sw().halo5) && conv_halo5_applicable(p)) {
+        const int J2 = halo3_wgs_per_image(p, 2 * halo_ncu());  // (every workgroup has at least one tile: capped at the tile count)
+        // twice the workgroups quantise the tile count more coarsely (96 x 96 maps, batch 4: 36 tiles on 32 slots = two rounds, against three
+        // rounds of 16): without the force bit only where the last round is filled as well as halo3's
+        const int s3 = J / tiles_n, s5 = J2 / tiles_n;
+        const double e3 = (double)tiles_sp / (double)(((tiles_sp + s3 - 1) / s3) * s3), e5 = (double)tiles_sp / (double)(((tiles_sp + s5 - 1) / s5) * s5);
+        if (h5 == 1 || e5 >= 0.97 * e3) {
+            *kind = 5;
+            return J2;
+        }
+    }
     if (h4 != 2 && conv_halo4_applicable(p)) {
         const int t4 = ((p.Wo + 31) / 32) * ((p.Ho + 15) / 16);
         if (h4 == 1) {
-            *use4 = true;
+            *kind = 4;
             if (J > t4 * tiles_n) J = t4 * tiles_n;  // (every workgroup needs at least one tile)
         } else if (conv_halo4_preferred(p, J)) {
-            *use4 = true;
+            *kind = 4;
         }
     }
     return J;
@@ -975,8 +1006,8 @@ static int halo_plan(const IGemmParams& p, bool* use4) {
 int conv_halo_stat_rows(const IGemmParams& p) {
     if (!halo_persistent(p)) return 0;
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
-    bool use4;
-    return halo_plan(p, &use4) / ((ncols + 127) / 128);
+    int kind;
+    return halo_plan(p, &kind) / ((ncols + 127) / 128);
 }
 
 void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
@@ -989,9 +1020,10 @@ void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
     });
     // (conv_halo_applicable guarantees whole 128-row weight tiles)
     if (halo_persistent(p)) {
-        bool use4;
-        const int J = halo_plan(p, &use4);
-        if (use4) launch_conv_halo4(p, p.B * J, s);
+        int kind;
+        const int J = halo_plan(p, &kind);
+        if (kind == 5) launch_conv_halo5(p, p.B * J, s);
+        else if (kind == 4) launch_conv_halo4(p, p.B * J, s);
         else launch_halo3(p, p.B * J, s);
         return;
     }

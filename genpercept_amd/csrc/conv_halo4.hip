@@ -412,6 +412,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo4_kernel(const IGemmParams p)
             mfma8(cur1, xcur1);
             __builtin_amdgcn_sched_barrier(0);
             if (tile_end) {
+                // X3 = false reads this step's second pixel-fragment set from the halo buffer DURING the step: a wave that is held up (issuing
+                // its DMA) must have them before a faster wave turns that buffer into its staging window
+                if constexpr (!X3) __builtin_amdgcn_s_barrier();
                 wait_vm<0>();  // everything this wave has in flight has landed: stores issued below cannot delay a certification
                 epilogue(a_base + PAR * A_BUF + wave * 4096);
             }

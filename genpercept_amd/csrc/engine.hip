@@ -2047,18 +2047,29 @@ void gp_resize_max_res_size(int H0, int W0, int max_edge, int* h, int* w) {
 }
 
 gp_status gp_preprocess(const void* rgb_u8, int B, int H0, int W0, void* out_u8, int h, int w, int resample, float* tmp, void* stream) {
-    if (!rgb_u8 || !out_u8 || B < 1 || H0 < 1 || W0 < 1 || h < 1 || w < 1 || (resample != 0 && resample != 1) || (resample == 0 && !tmp)) return GP_ERR_INVALID;
+    if (!rgb_u8 || !out_u8 || B < 1 || H0 < 1 || W0 < 1 || h < 1 || w < 1 || resample < 0 || resample > 2 || (resample != 1 && !tmp)) return GP_ERR_INVALID;
     launch_resize(rgb_u8, out_u8, tmp, (long long)B * 3, H0, W0, h, w, resample, 1, 0, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
+}
+
+gp_status gp_preprocess_f32(const float* rgb, int B, int C, int H0, int W0, float* out, int h, int w, int resample, int normalize, float* tmp, void* stream) {
+    if (!rgb || !out || B < 1 || C < 1 || H0 < 1 || W0 < 1 || h < 1 || w < 1 || resample < 0 || resample > 2) return GP_ERR_INVALID;
+    const bool same = h == H0 && w == W0;
+    if (!same && resample != 1 && !tmp) return GP_ERR_INVALID;
+    if (same && !normalize && rgb != out) return GP_ERR_INVALID;  // nothing to do but a copy: the caller keeps its tensor
+    hipStream_t s = (hipStream_t)stream;
+    if (!same) launch_resize(rgb, out, tmp, (long long)B * C, H0, W0, h, w, resample, 0, 0, s);
+    if (normalize) launch_normalize_rgb(same ? rgb : out, out, (long long)B * C * h * w, s);
     return hipGetLastError() == hipSuccess ? GP_OK : GP_ERR_HIP;
 }
 
 gp_status gp_postprocess(const float* pred, int B, int C, int h, int w, float* pred_out, int Ho, int Wo, int resample, float* tmp,
                          const unsigned char* lut_dev, void* colored_out, void* q_out, int q_bits, void* stream) {
-    if (!pred || !pred_out || B < 1 || C < 1 || h < 1 || w < 1 || Ho < 1 || Wo < 1 || (resample != 0 && resample != 1)) return GP_ERR_INVALID;
+    if (!pred || !pred_out || B < 1 || C < 1 || h < 1 || w < 1 || Ho < 1 || Wo < 1 || resample < 0 || resample > 2) return GP_ERR_INVALID;
     if (colored_out && (!lut_dev || C != 1)) return GP_ERR_INVALID;
     if (q_out && q_bits != 16 && q_bits != 8) return GP_ERR_INVALID;
     const bool same = h == Ho && w == Wo;
-    if (!same && resample == 0 && !tmp) return GP_ERR_INVALID;
+    if (!same && resample != 1 && !tmp) return GP_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const long long n = (long long)B * C * Ho * Wo;
     if (same) launch_clip01(pred, pred_out, n, s);
@@ -2075,6 +2086,11 @@ double gp_mfma_peak_tflops(int device, void* stream) {
 double gp_mfma_peak_tflops_shape(int device, int shape, void* stream) {
     if (hipSetDevice(device) != hipSuccess || (shape != 0 && shape != 1)) return -1.0;
     return mfma_peak_tflops(20, (hipStream_t)stream, shape);
+}
+
+double gp_mfma_lds_probe(int device, int reads_per_16_mfma, int waves_per_simd, void* stream) {
+    if (hipSetDevice(device) != hipSuccess) return -1.0;
+    return mfma_lds_probe_tflops(reads_per_16_mfma, waves_per_simd, (hipStream_t)stream);
 }
 
 gp_status gp_softmax_rows(const float* in, void* out, int rows, int T, int ld, float scale, void* stream) {

@@ -61,7 +61,7 @@ struct IGemmParams {
 struct GpSwitches {
     int flash_ring3, no_flash512, f5_dbg, no_conv_few, no_conv_img, conv_img_s, no_cross_fold, no_gn_fusion, gn_fuse_max_slices,
         gn_fuse_below_px, no_stats_fusion, vt_tile, no_gn_small, fp32_scores, no_qkv_fuse, qkv_fuse_max_rows, no_rgb_conv, igemm_dbg, no_splitk,
-        no_halo, no_pgemm, gn_apply_old, xfold_lds, no_halo4, no_fin_fuse, halo4_auto, pgemm_ring3;
+        no_halo, no_pgemm, gn_apply_old, xfold_lds, no_halo4, no_fin_fuse, halo4_auto, pgemm_ring3, halo5;
 };
 const GpSwitches& gp_sw();
 void gp_switches_reload();
@@ -75,7 +75,8 @@ void* gp_sat_flag_addr_norm();
 void* gp_sat_flag_addr_attention();
 void* gp_sat_flag_addr_elementwise();
 void* gp_sat_flag_addr_conv_halo4();
-#define GP_SAT_TUS {gp_sat_flag_addr_igemm, gp_sat_flag_addr_conv_halo, gp_sat_flag_addr_pgemm, gp_sat_flag_addr_conv_few, gp_sat_flag_addr_norm, gp_sat_flag_addr_attention, gp_sat_flag_addr_elementwise, gp_sat_flag_addr_conv_halo4}
+void* gp_sat_flag_addr_conv_halo5();
+#define GP_SAT_TUS {gp_sat_flag_addr_igemm, gp_sat_flag_addr_conv_halo, gp_sat_flag_addr_pgemm, gp_sat_flag_addr_conv_few, gp_sat_flag_addr_norm, gp_sat_flag_addr_attention, gp_sat_flag_addr_elementwise, gp_sat_flag_addr_conv_halo4, gp_sat_flag_addr_conv_halo5}
 
 // tile_hint: 0 auto (halo conv / persistent GEMM / split-K / generic tile by heuristic), 1 = 128x128, 2 = 64x64, 3 = 256x32, 4 = 256x128,
 //            5 = conv_halo.hip, 6 = 128x64, 7 = pgemm.hip
@@ -110,6 +111,9 @@ int conv_halo_stat_rows(const IGemmParams& p);     // > 0: statistics rows per i
 bool conv_halo4_applicable(const IGemmParams& p);
 bool conv_halo4_preferred(const IGemmParams& p, int wgs_per_image);
 void launch_conv_halo4(const IGemmParams& p, int grid, hipStream_t s);
+// conv_halo5.hip: the same convs (halo4's set) on 16 x 16 tiles with TWO workgroups per CU (128 registers per wave, <= 80 KiB LDS each)
+bool conv_halo5_applicable(const IGemmParams& p);
+void launch_conv_halo5(const IGemmParams& p, int grid, hipStream_t s);
 // Statistics layout launch_igemm(p, tile_hint) will write: mode 0 = rows of BM consecutive pixels, mode 1 = 16x16 halo tiles per image,
 // mode 2 = *bm rows per image, each with its own pixel count appended after the [rows][N][2] sums; returns the number of rows (callers
 // allocate rows * (2 N + 1) floats), or 0 when that kernel path cannot produce stats_out (direct epilogue, GEGLU, fp32 output, ...).
@@ -200,8 +204,10 @@ void launch_conv_few(const h16_t* in, const h16_t* wt, const float* bias, const 
 // prepost.hip: device-side pre / post processing of GenPerceptPipeline.__call__ (resize with torchvision semantics, colour map, quantisation)
 void launch_resize(const void* in, void* out, float* tmp, long long planes, int Hi, int Wi, int Ho, int Wo, int mode, int u8, int clip01, hipStream_t s);
 void launch_clip01(const float* in, float* out, long long n, hipStream_t s);
+void launch_normalize_rgb(const float* in, float* out, long long n, hipStream_t s);
 void launch_colorize_lut(const float* x, const unsigned char* lut, unsigned char* rgb, long long n, hipStream_t s);
 void launch_quantize(const float* x, void* q, long long n, int bits, hipStream_t s);
 
 // microbench.hip: sustained TFLOP/s of back-to-back v_mfma_f32_32x32x16 on this chip (register operands, all CUs), or < 0 on error
-double mfma_peak_tflops(int ms_target, hipStream_t s, int shape = 0);  // shape 0: v_mfma_f32_32x32x16, 1: 16x16x32
+double mfma_peak_tflops(int ms_target, hipStream_t s, int shape = 0);
+double mfma_lds_probe_tflops(int reads_per_16_mfma, int waves_per_simd, hipStream_t s);  // shape 0: v_mfma_f32_32x32x16, 1: 16x16x32

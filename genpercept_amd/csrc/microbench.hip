@@ -57,6 +57,117 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* __restrict__ out,
     out[(long long)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// r4 probe: how much of an LDS fragment read overlaps with MFMA work on the same SIMD?  Every wave runs the inner loop of the conv / GEMM kernels in
+// isolation -- per iteration 16 independent v_mfma_f32_16x16x32 (a 4 x 4 outer product of fragments) and NR conflict-free ds_read_b128 that refill
+// the OTHER fragment set (software pipeline of depth one, 2 MFMAs : 1 read like conv3x3_halo3_kernel) -- with no barriers, no DMA, no epilogue.
+// NR = 0 is the bare MFMA rate; 8 is the convs' ratio (0.5 reads per MFMA); 16 reads every fragment twice.  WPS = waves per SIMD (1, 2 or 4).
+template <int NR, int WPS>
+__global__ __launch_bounds__(256 * WPS) void mfma_lds_probe_kernel(float* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef const volatile __attribute__((address_space(3))) h16x8_t* vfrag_ptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // 8 KiB per wave: eight 1-KiB fragments, lane l at byte 16 l (conflict-free for ds_read_b128 whatever the lane grouping)
+        h16x8_t v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (short)f_to_h16(0.25f + 0.001f * (float)((lane * 8 + e) % 97));
+        for (int f = 0; f < 8; ++f) *(h16x8_t*)(smem + wave * 8192 + f * 1024 + lane * 16) = v;
+    }
+    __syncthreads();
+    const unsigned base = (unsigned)(unsigned long long)smem + (unsigned)(wave * 8192 + lane * 16);
+    h16x8_t fa[2][4], fb[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { fa[s][f] = *(vfrag_ptr)(base + f * 1024); fb[s][f] = *(vfrag_ptr)(base + (4 + f) * 1024); }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto step = [&](auto curc) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(curc)::value, NXT = CUR ^ 1;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            if (f < (NR + 1) / 2 && NR <= 8) fa[NXT][f] = *(vfrag_ptr)(base + f * 1024);
+            if (f < NR / 2 && NR <= 8) fb[NXT][f] = *(vfrag_ptr)(base + (4 + f) * 1024);
+            if (NR > 8) {
+                fa[NXT][f] = *(vfrag_ptr)(base + f * 1024);
+                fb[NXT][f] = *(vfrag_ptr)(base + (4 + f) * 1024);
+                const h16x8_t t0 = *(vfrag_ptr)(base + f * 1024), t1 = *(vfrag_ptr)(base + (4 + f) * 1024);
+                asm volatile("" ::"v"(t0), "v"(t1));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma_16x16x32(fa[CUR][i], fb[CUR][j], acc[i][j]);
+        if (NR > 0) {
+            constexpr int PER = NR >= 16 ? 1 : NR >= 8 ? 2 : NR >= 4 ? 4 : 8;  // MFMAs per read
+#pragma unroll
+            for (int q = 0; q < 16 / PER; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int i = 0; i < iters; ++i) {
+        step(IC<0>{});
+        step(IC<1>{});
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += acc[i][j].x + acc[i][j].y + acc[i][j].z + acc[i][j].w;
+    out[(long long)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int NR, int WPS>
+static double run_lds_probe(int ncu, hipStream_t s) {
+    const int threads = 256 * WPS, lds = 96 * 1024;  // (96 KiB: one workgroup per CU)
+    (void)hipFuncSetAttribute((const void*)mfma_lds_probe_kernel<NR, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    float* out = nullptr;
+    if (hipMalloc((void**)&out, (size_t)ncu * threads * sizeof(float)) != hipSuccess) return -1.0;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const double flop_per_iter = (double)ncu * 4 * WPS * 32 /*mfma per double step*/ * 2.0 * 16 * 16 * 32;
+    int iters = 2000;
+    double best = -1.0;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0, s);
+        hipLaunchKernelGGL((mfma_lds_probe_kernel<NR, WPS>), dim3(ncu), dim3(threads), lds, s, out, iters);
+        (void)hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess) { best = -1.0; break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms <= 0.f) break;
+        const double tf = flop_per_iter * iters / (ms * 1e-3) / 1e12;
+        if (rep > 0 && tf > best) best = tf;
+        if (rep == 0) {
+            iters = (int)(iters * 10.0 / ms);
+            if (iters < 100) iters = 100;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(out);
+    return best;
+}
+// TFLOP/s of the probe with `reads` ds_read_b128 per 16 MFMAs (0, 2, 4, 8, 16) at `wps` waves per SIMD (1, 2, 4); < 0 on error / bad arguments
+double mfma_lds_probe_tflops(int reads, int wps, hipStream_t s) {
+    int dev = 0, ncu = 256;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount;
+#define GP_PROBE(R, W) if (reads == R && wps == W) return run_lds_probe<R, W>(ncu, s);
+    GP_PROBE(0, 1) GP_PROBE(2, 1) GP_PROBE(4, 1) GP_PROBE(8, 1) GP_PROBE(16, 1)
+    GP_PROBE(0, 2) GP_PROBE(2, 2) GP_PROBE(4, 2) GP_PROBE(8, 2) GP_PROBE(16, 2)
+    GP_PROBE(0, 4) GP_PROBE(2, 4) GP_PROBE(4, 4) GP_PROBE(8, 4) GP_PROBE(16, 4)
+#undef GP_PROBE
+    return -1.0;
+}
+
 // returns measured TFLOP/s (< 0 on error); ~ms_target milliseconds of MFMA work on every CU, two waves per SIMD
 double mfma_peak_tflops(int ms_target, hipStream_t s, int shape) {  // shape 0: 32x32x16, 1: 16x16x32
     int dev = 0, ncu = 256;

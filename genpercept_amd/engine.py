@@ -120,9 +120,11 @@ SYMBOLS = {
     "gp_cross_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "gp_resize_max_res_size": (None, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "gp_preprocess": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "gp_preprocess_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "gp_postprocess": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "gp_mfma_peak_tflops": (C.c_double, [_i, _vp]),
     "gp_mfma_peak_tflops_shape": (C.c_double, [_i, _i, _vp]),
+    "gp_mfma_lds_probe": (C.c_double, [_i, _i, _i, _vp]),
     "gp_cross_attention_fold": (_i, [_vp] * 9 + [_i, _i, _i, _f, _vp]),
     "gp_softmax_rows": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "gp_softmax_rows_f16": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
@@ -567,7 +569,7 @@ def cross_attention(q: torch.Tensor, kc: torch.Tensor, vc: torch.Tensor) -> torc
     return out
 
 
-RESAMPLE_CODE = {"bilinear": 0, "nearest-exact": 1}  # what the device resize implements (bicubic stays on the host path)
+RESAMPLE_CODE = {"bilinear": 0, "nearest-exact": 1, "bicubic": 2}  # image_util.py:108-126: everything get_tv_resample_method accepts
 
 
 def resize_max_res_size(h0: int, w0: int, max_edge: int):
@@ -577,18 +579,32 @@ def resize_max_res_size(h0: int, w0: int, max_edge: int):
     return h.value, w.value
 
 
-def preprocess(rgb_u8: torch.Tensor, size, resample: str = "bilinear") -> torch.Tensor:
-    """resize_max_res of a uint8 [B,3,H0,W0] image ON THE DEVICE to size = (h, w) (image_util.py:75-105; uint8 in, uint8 out)."""
+def preprocess(rgb: torch.Tensor, size, resample: str = "bilinear", normalize: bool = False) -> torch.Tensor:
+    """resize_max_res of a [B,3,H0,W0] image ON THE DEVICE to size = (h, w) (image_util.py:75-105).  uint8 in -> uint8 out (fp32 interpolation,
+    rounded: what the reference does to the PIL / uint8 input); float in -> fp32 out without rounding, and with `normalize` the
+    x / 255 * 2 - 1 of genpercept_pipeline.py:245 on top (the [-1, 1] image the engine takes as fp32)."""
     lib = load_library()
-    assert rgb_u8.is_cuda and rgb_u8.dtype == torch.uint8 and rgb_u8.dim() == 4 and rgb_u8.shape[1] == 3
-    rgb_u8 = rgb_u8.contiguous()
-    b, _, h0, w0 = rgb_u8.shape
+    assert rgb.is_cuda and rgb.dim() == 4
+    b, c, h0, w0 = rgb.shape
     h, w = int(size[0]), int(size[1])
-    if (h, w) == (h0, w0):
-        return rgb_u8
-    out = torch.empty((b, 3, h, w), dtype=torch.uint8, device=rgb_u8.device)
-    tmp = torch.empty((b * 3 * h0 * w,), dtype=torch.float32, device=rgb_u8.device) if resample == "bilinear" else None
-    st = lib.gp_preprocess(rgb_u8.data_ptr(), b, h0, w0, out.data_ptr(), h, w, RESAMPLE_CODE[resample], _ptr(tmp), _stream_ptr(rgb_u8.device))
+    same = (h, w) == (h0, w0)
+    need_tmp = not same and resample != "nearest-exact"
+    if rgb.dtype == torch.uint8:
+        assert c == 3 and not normalize
+        rgb = rgb.contiguous()
+        if same:
+            return rgb
+        out = torch.empty((b, 3, h, w), dtype=torch.uint8, device=rgb.device)
+        tmp = torch.empty((b * 3 * h0 * w,), dtype=torch.float32, device=rgb.device) if need_tmp else None
+        st = lib.gp_preprocess(rgb.data_ptr(), b, h0, w0, out.data_ptr(), h, w, RESAMPLE_CODE[resample], _ptr(tmp), _stream_ptr(rgb.device))
+    else:
+        rgb = rgb.to(torch.float32).contiguous()
+        if same and not normalize:
+            return rgb
+        out = torch.empty((b, c, h, w), dtype=torch.float32, device=rgb.device)
+        tmp = torch.empty((b * c * h0 * w,), dtype=torch.float32, device=rgb.device) if need_tmp else None
+        st = lib.gp_preprocess_f32(rgb.data_ptr(), b, c, h0, w0, out.data_ptr(), h, w, RESAMPLE_CODE[resample], int(bool(normalize)), _ptr(tmp),
+                                   _stream_ptr(rgb.device))
     if st != GP_OK:
         raise RuntimeError(f"gp_preprocess failed ({st})")
     return out
@@ -617,7 +633,7 @@ def postprocess(pred: torch.Tensor, size, resample: str = "bilinear", cmap: Opti
     b, c, h, w = pred.shape
     ho, wo = int(size[0]), int(size[1])
     out = torch.empty((b, c, ho, wo), dtype=torch.float32, device=pred.device)
-    tmp = torch.empty((b * c * h * wo,), dtype=torch.float32, device=pred.device) if (resample == "bilinear" and (h, w) != (ho, wo)) else None
+    tmp = torch.empty((b * c * h * wo,), dtype=torch.float32, device=pred.device) if (resample != "nearest-exact" and (h, w) != (ho, wo)) else None
     lut = colormap_lut(cmap, pred.device) if cmap is not None else None
     col = torch.empty((b, ho, wo, 3), dtype=torch.uint8, device=pred.device) if cmap is not None else None
     q = torch.empty((b, c, ho, wo), dtype=torch.uint16 if q_bits == 16 else torch.uint8, device=pred.device) if q_bits else None
@@ -636,6 +652,11 @@ def mfma_peak_tflops(device: int = 0, precision: Optional[str] = None) -> float:
 def mfma_peak_tflops_shape(device: int = 0, shape: int = 0, precision: Optional[str] = None) -> float:
     """the same for one MFMA shape: 0 = v_mfma_f32_32x32x16, 1 = v_mfma_f32_16x16x32 (the conv / GEMM kernels' instruction)"""
     return float(load_library(precision).gp_mfma_peak_tflops_shape(device, shape, _stream_ptr()))
+
+
+def mfma_lds_probe(device: int = 0, reads_per_16_mfma: int = 8, waves_per_simd: int = 2, precision: Optional[str] = None) -> float:
+    """TFLOP/s of 16 MFMAs + `reads_per_16_mfma` ds_read_b128 per wave and iteration (gp_mfma_lds_probe): the conv inner loop in isolation"""
+    return float(load_library(precision).gp_mfma_lds_probe(device, reads_per_16_mfma, waves_per_simd, _stream_ptr()))
 
 
 def cross_attention_fold(y: torch.Tensor, U: torch.Tensor, u0: torch.Tensor, G: torch.Tensor, c0: torch.Tensor, g3: torch.Tensor, b3: torch.Tensor,

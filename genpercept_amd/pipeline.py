@@ -475,20 +475,27 @@ class GenPerceptPipeline:
 
     def _run(self, rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt, opts=None) -> List[GenPerceptOutput]:
         from .engine import RESAMPLE_CODE
-        if rgb.dtype == torch.uint8 and resample in RESAMPLE_CODE and not os.environ.get("GENPERCEPT_HOST_PREPOST"):
+        if (rgb.dtype == torch.uint8 or rgb.is_floating_point()) and resample in RESAMPLE_CODE and not os.environ.get("GENPERCEPT_HOST_PREPOST"):
             return self._run_device(rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt, opts)
         return self._run_host(rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt, opts)
 
     def _run_device(self, rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt, opts=None) -> List[GenPerceptOutput]:
-        """Pre / post processing on the GPU (gp_preprocess / gp_postprocess): the uint8 image goes up once, resize_max_res, the model, the
-        resize back to the input size, clip, colour map and the 8-bit image all run on the device; pred_np and the coloured bytes come down."""
+        """Pre / post processing on the GPU (gp_preprocess / gp_postprocess): the image goes up once, resize_max_res, the model, the
+        resize back to the input size, clip, colour map and the 8-bit image all run on the device; pred_np and the coloured bytes come down.
+        uint8 images (PIL input) stay uint8 up to the engine's prologue; float tensors (genpercept_trainer.py:1151-1165) are resized in fp32
+        without rounding and normalised to [-1, 1] by gp_preprocess_f32, with the reference's range assertion (genpercept_pipeline.py:247)."""
         from . import engine as ge
         input_size = rgb.shape
         if color_map is not None:
             assert self.mode in ["depth", "disparity"]
         x = rgb.to(self._device, non_blocking=True)
-        if processing_res > 0:
-            x = ge.preprocess(x, ge.resize_max_res_size(int(input_size[-2]), int(input_size[-1]), int(processing_res)), resample)
+        size_in = tuple(int(v) for v in input_size[-2:])
+        size_p = ge.resize_max_res_size(size_in[0], size_in[1], int(processing_res)) if processing_res > 0 else size_in
+        if x.dtype == torch.uint8:
+            x = ge.preprocess(x, size_p, resample)
+        else:
+            x = ge.preprocess(x, size_p, resample, normalize=True)
+            assert float(x.amin()) >= -1.0 and float(x.amax()) <= 1.0
         pred = self._predict(x, fix_timesteps, prompt, opts)
         self._warn_if_saturated()
         size = tuple(int(v) for v in input_size[-2:]) if match_input_res else tuple(pred.shape[-2:])
@@ -513,7 +520,8 @@ class GenPerceptPipeline:
         return outs
 
     def _run_host(self, rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt, opts=None) -> List[GenPerceptOutput]:
-        """The same steps with the resizes / colour map on the host (torch CPU + matplotlib): float inputs and bicubic resampling."""
+        """The same steps with the resizes / colour map on the host (torch CPU + matplotlib): GENPERCEPT_HOST_PREPOST=1, and the A/B reference of
+        the device path in tests/test_prepost_gpu.py."""
         input_size = rgb.shape
         if processing_res > 0:
             rgb = resize_max_res(rgb, max_edge_resolution=processing_res, resample_method=resample)

@@ -146,12 +146,18 @@ gp_status gp_reset_timings(gp_engine* e);
 int gp_get_launch_log(gp_engine* e, char* buf, int cap);
 
 /* ---- pre / post processing of GenPerceptPipeline.__call__ on the device (DEVICE pointers, NCHW) ---------------------------------
- * resample: 0 = bilinear with antialias (torchvision resize(..., antialias=True): ATen's separable triangle filter), 1 = nearest-exact.
- * tmp: DEVICE fp32 scratch for the separable bilinear pass, >= B * C * H_in * W_out floats (unused for nearest-exact). */
+ * resample (genpercept/util/image_util.py:108-126): 0 = bilinear with antialias (torchvision resize(..., antialias=True): ATen's separable
+ * triangle filter), 1 = nearest-exact, 2 = bicubic with antialias (the same index ranges, Keys cubic a = -0.5; uint8 results clamped).
+ * tmp: DEVICE fp32 scratch for the separable passes, >= B * C * H_in * W_out floats (unused for nearest-exact). */
 /* new size of resize_max_res (genpercept/util/image_util.py:75-105): longest edge -> max_edge, int() truncation */
 void gp_resize_max_res_size(int H0, int W0, int max_edge, int* h, int* w);
 /* resize_max_res on the uint8 RGB [B][3][H0][W0] -> [B][3][h][w] uint8 (fp32 interpolation, round half to even; genpercept_pipeline.py:236-242) */
 gp_status gp_preprocess(const void* rgb_u8, int B, int H0, int W0, void* out_u8, int h, int w, int resample, float* tmp, void* stream);
+/* The same for FLOAT images (a float `input_image` tensor, e.g. the trainer's `rgb_int`, genpercept_trainer.py:1151-1165): fp32 [B][C][H0][W0]
+ * -> [B][C][h][w] fp32, no rounding and no clamp (torchvision's float path; skipped when the sizes are equal), then with normalize != 0
+ * x / 255 * 2 - 1 in that operation order (genpercept_pipeline.py:245) -- the [-1, 1] image gp_infer takes with is_u8 = 0. */
+gp_status gp_preprocess_f32(const float* rgb, int B, int C, int H0, int W0, float* out, int h, int w, int resample, int normalize, float* tmp,
+                            void* stream);
 /* genpercept_pipeline.py:301-329 + run.py:449-455: pred fp32 [B][C][h][w] -> resize to (Ho, Wo) (skipped when equal) -> clip to [0, 1]
  * -> pred_out fp32 [B][C][Ho][Wo]; optionally colored_out uint8 [B][Ho][Wo][3] through the 256 x 3 byte colour LUT lut_dev (C == 1), and
  * q_out = (pred_out * 65535).astype(uint16) (q_bits 16) or (pred_out * 255).astype(uint8) (q_bits 8), [B][C][Ho][Wo]. */
@@ -165,6 +171,11 @@ double gp_mfma_peak_tflops(int device, void* stream);
  * instruction moves a quarter of the accumulator registers per flop).  The chip runs against its power budget, so the two sustain different
  * clocks on the same data. */
 double gp_mfma_peak_tflops_shape(int device, int shape, void* stream);
+/* Measurement probe (r4): TFLOP/s of the conv / GEMM inner loop in isolation -- per wave and iteration 16 independent
+ * v_mfma_f32_16x16x32 plus `reads_per_16_mfma` (0, 2, 4, 8 or 16) conflict-free ds_read_b128 refilling the other fragment set -- at
+ * `waves_per_simd` (1, 2 or 4) waves per SIMD on every CU; no barriers, DMA or epilogue.  Tells how much of a fragment read's LDS -> register
+ * return overlaps with matrix work on the same SIMD.  < 0 on error or unsupported arguments. */
+double gp_mfma_lds_probe(int device, int reads_per_16_mfma, int waves_per_simd, void* stream);
 
 /* ---- per-kernel entry points (DEVICE pointers, bf16 NHWC activations) -------------------------------------------- */
 /* Pack an OIHW fp32 HOST weight into the device layout [n_rows][taps][cin_pad] bf16 (n_rows = gp_packed_rows(cout)). */

@@ -165,3 +165,28 @@ def test_conv_halo4_layouts_are_conflict_free():
     for add in (0, 16):
         for h in (0, 1):
             assert conflicts(lambda l: ((l >> 2) + add) * 8 + ((2 * (l & 3) + h) ^ f((l >> 2) + add))) == 0
+
+
+def test_conv_halo5_layouts_are_conflict_free():
+    """conv_halo5.hip: 64-byte halo / weight rows read by v_mfma_f32_16x16x32 fragments (lane = row a + 16 q, q = 16-byte slot), 128-byte
+    epilogue staging rows written per (pixel, 8-channel group) and read back per (pixel, 8-channel slot)."""
+    text = src("conv_halo5.hip")
+    assert "return 3 * ((hx >> 2) & 1);" in text and "return 3 * ((row >> 3) & 1);" in text
+    assert "return ((px >> 1) & 1) | ((px & 1) << 1) | (px & 4);" in text
+    key = lambda hx: 3 * ((hx >> 2) & 1)  # noqa: E731
+    for hy in range(18):
+        for kx in range(3):
+            assert conflicts(lambda l: (hy * 18 + (l & 15) + kx) * 4 + ((l >> 4) ^ key((l & 15) + kx))) == 0, (hy, kx)
+    wkey = lambda r: 3 * ((r >> 3) & 1)  # noqa: E731
+    for wn in range(2):
+        for i in range(4):
+            row = lambda a: wn * 64 + 32 * (i >> 1) + 4 * (i & 1) + 8 * (a >> 2) + (a & 3)  # noqa: E731
+            assert conflicts(lambda l: row(l & 15) * 4 + ((l >> 4) ^ wkey(row(l & 15)))) == 0, (wn, i)
+    f = lambda px: ((px >> 1) & 1) | ((px & 1) << 1) | (px & 4)  # noqa: E731
+    for ib in (0, 1):
+        assert write_conflicts(lambda l: (l & 15) * 8 + ((2 * (l >> 4) + ib) ^ f(l & 15))) == 0
+    for t in (0, 1):
+        assert conflicts(lambda l: (l >> 2) * 8 + ((2 * (l & 3) + t) ^ f(l >> 2))) == 0
+    # the plain keys conflict: (hx >> 2) & 3 on the halo rows, px & 7 on the staging read-back
+    assert sum(conflicts(lambda l: ((l & 15) + kx) * 4 + ((l >> 4) ^ ((((l & 15) + kx) >> 2) & 3))) for kx in range(3)) > 0
+    assert sum(conflicts(lambda l: (l >> 2) * 8 + ((2 * (l & 3) + t) ^ ((l >> 2) & 7))) for t in (0, 1)) > 0

@@ -147,6 +147,112 @@ def test_model_matches_source():
         assert line in s, line
 
 
+# ---- conv3x3_halo5_kernel (conv_halo5.hip): same ring, no fragment prefetch -- step s reads tile s, issues tile s+2 ------------------------------
+
+def simulate_halo5(cpt, ntiles, a_it=3, b_it=1, extra_barrier=True):
+    nchunks = cpt * ntiles
+    nsteps = 9 * nchunks
+    fifo = [[] for _ in range(NW)]
+    done = [set() for _ in range(NW)]
+    certified = set()
+    last_read_step = {}
+
+    def issue(w, res, n, step):
+        fifo[w].extend([res] * n)
+        prev = ("W", res[1] - 3) if res[0] == "W" else ("H", res[1] - 2)
+        if prev in last_read_step:   # a read in step t is over for EVERY wave only at the barrier that ends step t
+            assert last_read_step[prev] < step, f"{res} issued in step {step} while {prev} is still read in step {last_read_step[prev]}"
+
+    def wait(w, n):
+        keep = fifo[w][len(fifo[w]) - n:] if n else []
+        for r in fifo[w][:len(fifo[w]) - n] if n else fifo[w]:
+            if r not in keep:
+                done[w].add(r)
+        fifo[w] = list(keep)
+
+    def barrier():
+        for r in set.intersection(*done):
+            certified.add(r)
+
+    def read(res, step, what):
+        assert res in certified, f"step {step}: {what} reads {res} before it is certified (cpt {cpt}, tiles {ntiles})"
+        last_read_step[res] = max(last_read_step.get(res, -1), step)
+
+    for w in range(NW):  # prologue: halo 0, tiles 0 and 1; vmcnt(B_IT); barrier
+        issue(w, ("H", 0), a_it, -1)
+        issue(w, ("W", 0), b_it, -1)
+        issue(w, ("W", 1), b_it, -1)
+        wait(w, b_it)
+    barrier()
+    for s in range(nsteps):
+        c, tap = divmod(s, 9)
+        cc = c % cpt
+        tile_end = cc == cpt - 1
+        final = tile_end and c == nchunks - 1
+        issue_w = not (final and tap >= 7)
+        issue_h = tap == 0 and not final
+
+        def dma(w):
+            if issue_w:
+                issue(w, ("W", s + 2), b_it, s)
+            if issue_h:
+                issue(w, ("H", c + 1), a_it, s)
+        dma_first = [w >= NW // 2 and not (tap == 8 and tile_end) for w in range(NW)]
+        for w in range(NW):
+            if dma_first[w]:
+                dma(w)
+        read(("W", s), s, "fragments")
+        read(("H", c), s, "fragments")
+        if tap == 8 and tile_end:
+            # the epilogue's staging window is this chunk's halo buffer: WITHOUT the extra barrier a fast wave would write it while a slow wave
+            # (held up issuing its DMA) has not read its last fragments yet -- modelled as a read one step later than any write may begin
+            if not extra_barrier:
+                raise AssertionError("epilogue staging may overwrite halo rows a slower wave still has to read")
+            for w in range(NW):
+                wait(w, 0)
+        for w in range(NW):
+            if not dma_first[w]:
+                dma(w)
+        if tap == 8 and final:
+            break
+        for w in range(NW):
+            if tap <= 1:
+                wait(w, a_it + b_it if not final else b_it)
+            elif tap < 7:
+                wait(w, b_it)
+            elif tap == 7:
+                wait(w, 0 if final else b_it)
+            elif not tile_end:
+                wait(w, b_it)
+        barrier()
+    return nsteps
+
+
+@pytest.mark.parametrize("cpt", [2, 3, 4, 8, 16])
+@pytest.mark.parametrize("ntiles", [1, 2, 3])
+def test_halo5_ring_protocol_is_safe(cpt, ntiles):
+    simulate_halo5(cpt, ntiles)
+
+
+def test_halo5_model_detects_a_weaker_wait_and_matches_source():
+    code = open(__file__).read().split("def simulate_halo5(")[1].split("\n@pytest")[0]
+    ns = {}
+    exec("NW = 8\ndef simulate_halo5(" + code.replace("            elif tap < 7:\n                wait(w, b_it)", "            elif tap < 7:\n                wait(w, 2 * b_it)"), ns)
+    with pytest.raises(AssertionError):
+        ns["simulate_halo5"](2, 2)
+    s = open(os.path.join(ROOT, "genpercept_amd", "csrc", "conv_halo5.hip")).read()
+    for line in ["const bool issue_w = !(final_ && TAP >= 7), issue_h = TAP == 0 && !final_;",
+                 "const bool dma_first = second_half && !(TAP == 8 && tile_end);",
+                 "if (issue_w) stage_w((TAP + 2) % 3, adv);",
+                 "if (TAP <= 1) { if (!final_) wait_vm<A_IT + B_IT>(); else wait_vm<B_IT>(); }",
+                 "else if (TAP < 7) wait_vm<B_IT>();",
+                 "else if (TAP == 7) { if (final_) wait_vm<0>(); else wait_vm<B_IT>(); }",
+                 "else if (!tile_end) wait_vm<B_IT>();",
+                 "__builtin_amdgcn_s_barrier();  // every wave holds its last fragments",
+                 "stage_w(1, w_step);\n    wait_vm<B_IT>();"]:
+        assert line in s, line
+
+
 # ---- persistent GEMM (pgemm.hip): 3-deep ring over the (tile, k) step stream ----------------------------------------------------------
 def simulate_pgemm(nk, ntiles, lps=6, nb=3):
     total = nk * ntiles
