@@ -234,6 +234,15 @@ def main(argv=None, engine_factory=None, device=None):
         eng.set_profile(0)
         peak_meas = ge.mfma_peak_tflops(local_rank, args.precision) if rank == 0 else None
         peak_meas16 = ge.mfma_peak_tflops_shape(local_rank, 1, args.precision) if rank == 0 else None  # the dominant kernel's own MFMA shape
+        # the dominant kernel's inner loop in isolation (gp_mfma_lds_probe, ~10 ms each): 16 MFMAs + 8 fragment reads per wave at two waves per SIMD,
+        # alone / with the per-step barrier, the weight stream and the halo stream of the real kernel (constant operand bits: an upper bound)
+        loop_probe = None
+        if rank == 0:
+            try:
+                loop_probe = {"mfma_and_fragment_reads": round(ge.mfma_lds_probe(local_rank, 8, 2, 0, args.precision), 1),
+                              "plus_barrier_weight_and_halo_streams": round(ge.mfma_lds_probe(local_rank, 8, 2, 19, args.precision), 1)}
+            except Exception:
+                loop_probe = None
         scale = (args.res / 768.0) ** 2 * ((TFLOP_PER_IMAGE_768_DPT / TFLOP_PER_IMAGE_768) if dpt else 1.0)
         if tm["ms_halo"] > 0:
             ach = tm["flops_halo"] / (tm["ms_halo"] * 1e-3) / 1e12
@@ -258,6 +267,7 @@ def main(argv=None, engine_factory=None, device=None):
                         "peak_measured": round(peak_meas, 1) if peak_meas and peak_meas > 0 else None,
                         "frac_of_measured_peak": round(ach / peak_meas, 4) if peak_meas and peak_meas > 0 else None,
                         "peak_measured_16x16x32": round(peak_meas16, 1) if peak_meas16 and peak_meas16 > 0 else None,
+                        "inner_loop_probe": loop_probe,
                         "traffic": traffic, "traffic_note": traffic_note,
                         "launches": tm["n_halo"], "flops_per_launch_avg": tm["flops_halo"] / max(tm["n_halo"], 1),
                         "avg_launch_ms": tm["ms_halo"] / max(tm["n_halo"], 1), "sum_ms": round(tm["ms_halo"], 3),

@@ -384,6 +384,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     // ---- fetch state: the tile whose halo is being staged / normalised (one chunk ahead of the compute) ----------------------------
     constexpr int T_IT = (HROWS * 8 + 511) / 512;
     constexpr bool fused = FUSED != 0;
+    // r4: LDS-DMA through buffer resources (common.h blds16: buffer_load_dwordx4 ... offen lds) -- per DMA instruction a 32-bit lane offset and a
+    // uniform offset instead of a 64-bit pointer per lane (no v_lshl_add_u64 / select per piece), and zero padding comes from the range check
+    // instead of a pointer to a zero page.  In the isolated loop (tools/mfma_lds_probe.py, modes 3 / 11 and 7 / 15) the MUBUF form is 1.4-2.8 %
+    // faster than global_load_lds.  ABL & 65536 (GP_HALO_ABLATIONS builds): the FLAT form of r2 / r3.
+    constexpr bool MUBUF = !(ABL & 65536);
+    const buf_rsrc_t in_rs = make_rsrc(in_b, (unsigned)Hi * (unsigned)Wi * (unsigned)Cin * 2u);
+    const buf_rsrc_t w_rs = make_rsrc(p.wt, (unsigned)p.n_rows * (unsigned)p.ldw * 2u);
     int h_off[A_IT];
     unsigned h_ok = 0, t_ok = 0;
     auto setup_fetch = [&](int sp) __attribute__((always_inline)) {
@@ -400,6 +407,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
             const int iy = sy0 + hy, ix = sx0 + hx;
             const bool ok = r < HROWS && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
             h_off[i] = (iy * Wi + ix) * Cin + (((lane_o & 7) ^ halo_key<UPS>(hx)) << 3);
+            if (MUBUF) h_off[i] = ok ? (int)((unsigned)h_off[i] * 2u) : (int)0xfffffff0u;  // byte offset; past the image: the buffer load returns zeros (the padding)
             if (ok) h_ok |= 1u << i;
         }
         if (fused) {
@@ -414,8 +422,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     const h16_t* zsrc_a = p.zero;
     const int chunk_w = (lane & 7) ^ (((lane >> 4) & 1) | ((wave & 1) << 1) | (((wave >> 1) & 1) << 2));
     const h16_t* wq[B_IT];
+    unsigned w_lane[B_IT], w_uni = 0;  // MUBUF: byte offset of this lane's (row, 16-byte slot) and the running (tile, chunk, tap) offset, wave-uniform
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) wq[i] = p.wt + (long long)(n0 + (wave + NW * i) * 8 + (lane >> 3)) * p.ldw + chunk_w * 8;
+    for (int i = 0; i < B_IT; ++i) {
+        wq[i] = p.wt + (long long)(n0 + (wave + NW * i) * 8 + (lane >> 3)) * p.ldw + chunk_w * 8;
+        w_lane[i] = (unsigned)(((n0 + (wave + NW * i) * 8 + (lane >> 3)) * p.ldw + chunk_w * 8) * 2);
+    }
     const int w_step = Cin, w_wrap = 64 - 8 * Cin, w_tile_wrap = -8 * Cin - (cpt - 1) * 64;  // next tap / next chunk / first tile again
 
     if (fused) {
@@ -490,17 +502,26 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int g = wave + NW * i;
-            const h16_t* src = ((h_ok >> i) & 1u) ? in_b + (h_off[i] + (cc << 6)) : zsrc_a;
-            if (!(ABL & 8)) glds16(src, g < G::GROUPS ? dst + g * 1024 : dump);
+            if (MUBUF) {
+                if (!(ABL & 8)) blds16(in_rs, (unsigned)h_off[i], (unsigned)(cc << 7), g < G::GROUPS ? dst + g * 1024 : dump);
+            } else {
+                const h16_t* src = ((h_ok >> i) & 1u) ? in_b + (h_off[i] + (cc << 6)) : zsrc_a;
+                if (!(ABL & 8)) glds16(src, g < G::GROUPS ? dst + g * 1024 : dump);
+            }
         }
     };
     auto stage_w = [&](int slot, int adv) __attribute__((always_inline)) {  // next weight tile in (tile, chunk, tap) order, then advance by `adv` elements
         char* dst = b_lds + slot * B_STAGE;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            if (!(ABL & 16)) glds16(wq[i], dst + (wave + NW * i) * 1024);
-            wq[i] += adv;
+            if (MUBUF) {
+                if (!(ABL & 16)) blds16(w_rs, w_lane[i], w_uni, dst + (wave + NW * i) * 1024);
+            } else {
+                if (!(ABL & 16)) glds16(wq[i], dst + (wave + NW * i) * 1024);
+                wq[i] += adv;
+            }
         }
+        if (MUBUF) w_uni += (unsigned)(adv * 2);
     };
 
     f32x4_t acc[FN][FM];
@@ -898,6 +919,8 @@ bool conv_halo_applicable(const IGemmParams& p) {
     } else if (p.Ho != p.Hi || p.Wo != p.Wi) return false;
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
     if (((ncols + 127) / 128) * 128 > p.n_rows) return false;  // the kernels read whole 128-row weight tiles
+    // 32-bit byte offsets into one image / the packed weight (buffer-resource DMA of conv3x3_halo3_kernel)
+    if ((long long)p.Hi * p.Wi * p.Cin * 2 >= 0xfffffff0ll || (long long)p.n_rows * p.ldw * 2 >= 0xfffffff0ll) return false;
     return p.Ho >= 16 && p.Wo >= 16;
 }
 
@@ -929,6 +952,7 @@ static void launch_halo3(const IGemmParams& p, int grid, hipStream_t s) {
     else if (((p.dbg >> 26) & 3) == 2) launch_halo3_one<false, 0, 16384>(p, grid, s);   // traffic -- no weight fragments / no pixel fragments / neither
     else if (((p.dbg >> 26) & 3) == 3) launch_halo3_one<false, 0, 24576>(p, grid, s);   // (MFMAs, DMA, waits, barriers, epilogue unchanged; garbage results)
     else if ((p.dbg >> 30) & 1) launch_halo3_one<false, 0, 32768>(p, grid, s);          // r4 (bit 30): every fragment read issued twice
+    else if ((p.dbg >> 31) & 1) launch_halo3_one<false, 0, 65536>(p, grid, s);          // r4 (bit 31): LDS-DMA as global_load_lds (r2 / r3) instead of MUBUF
     else if (abl == 4) launch_halo3_one<false, 0, 4>(p, grid, s);
     else if (abl == 8) launch_halo3_one<false, 0, 8>(p, grid, s);
     else if (abl == 16) launch_halo3_one<false, 0, 16>(p, grid, s);

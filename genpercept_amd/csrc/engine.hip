@@ -2088,9 +2088,9 @@ double gp_mfma_peak_tflops_shape(int device, int shape, void* stream) {
     return mfma_peak_tflops(20, (hipStream_t)stream, shape);
 }
 
-double gp_mfma_lds_probe(int device, int reads_per_16_mfma, int waves_per_simd, void* stream) {
+double gp_mfma_lds_probe(int device, int reads_per_16_mfma, int waves_per_simd, int mode, void* stream) {
     if (hipSetDevice(device) != hipSuccess) return -1.0;
-    return mfma_lds_probe_tflops(reads_per_16_mfma, waves_per_simd, (hipStream_t)stream);
+    return mfma_lds_probe_tflops(reads_per_16_mfma, waves_per_simd, mode, (hipStream_t)stream);
 }
 
 gp_status gp_softmax_rows(const float* in, void* out, int rows, int T, int ld, float scale, void* stream) {

@@ -210,4 +210,4 @@ void launch_quantize(const float* x, void* q, long long n, int bits, hipStream_t
 
 // microbench.hip: sustained TFLOP/s of back-to-back v_mfma_f32_32x32x16 on this chip (register operands, all CUs), or < 0 on error
 double mfma_peak_tflops(int ms_target, hipStream_t s, int shape = 0);
-double mfma_lds_probe_tflops(int reads_per_16_mfma, int waves_per_simd, hipStream_t s);  // shape 0: v_mfma_f32_32x32x16, 1: 16x16x32
+double mfma_lds_probe_tflops(int reads_per_16_mfma, int waves_per_simd, int mode, hipStream_t s);  // shape 0: v_mfma_f32_32x32x16, 1: 16x16x32

@@ -32,7 +32,7 @@ struct PGemmGeom {
 // NB: ring depth (stages in flight ahead of the compute).  3 everywhere in r2 / r3; r4: 4 for the 128-row tile (4 x 32 KiB), whose launches are the
 // latency-bound ones -- M = 2304 / 9216 with one or two tiles per workgroup and 10-40 K-steps each, ~1.5 us per K-step against 0.2 us of MFMA work:
 // with a prefetch distance of three steps a stage has 1.5x as long to arrive.
-// ABL: compile-time ablations for profiling (2: no MFMA, 4: no output stores, 8: no DMA)
+// ABL: compile-time ablations for profiling (1: LDS-DMA as global_load_lds, the r2 / r3 form; 2: no MFMA, 4: no output stores, 8: no DMA)
 template <int BM, int ABL = 0, int NB = 3>
 __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
     using G = PGemmGeom<BM, NB>;
@@ -92,9 +92,33 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
     const long long a_wrap = (long long)tile_adv * p.lda - (nk - 1) * 64;
     const int w_wrap = -(nk - 1) * 64;
     const h16_t* zsrc = p.zero;
+    // r4: LDS-DMA through buffer resources (common.h blds16; conv_halo.hip has the measurement: 2-4 % on every conv shape): a 32-bit lane offset
+    // (row, 16-byte slot) + the k offset as the uniform operand, no 64-bit pointer arithmetic per piece; rows past M / past n_rows are past the
+    // resource's size, so the hardware's range check writes the zeros the pointer-to-a-zero-page select used to fetch.  ABL & 1: the FLAT form.
+    constexpr bool MUBUF = !(ABL & 1);
+    const buf_rsrc_t a_rs = make_rsrc(p.in, (unsigned)(((long long)(p.M - 1) * p.lda + p.Cin) * 2));
+    const buf_rsrc_t w_rs = make_rsrc(p.wt, (unsigned)((long long)p.n_rows * p.ldw * 2));
+    unsigned a_lane[A_IT], w_lane[B_IT], k_uni = 0;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) a_lane[i] = (unsigned)(im0 + (wave + 8 * i) * 8 + (lane >> 3)) * (unsigned)(p.lda * 2) + (unsigned)(chunk_a * 16);
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) w_lane[i] = (unsigned)(n0 + (wave + 8 * i) * 8 + (lane >> 3)) * (unsigned)(p.ldw * 2) + (unsigned)(chunk_w * 16);
+    const unsigned a_tile_adv = (unsigned)tile_adv * (unsigned)(p.lda * 2);
     auto stage = [&](int slot) __attribute__((always_inline)) {  // next stage in (tile, k) order into ring slot `slot`
         char* sb = smem + slot * STAGE;
         const bool wrap = ikt == nk - 1;
+        if (MUBUF) {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                if (!(ABL & 8)) blds16(a_rs, a_lane[i], k_uni, sb + (wave + 8 * i) * 1024);
+                if (wrap) a_lane[i] += a_tile_adv;
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i)
+                if (!(ABL & 8)) blds16(w_rs, w_lane[i], k_uni, sb + A_BYTES + (wave + 8 * i) * 1024);
+            if (wrap) { ikt = 0; k_uni = 0; } else { ++ikt; k_uni += 128u; }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const h16_t* src = ((a_ok >> i) & 1u) ? aq[i] : zsrc;
@@ -495,6 +519,8 @@ bool pgemm_applicable(const IGemmParams& p) {
     if (p.vt_out && ((p.vt_col0 & 127) || (p.vt_T & 15) || (p.vt_Tpad & 7) || p.vt_col0 != p.n_store || p.res || p.stats_out || p.act != GP_ACT_NONE ||
                      p.bias_mode != GP_BIAS_NONE || p.M % p.vt_T)) return false;
     if (p.ks != 1 || p.batch > 1 || p.out_fp32 || p.bias_mode == GP_BIAS_ROW || p.in_scale) return false;
+    // 32-bit byte offsets into A (incl. the rows of a ragged last tile) and into the packed weight: the buffer-resource DMA
+    if (((long long)p.M + 256) * p.lda * 2 >= 0xfffffff0ll || (long long)p.n_rows * p.ldw * 2 >= 0xfffffff0ll) return false;
     if (p.act == GP_ACT_GEGLU) return !p.res && !p.stats_out && (p.N & 63) == 0 && (p.Cin & 63) == 0 && (p.lda & 7) == 0 && (p.ldw & 7) == 0 &&
                                       (p.ldo & 7) == 0 && (p.n_store & 7) == 0 && p.M >= 256;  // (16-byte output stores)
     if ((p.Cin & 63) || (p.lda & 7) || (p.ldw & 7) || (p.ldo & 7) || (p.n_store & 7)) return false;
@@ -535,12 +561,14 @@ void launch_pgemm(const IGemmParams& p, hipStream_t s) {
     }
     const int abl = (p.dbg >> 9) & 15;  // profiling ablations (GENPERCEPT_IGEMM_DBG = 512 * ABL)
     if (pgemm_bm(p) == 256) {
-        if (abl == 2) launch_pgemm_one<256, 2>(p, ncu, s);
+        if (abl == 1) launch_pgemm_one<256, 1>(p, ncu, s);   // A/B: LDS-DMA as global_load_lds (r2 / r3)
+        else if (abl == 2) launch_pgemm_one<256, 2>(p, ncu, s);
         else if (abl == 4) launch_pgemm_one<256, 4>(p, ncu, s);
         else if (abl == 8) launch_pgemm_one<256, 8>(p, ncu, s);
         else launch_pgemm_one<256, 0>(p, ncu, s);
     } else {
-        if (abl == 2) launch_pgemm_one<128, 2>(p, ncu, s);
+        if (abl == 1) launch_pgemm_one<128, 1, 4>(p, ncu, s);
+        else if (abl == 2) launch_pgemm_one<128, 2>(p, ncu, s);
         else if (abl == 4) launch_pgemm_one<128, 4>(p, ncu, s);
         else if (abl == 8) launch_pgemm_one<128, 8>(p, ncu, s);
         else if (abl == 10) launch_pgemm_one<128, 10>(p, ncu, s);

@@ -124,7 +124,7 @@ SYMBOLS = {
     "gp_postprocess": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "gp_mfma_peak_tflops": (C.c_double, [_i, _vp]),
     "gp_mfma_peak_tflops_shape": (C.c_double, [_i, _i, _vp]),
-    "gp_mfma_lds_probe": (C.c_double, [_i, _i, _i, _vp]),
+    "gp_mfma_lds_probe": (C.c_double, [_i, _i, _i, _i, _vp]),
     "gp_cross_attention_fold": (_i, [_vp] * 9 + [_i, _i, _i, _f, _vp]),
     "gp_softmax_rows": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "gp_softmax_rows_f16": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
@@ -654,9 +654,10 @@ def mfma_peak_tflops_shape(device: int = 0, shape: int = 0, precision: Optional[
     return float(load_library(precision).gp_mfma_peak_tflops_shape(device, shape, _stream_ptr()))
 
 
-def mfma_lds_probe(device: int = 0, reads_per_16_mfma: int = 8, waves_per_simd: int = 2, precision: Optional[str] = None) -> float:
-    """TFLOP/s of 16 MFMAs + `reads_per_16_mfma` ds_read_b128 per wave and iteration (gp_mfma_lds_probe): the conv inner loop in isolation"""
-    return float(load_library(precision).gp_mfma_lds_probe(device, reads_per_16_mfma, waves_per_simd, _stream_ptr()))
+def mfma_lds_probe(device: int = 0, reads_per_16_mfma: int = 8, waves_per_simd: int = 2, mode: int = 0, precision: Optional[str] = None) -> float:
+    """TFLOP/s of 16 MFMAs + `reads_per_16_mfma` ds_read_b128 per wave and iteration (gp_mfma_lds_probe): the conv inner loop in isolation
+    (mode 0) or with barrier / DMA ring / ring reads / halo stream added (mode bits 1 / 2 / 4 / 16; 8 = MUBUF DMA)"""
+    return float(load_library(precision).gp_mfma_lds_probe(device, reads_per_16_mfma, waves_per_simd, mode, _stream_ptr()))
 
 
 def cross_attention_fold(y: torch.Tensor, U: torch.Tensor, u0: torch.Tensor, G: torch.Tensor, c0: torch.Tensor, g3: torch.Tensor, b3: torch.Tensor,

@@ -173,9 +173,12 @@ double gp_mfma_peak_tflops(int device, void* stream);
 double gp_mfma_peak_tflops_shape(int device, int shape, void* stream);
 /* Measurement probe (r4): TFLOP/s of the conv / GEMM inner loop in isolation -- per wave and iteration 16 independent
  * v_mfma_f32_16x16x32 plus `reads_per_16_mfma` (0, 2, 4, 8 or 16) conflict-free ds_read_b128 refilling the other fragment set -- at
- * `waves_per_simd` (1, 2 or 4) waves per SIMD on every CU; no barriers, DMA or epilogue.  Tells how much of a fragment read's LDS -> register
- * return overlaps with matrix work on the same SIMD.  < 0 on error or unsupported arguments. */
-double gp_mfma_lds_probe(int device, int reads_per_16_mfma, int waves_per_simd, void* stream);
+ * `waves_per_simd` (1, 2 or 4) waves per SIMD on every CU.  mode 0: nothing else (how much of a fragment read's LDS -> register return overlaps
+ * with matrix work on the same SIMD); mode bits (8 reads, 2 waves per SIMD only) add the real kernels' other ingredients per 32-MFMA step:
+ * 1 = one s_barrier, 2 = the weight stream (16 KiB per workgroup by LDS-DMA into a 3-deep ring, counted vmcnt), 4 = weight fragments read from
+ * that ring, 8 = the DMA as buffer_load ... lds, 16 = the halo stream (48 KiB per workgroup every ninth step from HBM).  < 0 on error or an
+ * unsupported combination (csrc/microbench.hip lists them). */
+double gp_mfma_lds_probe(int device, int reads_per_16_mfma, int waves_per_simd, int mode, void* stream);
 
 /* ---- per-kernel entry points (DEVICE pointers, bf16 NHWC activations) -------------------------------------------- */
 /* Pack an OIHW fp32 HOST weight into the device layout [n_rows][taps][cin_pad] bf16 (n_rows = gp_packed_rows(cout)). */

@@ -793,3 +793,14 @@ def test_cross_attention_two_token_fold(case, metric_log):
     yo, n3 = e.cross_attention_fold(y.to(d).to(e.act_dtype()), U.to(d).contiguous(), u0.to(d), G.to(d).contiguous(), c0.to(d), g3.to(d), b3.to(d))
     check(f"cross_fold_y{case}", yo, ref_y, metric_log)
     check(f"cross_fold_n3{case}", n3, ref_n3, metric_log)
+
+
+def test_mfma_lds_probe_entry(metric_log):
+    """gp_mfma_lds_probe (measurement probe of DESIGN.md section 5): supported combinations report a plausible rate, others are refused"""
+    from genpercept_amd import engine as ge
+    bare = ge.mfma_lds_probe(0, 0, 2, 0)
+    conv = ge.mfma_lds_probe(0, 8, 2, 0)
+    full = ge.mfma_lds_probe(0, 8, 2, 19)
+    metric_log("mfma_lds_probe", bare=bare, with_reads=conv, with_barrier_dma=full)
+    assert 500.0 < full <= conv * 1.05 and conv <= bare * 1.05 and bare < 2600.0
+    assert ge.mfma_lds_probe(0, 3, 2, 0) < 0 and ge.mfma_lds_probe(0, 8, 1, 19) < 0 and ge.mfma_lds_probe(0, 8, 3, 0) < 0

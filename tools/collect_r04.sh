@@ -9,6 +9,7 @@ cp $O/bench_normal.log profiles/r04_bench_normal_b4_768.json
 cp $O/bench_dpt.log profiles/r04_bench_dpt_b4_768.json
 cp $O/bench_b8.log profiles/r04_bench_depth_b8_768.json
 cp gpurun_out/launch_log_r04_vae_b4_768.txt profiles/r04_launch_log_b4_768.txt
+[ -s $O/mfma_lds_probe.json ] && cp $O/mfma_lds_probe.json profiles/r04_mfma_lds_probe.json
 python3 - <<'PY'
 import json, bench
 d = json.load(open('profiles/r04_bench_depth_b4_768_session.json'))

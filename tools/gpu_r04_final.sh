@@ -61,4 +61,13 @@ timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu --no-fp16 --mode norma
 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu --no-fp16 --head dpt 2>&1 | tail -1 > $O/bench_dpt.log; cut -c1-160 $O/bench_dpt.log
 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu --no-fp16 --batch 8 2>&1 | tail -1 > $O/bench_b8.log; cut -c1-160 $O/bench_b8.log
 timeout 300 python tools/launch_log.py --tag r04 > $O/launch_log_run.log 2>&1; echo "== launch_log exit $?"; tail -n 3 $O/launch_log_run.log
+# pipeline A/B of the LDS-DMA form (r4): the product library (buffer_load ... lds in conv3x3_halo3_kernel and pgemm_kernel) vs the global_load_lds form of
+# r2 / r3 (ablation library of tools/build_kbench_abl.sh: dbg bit 31 for the conv, ABL 1 = 512 for the GEMM), alternating
+if [ -f genpercept_amd/lib/abl/libgenpercept_hip.so ]; then
+  for E in "mubuf:" "flat:GENPERCEPT_HIP_LIB=$ROOTD/genpercept_amd/lib/abl/libgenpercept_hip.so GENPERCEPT_IGEMM_DBG=-2147483136" "mubuf2:" "flat2:GENPERCEPT_HIP_LIB=$ROOTD/genpercept_amd/lib/abl/libgenpercept_hip.so GENPERCEPT_IGEMM_DBG=-2147483136"; do
+    env ${E#*:} timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu --no-fp16 2>&1 | tail -1 > $O/bench_dma_${E%%:*}.log
+    python3 -c "import json; d=json.load(open('$O/bench_dma_${E%%:*}.log')); print('dma ${E%%:*}', d['value'], d['ms_per_step'], d['stages']['ms_encode'], d['stages']['ms_unet'], d['stages']['ms_head'])"
+  done
+fi
+timeout 300 python tools/mfma_lds_probe.py > $O/mfma_lds_probe.json 2> $O/probe.err; echo "== probe exit $?"
 find $O -name "*.csv" -size +3M -delete; find $O -name "*.db" -delete; du -sh $O

@@ -7,4 +7,5 @@ python3 - <<'PY'
 import json
 d = json.load(open("gpurun_out/r04s12/mfma_lds_probe.json"))
 for r in d["rows"]: print(r)
+for r in d["build_up_at_2_waves_per_simd"]: print(r)
 PY
