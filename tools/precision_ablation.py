@@ -43,9 +43,10 @@ def rounder(kind):
 
 
 class Hooks:
-    def __init__(self, W="fp32", X="fp32", O="fp32", T="fp32", P=None):
+    def __init__(self, W="fp32", X="fp32", O="fp32", T="fp32", P=None, winograd=False):
         self.w, self.x, self.o, self.t = rounder(W), rounder(X), rounder(O), rounder(T)
         self.p = rounder(P if P is not None else X)
+        self.winograd = winograd  # r4: the stride-1 3x3 convs (Cin >= 64) as Winograd F(2x2, 3x3) with the TRANSFORMED operands rounded
         self._wcache = {}
 
     def weight(self, sd, key):
@@ -58,7 +59,51 @@ class Hooks:
 def install(h: Hooks):
     """Monkeypatch the oracle's building blocks with rounding versions (same math, same order)."""
 
+    BT = torch.tensor([[1., 0., -1., 0.], [0., 1., 1., 0.], [0., -1., 1., 0.], [0., 1., 0., -1.]])
+    G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]])
+    AT = torch.tensor([[1., 1., 1., 0.], [0., 1., -1., -1.]])
+
+    def winograd_conv(x, w, bias):
+        """F(2x2, 3x3): Y = A^T [ (G g G^T) . (B^T d B) ] A per 4x4 input tile (stride 2), the elementwise products summed over the input channels in
+        fp32 (the MFMA accumulator); what a 16-bit engine has to round are the transformed operands U = G g G^T (once, from the fp32 weight) and
+        V = B^T d B (from the 16-bit activations, AFTER the additions)."""
+        b, c, hh, ww = x.shape
+        he, we = (hh + 1) // 2 * 2, (ww + 1) // 2 * 2
+        xp = F.pad(h.x(x), (1, 1 + we - ww, 1, 1 + he - hh))
+        d = xp.unfold(2, 4, 2).unfold(3, 4, 2)                                   # [b, c, he/2, we/2, 4, 4]
+        V = h.x(torch.einsum("ij,bcyxjk,lk->bcyxil", BT, d, BT))
+        key = (id(w), "wino")
+        if key not in h._wcache:
+            h._wcache[key] = h.w(torch.einsum("ij,ocjk,lk->ocil", G, w, G))     # [o, c, 4, 4]
+        U = h._wcache[key]
+        M = torch.einsum("ocil,bcyxil->boyxil", U, V)
+        Y = torch.einsum("ij,boyxjk,lk->boyxil", AT, M, AT)                      # [b, o, he/2, we/2, 2, 2]
+        out = Y.permute(0, 1, 2, 4, 3, 5).reshape(b, w.shape[0], he, we)[:, :, :hh, :ww]
+        return out + bias[None, :, None, None] if bias is not None else out
+
+    def winograd1d_conv(x, w, bias):
+        """F(2, 3) along x only, direct along y (1.5x fewer multiplications, 4 accumulator sets instead of 16): per output row pair
+        Y[., 2q + {0,1}] = A^T sum_ky [ (G g[ky]) . (B^T d[y + ky, 2q .. 2q+3]) ]"""
+        b, c, hh, ww = x.shape
+        we = (ww + 1) // 2 * 2
+        xp = F.pad(h.x(x), (1, 1 + we - ww, 1, 1))
+        d = xp.unfold(3, 4, 2)                                                    # [b, c, hh+2, we/2, 4]
+        V = h.x(torch.einsum("ij,bcyxj->bcyxi", BT, d))                          # [b, c, hh+2, we/2, 4]
+        key = (id(w), "wino1d")
+        if key not in h._wcache:
+            h._wcache[key] = h.w(torch.einsum("ij,ockj->ocki", G, w))            # [o, c, ky, 4]
+        U = h._wcache[key]
+        M = sum(torch.einsum("oci,bcyxi->boyxi", U[:, :, ky], V[:, :, ky:ky + hh]) for ky in range(3))
+        Y = torch.einsum("ij,boyxj->boyxi", AT, M)                               # [b, o, hh, we/2, 2]
+        out = Y.reshape(b, w.shape[0], hh, we)[:, :, :, :ww]
+        return out + bias[None, :, None, None] if bias is not None else out
+
     def conv(x, sd, p, stride=1, padding=1):
+        w = sd[p + ".weight"]
+        if h.winograd == "1d" and stride == 1 and padding == 1 and w.shape[2] == 3 and w.shape[1] >= 64 and w.shape[0] >= 64:
+            return winograd1d_conv(x, w, sd.get(p + ".bias"))
+        if h.winograd and stride == 1 and padding == 1 and w.shape[2] == 3 and w.shape[1] >= 64 and w.shape[0] >= 64:
+            return winograd_conv(x, w, sd.get(p + ".bias"))
         return F.conv2d(h.x(x), h.weight(sd, p + ".weight"), sd.get(p + ".bias"), stride=stride, padding=padding)
 
     def linear(x, sd, p):
@@ -205,6 +250,13 @@ CONFIGS = [
     ("operands-only-fp16", dict(W="fp16", X="fp16")),                         # floor of ANY engine with fp16 MFMA operands (everything stored fp32)
     ("weights-only-fp16", dict(W="fp16")),
     ("fp16-acts+fp32-weights", dict(X="fp16", O="fp16", T="fp16")),           # (not buildable on MFMA: shows what the weight rounding alone carries)
+    # r4: would Winograd F(2x2, 3x3) for the stride-1 3x3 convs (2.25x fewer MFMA flops) keep the parity?  transformed operands rounded to 16 bits
+    ("winograd-fp32", dict(winograd=True)),                                    # sanity: the transform alone (fp32 reassociation only)
+    ("engine-fp16+winograd", dict(W="fp16", X="fp16", O="fp16", T="fp16", winograd=True)),
+    ("engine-bf16+winograd", dict(W="bf16", X="bf16", O="bf16", T="bf16", winograd=True)),
+    ("winograd1d-fp32", dict(winograd="1d")),                                  # F(2,3) along x only (1.5x fewer flops, 4 accumulator sets)
+    ("engine-fp16+winograd1d", dict(W="fp16", X="fp16", O="fp16", T="fp16", winograd="1d")),
+    ("engine-bf16+winograd1d", dict(W="bf16", X="bf16", O="bf16", T="bf16", winograd="1d")),
 ]
 
 
@@ -212,9 +264,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--px", type=int, default=128)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_precision_ablation.json"))
+    ap.add_argument("--only", default="", help="comma-separated config names (default: all)")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count() or 8)
-    rows = run(CONFIGS, args.px)
+    rows = run([c for c in CONFIGS if not args.only or c[0] in args.only.split(",")], args.px)
+    if args.only and os.path.exists(args.out):  # (re-)measure a few rows: the others stay as they are in the file
+        old = json.load(open(args.out))
+        if old.get("px") == args.px:
+            names = {r["config"] for r in rows}
+            rows = [r for r in old["rows"] if r["config"] not in names] + rows
     json.dump({"px": args.px, "weights": "seeded synthetic, full SD2.1 widths (oracle.synth_state_dict seeds 11 / 12)", "rows": rows},
               open(args.out, "w"), indent=1)
     print("wrote", args.out)
