@@ -1003,7 +1003,11 @@ static int halo_plan(const IGemmParams& p, int* kind) {
     int J = halo3_wgs_per_image(p, halo_ncu());
     const int h4 = (p.dbg >> 20) & 3, h5 = (p.dbg >> 28) & 3;
     *kind = 3;
-    if (h5 != 2 && (h5 == 1 || gp_sw().halo5) && conv_halo5_applicable(p)) {
+    if ((h5 == 3 || gp_sw().wino) && h5 != 2 && conv_halo6_applicable(p)) {  // bits 28-29 = 3: the Winograd kernel (one workgroup per CU, halo3's grid)
+        *kind = 6;
+        return J;
+    }
+    if (h5 != 2 && h5 != 3 && (h5 == 1 || gp_sw().halo5) && conv_halo5_applicable(p)) {
         const int J2 = halo3_wgs_per_image(p, 2 * halo_ncu());  // (every workgroup has at least one tile: capped at the tile count)
         // twice the workgroups quantise the tile count more coarsely (96 x 96 maps, batch 4: 36 tiles on 32 slots = two rounds, against three
         // rounds of 16): without the force bit only where the last round is filled as well as halo3's
@@ -1046,7 +1050,8 @@ void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
     if (halo_persistent(p)) {
         int kind;
         const int J = halo_plan(p, &kind);
-        if (kind == 5) launch_conv_halo5(p, p.B * J, s);
+        if (kind == 6) launch_conv_halo6(p, p.B * J, s);
+        else if (kind == 5) launch_conv_halo5(p, p.B * J, s);
         else if (kind == 4) launch_conv_halo4(p, p.B * J, s);
         else launch_halo3(p, p.B * J, s);
         return;

@@ -68,6 +68,7 @@ void gp_switches_reload() {
     s.no_fin_fuse = flag("GENPERCEPT_NO_FIN_FUSE");
     s.pgemm_ring3 = flag("GENPERCEPT_PGEMM_RING3");       // A/B: the 128-row persistent GEMM with the 3-deep ring of r2 / r3 (default since r4: 4-deep)
     s.halo4_auto = flag("GENPERCEPT_HALO4");              // let the launcher pick the 512-pixel-tile conv where its tile count fits (off: r4 kbench has it 5 % behind halo3)      // GroupNorm statistics finalised by their own launch again
+    s.wino = flag("GENPERCEPT_WINO");                     // Winograd F(2,3)-along-x conv (conv_halo6.hip) where it applies
     s.halo5 = flag("GENPERCEPT_HALO5");                   // two-workgroups-per-CU conv (conv_halo5.hip) where it applies
     g_switches = s;
 }

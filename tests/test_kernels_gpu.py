@@ -795,6 +795,63 @@ def test_cross_attention_two_token_fold(case, metric_log):
     check(f"cross_fold_n3{case}", n3, ref_n3, metric_log)
 
 
+# conv_halo6.hip: Winograd F(2, 3) along x (2/3 of the MFMA work); forced through IGemmParams::dbg bits 28-29 = 3; GENPERCEPT_WINO=1 enables it
+@pytest.mark.parametrize("case", HALO5_CASES)
+def test_conv3x3_halo6_winograd_kernel(case, metric_log, monkeypatch):
+    e = _eng()
+    b, h, w, cin, cout, with_res = case
+    g = torch.Generator().manual_seed(sum(int(v) for v in case[:5]) + 6)
+    x = rbf(torch.randn(b, cin, h, w, generator=g))
+    wt = rbf(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, bias, padding=1)
+    res = rbf(torch.randn(ref.shape, generator=g)) if with_res else None
+    if with_res:
+        ref = ref + res
+    d = _dev()
+    args = (e.to_nhwc_bf16(x.to(d)), e.pack_weight(wt, device=d), bias.to(d), cout, 3)
+    kw = dict(residual=e.to_nhwc_bf16(res.to(d)) if with_res else None, tile=5)
+    monkeypatch.setenv("GENPERCEPT_IGEMM_DBG", str(3 << 28))
+    y6 = e.conv2d(*args, **kw)
+    # the transformed operands (V = B^T d, U = G g) are rounded AFTER their additions: per layer 1.3-1.5x the direct conv's mean error (measured);
+    # end to end nothing (profiles/r04_precision_ablation.json, rows *winograd1d*)
+    check(f"conv_halo6{case}", nhwc_to_nchw(y6), ref, metric_log, mean_factor=1.8)
+    monkeypatch.setenv("GENPERCEPT_IGEMM_DBG", str(2 << 28))
+    y3 = e.conv2d(*args, **kw)
+    dlt = (nhwc_to_nchw(y6) - nhwc_to_nchw(y3)).abs().max().item()
+    metric_log(f"conv_halo6_vs_halo3{case}", max_abs=dlt)
+    assert dlt <= 6 * _tol16()[0] * ref.abs().max().item()  # (the transformed operands are rounded after their additions)
+    monkeypatch.setenv("GENPERCEPT_IGEMM_DBG", str(3 << 28))
+    for _ in range(2):
+        assert torch.equal(e.conv2d(*args, **kw), y6)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 64, 128, 128, True), (1, 40, 72, 64, 192, False), (4, 144, 160, 64, 128, True), (1, 17, 33, 64, 320, True)])
+def test_conv_halo6_groupnorm_statistics(case, metric_log, monkeypatch):
+    monkeypatch.setenv("GENPERCEPT_IGEMM_DBG", str(3 << 28))
+    e = _eng()
+    b, h, w, cin, cout, with_res = case
+    groups, eps = 32, 1e-6
+    g = torch.Generator().manual_seed(cin + cout + h + 6)
+    x = rbf(torch.randn(b, cin, h, w, generator=g))
+    wt = rbf(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
+    bias = torch.randn(cout, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(cout, generator=g), 0.3 * torch.randn(cout, generator=g)
+    res = rbf(torch.randn(b, cout, h, w, generator=g)) if with_res else None
+    d = _dev()
+    y, scale, shift = e.conv2d_stats(e.to_nhwc_bf16(x.to(d)), e.pack_weight(wt, device=d), bias.to(d), cout, 3, gamma.to(d), beta.to(d), groups, eps,
+                                     ups=False, residual=e.to_nhwc_bf16(res.to(d)) if with_res else None, tile=5)
+    yg = nhwc_to_nchw(y).float().cpu().reshape(b, groups, -1)
+    mean, var = yg.mean(dim=2), yg.var(dim=2, unbiased=False)
+    cpg = cout // groups
+    sc_ref = gamma[None, :] * (var + eps).rsqrt().repeat_interleave(cpg, dim=1)
+    sh_ref = beta[None, :] - mean.repeat_interleave(cpg, dim=1) * sc_ref
+    e_sc = ((scale.cpu() - sc_ref).abs() / sc_ref.abs().clamp_min(1e-3)).max().item()
+    e_sh = (shift.cpu() - sh_ref).abs().max().item()
+    metric_log(f"conv_halo6_stats{case}", scale_rel=e_sc, shift_abs=e_sh)
+    assert e_sc < 2e-4 and e_sh < 2e-4, (e_sc, e_sh)
+
+
 def test_mfma_lds_probe_entry(metric_log):
     """gp_mfma_lds_probe (measurement probe of DESIGN.md section 5): supported combinations report a plausible rate, others are refused"""
     from genpercept_amd import engine as ge

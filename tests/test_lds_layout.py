@@ -190,3 +190,25 @@ def test_conv_halo5_layouts_are_conflict_free():
     # the plain keys conflict: (hx >> 2) & 3 on the halo rows, px & 7 on the staging read-back
     assert sum(conflicts(lambda l: ((l & 15) + kx) * 4 + ((l >> 4) ^ ((((l & 15) + kx) >> 2) & 3))) for kx in range(3)) > 0
     assert sum(conflicts(lambda l: (l >> 2) * 8 + ((2 * (l & 3) + t) ^ ((l >> 2) & 7))) for t in (0, 1)) > 0
+
+
+def test_conv_halo6_layouts_are_conflict_free():
+    """conv_halo6.hip (Winograd F(2,3) along x): V rows [position][halo row][column pair] of 64 bytes read as 16 consecutive rows starting at a
+    multiple of 8; weight rows like conv_halo5's; staging block [2 rows x 16 px][8 units] written per (patch, 8-channel group) for two pixels."""
+    text = src("conv_halo6.hip")
+    assert "return 3 * ((row >> 2) & 1);" in text and "return 3 * ((row >> 3) & 1);" in text and "return (px >> 1) & 7;" in text
+    for base in range(0, 4 * 18 * 8, 8):
+        assert conflicts(lambda l: (base + (l & 15)) * 4 + ((l >> 4) ^ (3 * (((base + (l & 15)) >> 2) & 1)))) == 0, base
+    for pp in range(2):
+        for wn in range(2):
+            for i in range(4):
+                row = lambda a: pp * 128 + wn * 64 + 32 * (i >> 1) + 4 * (i & 1) + 8 * (a >> 2) + (a & 3)  # noqa: E731
+                assert conflicts(lambda l: row(l & 15) * 4 + ((l >> 4) ^ (3 * ((row(l & 15) >> 3) & 1)))) == 0
+    f = lambda px: (px >> 1) & 7  # noqa: E731
+    wpx = lambda l, e: ((l & 15) >> 3) * 16 + 2 * (l & 7) + e  # noqa: E731
+    for e in (0, 1):
+        for u in (0, 1):
+            assert write_conflicts(lambda l: wpx(l, e) * 8 + ((2 * (l >> 4) + u) ^ f(wpx(l, e)))) == 0
+    for rb in (0, 1):
+        for t in (0, 1):
+            assert conflicts(lambda l: (rb * 16 + (l >> 2)) * 8 + ((2 * (l & 3) + t) ^ f(rb * 16 + (l >> 2)))) == 0

@@ -149,9 +149,11 @@ def test_model_matches_source():
 
 # ---- conv3x3_halo5_kernel (conv_halo5.hip): same ring, no fragment prefetch -- step s reads tile s, issues tile s+2 ------------------------------
 
-def simulate_halo5(cpt, ntiles, a_it=3, b_it=1, extra_barrier=True):
+def simulate_halo5(cpt, ntiles, a_it=3, b_it=1, extra_barrier=True, S=9, transform_steps=(), single_halo_buffer=False):
+    """S steps per chunk (9 taps: conv_halo5.hip; 6 (ky, position pair) steps: conv_halo6.hip, whose raw halo is a single buffer that a
+    transform reads in `transform_steps` of the chunk before)"""
     nchunks = cpt * ntiles
-    nsteps = 9 * nchunks
+    nsteps = S * nchunks
     fifo = [[] for _ in range(NW)]
     done = [set() for _ in range(NW)]
     certified = set()
@@ -159,7 +161,7 @@ def simulate_halo5(cpt, ntiles, a_it=3, b_it=1, extra_barrier=True):
 
     def issue(w, res, n, step):
         fifo[w].extend([res] * n)
-        prev = ("W", res[1] - 3) if res[0] == "W" else ("H", res[1] - 2)
+        prev = ("W", res[1] - 3) if res[0] == "W" else ("H", res[1] - (1 if single_halo_buffer else 2))
         if prev in last_read_step:   # a read in step t is over for EVERY wave only at the barrier that ends step t
             assert last_read_step[prev] < step, f"{res} issued in step {step} while {prev} is still read in step {last_read_step[prev]}"
 
@@ -184,12 +186,14 @@ def simulate_halo5(cpt, ntiles, a_it=3, b_it=1, extra_barrier=True):
         issue(w, ("W", 1), b_it, -1)
         wait(w, b_it)
     barrier()
+    if transform_steps:
+        read(("H", 0), -1, "prologue transform")
     for s in range(nsteps):
-        c, tap = divmod(s, 9)
+        c, tap = divmod(s, S)
         cc = c % cpt
         tile_end = cc == cpt - 1
         final = tile_end and c == nchunks - 1
-        issue_w = not (final and tap >= 7)
+        issue_w = not (final and tap >= S - 2)
         issue_h = tap == 0 and not final
 
         def dma(w):
@@ -197,13 +201,16 @@ def simulate_halo5(cpt, ntiles, a_it=3, b_it=1, extra_barrier=True):
                 issue(w, ("W", s + 2), b_it, s)
             if issue_h:
                 issue(w, ("H", c + 1), a_it, s)
-        dma_first = [w >= NW // 2 and not (tap == 8 and tile_end) for w in range(NW)]
+        dma_first = [w >= NW // 2 and not (tap == S - 1 and tile_end) for w in range(NW)]
         for w in range(NW):
             if dma_first[w]:
                 dma(w)
         read(("W", s), s, "fragments")
-        read(("H", c), s, "fragments")
-        if tap == 8 and tile_end:
+        if not transform_steps:
+            read(("H", c), s, "fragments")
+        elif tap in transform_steps and not final:
+            read(("H", c + 1), s, "input transform")
+        if tap == S - 1 and tile_end:
             # the epilogue's staging window is this chunk's halo buffer: WITHOUT the extra barrier a fast wave would write it while a slow wave
             # (held up issuing its DMA) has not read its last fragments yet -- modelled as a read one step later than any write may begin
             if not extra_barrier:
@@ -213,14 +220,14 @@ def simulate_halo5(cpt, ntiles, a_it=3, b_it=1, extra_barrier=True):
         for w in range(NW):
             if not dma_first[w]:
                 dma(w)
-        if tap == 8 and final:
+        if tap == S - 1 and final:
             break
         for w in range(NW):
             if tap <= 1:
                 wait(w, a_it + b_it if not final else b_it)
-            elif tap < 7:
+            elif tap < S - 2:
                 wait(w, b_it)
-            elif tap == 7:
+            elif tap == S - 2:
                 wait(w, 0 if final else b_it)
             elif not tile_end:
                 wait(w, b_it)
@@ -234,10 +241,27 @@ def test_halo5_ring_protocol_is_safe(cpt, ntiles):
     simulate_halo5(cpt, ntiles)
 
 
+@pytest.mark.parametrize("cpt", [2, 3, 4, 8, 16])
+@pytest.mark.parametrize("ntiles", [1, 2, 3])
+def test_halo6_ring_protocol_is_safe(cpt, ntiles):
+    """conv_halo6.hip: six steps per chunk, two DMA pieces per wave and weight tile, single raw-halo buffer transformed in steps 3 and 4"""
+    simulate_halo5(cpt, ntiles, a_it=3, b_it=2, S=6, transform_steps=(3, 4), single_halo_buffer=True)
+    with pytest.raises(AssertionError):  # the transform one step earlier would read a halo that is not certified yet
+        simulate_halo5(cpt, ntiles, a_it=3, b_it=2, S=6, transform_steps=(2, 3), single_halo_buffer=True)
+    s6 = open(os.path.join(ROOT, "genpercept_amd", "csrc", "conv_halo6.hip")).read()
+    for line in ["const bool issue_w = !(final_ && T >= 4), issue_h = T == 0 && !final_;",
+                 "if (T <= 1) { if (!final_) wait_vm<A_IT + B_IT>(); else wait_vm<B_IT>(); }",
+                 "else if (T < 4) wait_vm<B_IT>();",
+                 "else if (T == 4) { if (final_) wait_vm<0>(); else wait_vm<B_IT>(); }",
+                 "if (T == 3) transform_item(PAR ^ 1, wave * 64 + h6_lane_now());",
+                 "if (T == 4 && wave == 0) transform_item(PAR ^ 1, 512 + h6_lane_now());"]:
+        assert line in s6, line
+
+
 def test_halo5_model_detects_a_weaker_wait_and_matches_source():
     code = open(__file__).read().split("def simulate_halo5(")[1].split("\n@pytest")[0]
     ns = {}
-    exec("NW = 8\ndef simulate_halo5(" + code.replace("            elif tap < 7:\n                wait(w, b_it)", "            elif tap < 7:\n                wait(w, 2 * b_it)"), ns)
+    exec("NW = 8\ndef simulate_halo5(" + code.replace("            elif tap < S - 2:\n                wait(w, b_it)", "            elif tap < S - 2:\n                wait(w, 2 * b_it)"), ns)
     with pytest.raises(AssertionError):
         ns["simulate_halo5"](2, 2)
     s = open(os.path.join(ROOT, "genpercept_amd", "csrc", "conv_halo5.hip")).read()

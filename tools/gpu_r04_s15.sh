@@ -1,0 +1,11 @@
+#!/bin/bash
+# Round-4 GPU session 15: conv3x3_halo6_kernel (Winograd F(2,3) along x): parity tests, then kbench against conv3x3_halo3_kernel, interleaved
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out/r04s15; rm -rf $O; mkdir -p $O
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "halo6" --timeout=300 -p no:cacheprovider > $O/pytest_halo6.log 2>&1; echo "== halo6 tests exit $?"; tail -n 25 $O/pytest_halo6.log | cut -c1-220
+S="conv:4,768,768,128,128 conv:4,384,384,256,256 conv:4,192,192,512,512 conv:4,96,96,512,512 conv:4,768,768,256,128 conv:4,96,96,320,320 conv:4,96,96,640,320"
+for rep in 1 2; do
+  for V in "halo3:$((2<<28))" "halo6:$((3<<28))"; do
+    echo "== ${V%%:*} rep $rep"; GENPERCEPT_IGEMM_DBG=${V##*:} timeout 200 tools/kbench iters=20 cold=1 check=$((rep==1)) $S | grep -vE "^#" | tee -a $O/kbench_${V%%:*}.log
+  done
+done
