@@ -12,8 +12,8 @@
 //
 //   Workgroup tile: 16 x 16 output pixels x 128 channels = 16 rows x 8 column pairs ("patches") x 4 positions.  8 waves = 4 groups of 4 rows x 2
 //        channel halves; a wave owns 64 channels x 32 patches x 4 positions = 4 x 4 x 2 accumulator tiles of v_mfma_f32_16x16x32 (128 registers).
-//   K chunk = 32 input channels; K-step = (ky, position pair): weight tile [2 positions][128 cout][32 cin] = 16 KiB through a 3-deep LDS-DMA ring, six
-//        steps per chunk, 16 MFMAs per wave and step (the direct conv: nine taps x 16 = 144 MFMAs per 32-channel chunk, here 96).
+//   K chunk = 32 input channels; K-step = (ky, position pair) = two weight planes [128 cout][32 cin] of 8 KiB through a ring of SIX plane slots, six
+//        steps per chunk, 16 MFMAs per wave and step; fragments of one plane per register set, the next plane always read under the current one's MFMAs (the direct conv: nine taps x 16 = 144 MFMAs per 32-channel chunk, here 96).
 //   LDS: the raw 18 x 18 halo of a chunk (21 KiB, DMA target, single) -> transformed V[4][18][8] rows of 64 bytes (36 KiB, double-buffered): the
 //        transform of chunk c+1 runs in steps 3 and 4 of chunk c (its halo was certified by the barrier that ended step 2).
 //   Ring / waits / role split / persistence / statistics / epilogue staging: conv3x3_halo5_kernel's (conv_halo5.hip), restated for six steps.
@@ -34,9 +34,9 @@ constexpr int H6_RAW = H6_GROUPS * 1024;               // 21 KiB
 constexpr int H6_VROWS = 4 * 18 * 8;                   // transformed halo: [position][halo row][column pair] rows of 64 bytes
 constexpr int H6_V_BUF = H6_VROWS * 64;                // 36 KiB
 constexpr int H6_V_OFF = H6_RAW;
-constexpr int H6_B_STAGE = 2 * 128 * 64;               // [2 positions][128 cout][32 cin] 16-bit = 16 KiB
+constexpr int H6_PLANE = 128 * 64;                     // one (ky, position) weight plane [128 cout][32 cin] 16-bit = 8 KiB; ring of six
 constexpr int H6_B_OFF = H6_V_OFF + 2 * H6_V_BUF;
-constexpr int H6_DUMP_OFF = H6_B_OFF + 3 * H6_B_STAGE;
+constexpr int H6_DUMP_OFF = H6_B_OFF + 6 * H6_PLANE;
 constexpr int H6_ST_OFF = H6_DUMP_OFF + 1024;          // [8 waves][64 ch][sum, sumsq]
 constexpr int H6_BIAS_OFF = H6_ST_OFF + 4096;          // [128] bias of the workgroup's channel slice
 constexpr int H6_RUN_OFF = H6_BIAS_OFF + 512;          // [128 ch][sum, sumsq] running statistics of the workgroup
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const h16_t* __restri
 }
 
 __global__ __launch_bounds__(512) void conv3x3_halo6_kernel(const IGemmParams p, const h16_t* __restrict__ uw) {
-    constexpr int BN = 128, NW = 8, A_IT = H6_A_IT, B_STAGE = H6_B_STAGE, HW_ = H6_HW, B_IT = 2, V_BUF = H6_V_BUF;
+    constexpr int BN = 128, NW = 8, A_IT = H6_A_IT, PLANE = H6_PLANE, HW_ = H6_HW, B_IT = 2, V_BUF = H6_V_BUF;
     constexpr int FN = 4, FJ = 2;  // per position: 4 x 16 channels (two 32-channel blocks) x 2 x 16 patches (two row pairs)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const raw_lds = smem;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo6_kernel(const IGemmParams p,
         const int row = wave * 16 + (lane >> 2);
         w_lane = ((unsigned)(n0 + row) * (unsigned)(12 * Cin) + (unsigned)(((lane & 3) ^ h6_wkey(row)) << 3)) * 2u;
     }
-    const int w_step = 2 * Cin, w_wrap = 32 - 10 * Cin, w_tile_wrap = -10 * Cin - (cpt - 1) * 32;  // next step / next chunk / first chunk again (elements)
+    const int w_step = Cin, w_wrap = 32 - 11 * Cin, w_tile_wrap = -11 * Cin - (cpt - 1) * 32;  // next plane / next chunk / first chunk again (elements)
 
     const unsigned raw_base = (unsigned)(unsigned long long)raw_lds, v_base = (unsigned)(unsigned long long)(smem + H6_V_OFF);
     const unsigned b_base = (unsigned)(unsigned long long)b_lds;
@@ -141,24 +141,26 @@ __global__ __launch_bounds__(512) void conv3x3_halo6_kernel(const IGemmParams p,
             blds16(in_rs, (unsigned)off[i], (unsigned)(cc << 6), g < H6_GROUPS ? raw_lds + g * 1024 : dump);
         }
     };
-    auto stage_w = [&](int slot, int adv) __attribute__((always_inline)) {  // next weight tile (two planes) in (tile, chunk, step) order, then advance
-        char* dst = b_lds + slot * B_STAGE + wave * 1024;
-        blds16(w_rs, w_lane, w_uni, dst);                                   // position 2 t:     rows wave * 16 .. + 15
-        blds16(w_rs, w_lane, w_uni + (unsigned)(Cin * 2), dst + 8192);      // position 2 t + 1
+    auto stage_plane = [&](int slot, int adv) __attribute__((always_inline)) {  // next weight plane in (tile, chunk, ky, position) order, then advance
+        blds16(w_rs, w_lane, w_uni, b_lds + slot * PLANE + wave * 1024);       // rows wave * 16 .. + 15 of the plane
         w_uni += (unsigned)(adv * 2);
     };
     // ---- B^T d: the raw halo of the chunk just certified -> V buffer `vb`; item = (halo row hy, column pair q, 8-channel slot) --------------------
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) u32x4_t* lds_u4_ptr;
-    auto transform_item = [&](int vb, int item) __attribute__((always_inline)) {
+    struct TItem { u32x4_t d0, d1, d2, d3; };
+    auto transform_load = [&](TItem& t, int item) __attribute__((always_inline)) {
         const int hy = item >> 5, q = (item >> 2) & 7, slot = item & 3;
         const unsigned src = raw_base + (unsigned)((hy * HW_ + 2 * q) * 64 + slot * 16);
-        const u32x4_t d0 = *(lds_u4_ptr)src, d1 = *(lds_u4_ptr)(src + 64), d2 = *(lds_u4_ptr)(src + 128), d3 = *(lds_u4_ptr)(src + 192);
+        t.d0 = *(lds_u4_ptr)src; t.d1 = *(lds_u4_ptr)(src + 64); t.d2 = *(lds_u4_ptr)(src + 128); t.d3 = *(lds_u4_ptr)(src + 192);
+    };
+    auto transform_finish = [&](const TItem& t, int vb, int item) __attribute__((always_inline)) {
+        const int hy = item >> 5, q = (item >> 2) & 7, slot = item & 3;
         u32x4_t v0, v1, v2, v3;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const float a0 = h16_lo(d0[w]), b0 = h16_hi(d0[w]), a1 = h16_lo(d1[w]), b1 = h16_hi(d1[w]);
-            const float a2 = h16_lo(d2[w]), b2 = h16_hi(d2[w]), a3 = h16_lo(d3[w]), b3 = h16_hi(d3[w]);
+            const float a0 = h16_lo(t.d0[w]), b0 = h16_hi(t.d0[w]), a1 = h16_lo(t.d1[w]), b1 = h16_hi(t.d1[w]);
+            const float a2 = h16_lo(t.d2[w]), b2 = h16_hi(t.d2[w]), a3 = h16_lo(t.d3[w]), b3 = h16_hi(t.d3[w]);
             v0[w] = pack_h16x2(a0 - a2, b0 - b2);  // (saturating in the fp16 build: |d0 - d2| may leave the fp16 range where d0, d2 do not)
             v1[w] = pack_h16x2(a1 + a2, b1 + b2);
             v2[w] = pack_h16x2(a2 - a1, b2 - b1);
@@ -171,10 +173,17 @@ __global__ __launch_bounds__(512) void conv3x3_halo6_kernel(const IGemmParams p,
         *(lds_u4_ptr)(dst + 2 * 144 * 64) = v2;
         *(lds_u4_ptr)(dst + 3 * 144 * 64) = v3;
     };
+    auto transform_item = [&](int vb, int item) __attribute__((always_inline)) {
+        TItem t;
+        transform_load(t, item);
+        transform_finish(t, vb, item);
+    };
 
     f32x4_t acc[4][FN][FJ];
 
-    struct Frags { h16x8_t w[2][FN], x[2][FJ]; };
+    // Fragments of ONE position (plane): two register sets.  Step s computes position pair (2 t, 2 t + 1): `f0` (plane 2 s, read during the second
+    // half of step s-1) first, `f1` (plane 2 s + 1, read at the start of step s) second; while the second half runs, f0 is refilled for step s+1.
+    struct HalfFrags { h16x8_t w[FN], x[FJ]; };
     unsigned xb, wb;
     auto frag_bases = [&]() __attribute__((always_inline)) {  // (re)computed after every epilogue: values that live ACROSS it end up in scratch
         const int lane_o = h6_lane_now();
@@ -184,24 +193,21 @@ __global__ __launch_bounds__(512) void conv3x3_halo6_kernel(const IGemmParams p,
         xb = v_base + ((4 * wm + (a15 >> 3)) * 8 + (a15 & 7)) * 64 + ((qk ^ h6_vkey(a15 & 7)) << 4);
     };
     frag_bases();
-    auto load_frags = [&](Frags& f, auto tc, auto parc) __attribute__((always_inline)) {
-        constexpr int T = decltype(tc)::value, PAR = decltype(parc)::value, SLOT = T % 3, KY = T >> 1, P0 = 2 * (T & 1);
+    // plane index PL within the chunk stream (0..11 this chunk, 12 = plane 0 of the next chunk, whose V is the other buffer): ky = (PL % 12) / 4,
+    // position = PL % 4, ring slot PL % 6
+    auto load_half = [&](HalfFrags& f, auto plc, auto parc) __attribute__((always_inline)) {
+        constexpr int PL = decltype(plc)::value, PAR = decltype(parc)::value ^ (PL >= 12 ? 1 : 0), PI = PL % 12, KY = PI >> 2, POS = PI & 3, SLOT = PL % 6;
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
+        for (int i = 0; i < FN; ++i) f.w[i] = lds_frag(wb, SLOT * PLANE + (32 * (i >> 1) + 4 * (i & 1)) * 64);
 #pragma unroll
-            for (int i = 0; i < FN; ++i) f.w[pp][i] = lds_frag(wb, SLOT * B_STAGE + pp * 8192 + (32 * (i >> 1) + 4 * (i & 1)) * 64);
-#pragma unroll
-            for (int j = 0; j < FJ; ++j) f.x[pp][j] = lds_frag(xb, PAR * V_BUF + (((P0 + pp) * 18 + 2 * j + KY) * 8) * 64);
-        }
+        for (int j = 0; j < FJ; ++j) f.x[j] = lds_frag(xb, PAR * V_BUF + ((POS * 18 + 2 * j + KY) * 8) * 64);
     };
-    auto mfma16 = [&](const Frags& f, auto tc) __attribute__((always_inline)) {
-        constexpr int P0 = 2 * (decltype(tc)::value & 1);
+    auto mfma8 = [&](const HalfFrags& f, auto posc) __attribute__((always_inline)) {
+        constexpr int POS = decltype(posc)::value;
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp)
+        for (int i = 0; i < FN; ++i)
 #pragma unroll
-            for (int i = 0; i < FN; ++i)
-#pragma unroll
-                for (int j = 0; j < FJ; ++j) acc[P0 + pp][i][j] = mfma_16x16x32(f.w[pp][i], f.x[pp][j], acc[P0 + pp][i][j]);
+            for (int j = 0; j < FJ; ++j) acc[POS][i][j] = mfma_16x16x32(f.w[i], f.x[j], acc[POS][i][j]);
     };
 
     if (tid < BN) {
@@ -237,6 +243,16 @@ __global__ __launch_bounds__(512) void conv3x3_halo6_kernel(const IGemmParams p,
         const unsigned wk0 = (unsigned)h6_stg_key((aw >> 3) * 16 + 2 * (aw & 7)), wk1 = wk0;  // (px >> 1) & 7 is the same for x = 2 q and 2 q + 1
         float satm = 0.f;
         const unsigned ba = bias_base + (wn * 64 + 8 * qw) * 4;
+        uint4 rv[4];  // residual rows of the block being stored (four output rows of this lane's pixel column), loaded a block ahead
+        auto load_res = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = row_index(rr), col = col0 + 32 * c;
+                rv[rr] = make_uint4(0u, 0u, 0u, 0u);
+                if (m >= 0 && col < p.n_store) rv[rr] = *(const uint4*)(p.res + (long long)m * p.ldres + col);
+            }
+        };
+        if (RES) load_res(0);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int col = col0 + 32 * c;
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo6_kernel(const IGemmParams p,
                     if (m >= 0 && col_ok) {
                         float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                         if (RES) {
-                            const uint4 r4 = *(const uint4*)(p.res + m * p.ldres + col);
+                            const uint4 r4 = rv[2 * jj + rb];
                             v[0] += h16_lo(r4.x); v[1] += h16_hi(r4.x); v[2] += h16_lo(r4.y); v[3] += h16_hi(r4.y);
                             v[4] += h16_lo(r4.z); v[5] += h16_hi(r4.z); v[6] += h16_lo(r4.w); v[7] += h16_hi(r4.w);
                         }
@@ -284,6 +300,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo6_kernel(const IGemmParams p,
                     }
                 }
             }
+            if (RES && c == 0) load_res(1);  // (the statistics reduction below is its cover)
             if (STATS) {  // lanes sharing a slot (lane & 3) -> lanes 0..3; [(wave) * 64 + 32 c + 8 slot + e][sum, sumsq]
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { st_s[e] = slot_sum<4>(st_s[e]); st_q[e] = slot_sum<4>(st_q[e]); }
@@ -344,56 +361,77 @@ __global__ __launch_bounds__(512) void conv3x3_halo6_kernel(const IGemmParams p,
     acc_init();
     setup_fetch(sp_cur);
     stage_halo(0);
-    stage_w(0, w_step);
-    stage_w(1, w_step);
-    wait_vm<B_IT>();     // the raw halo of chunk 0 and the tile of step 0 have landed
+#pragma unroll
+    for (int pl = 0; pl < 5; ++pl) stage_plane(pl, w_step);   // planes 0 .. 4 (cpt >= 2: all of the first chunk)
+    wait_vm<B_IT>();     // the raw halo of chunk 0 and planes 0 .. 2 have landed
     __builtin_amdgcn_s_barrier();
     transform_item(0, tid);
     if (tid < 18 * 32 - 512) transform_item(0, tid + 512);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    HalfFrags f0, f1;
+    load_half(f0, IC<0>{}, IC<0>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave holds plane 0's fragments: step 0 refills that slot (plane 6)
 
     // ---- main loop over (tile, chunk), six unrolled steps each ----------------------------------------------------------------------------
-    // Invariant at the top of step s = (cc, T): the barrier that certified weight tile s (and V of chunk cc) has been passed, tile s+1 is in flight.
-    // The step issues tile s+2 into slot (T + 2) % 3, at T = 0 the raw halo of the next chunk (certified by the barrier that ends step 2, transformed
-    // in steps 3 and 4 into the other V buffer), reads its twelve fragments and runs its 16 MFMAs.
+    // Invariant at the top of step s = (cc, T): f0 holds the fragments of plane 2 s (read during step s-1), planes <= 2 s + 2 are certified, planes
+    // 2 s + 3 and 2 s + 4 in flight.  The step issues planes 2 s + 5 and 2 s + 6 into the slots planes 2 s - 1 and 2 s left at the last barrier, at
+    // T = 0 the raw halo of the next chunk (certified by the barrier that ends step 2, transformed in steps 3 and 4 into the other V buffer), reads
+    // plane 2 s + 1 into f1 at its start (eight MFMAs of cover) and plane 2 s + 2 into f0 under its second half.
     int cc = 0;
     bool tile_end = cpt == 1;
     bool final_ = tile_end && sp_cur + sp_stride >= tiles_sp;
-    Frags f;
     auto kstep = [&](auto tc, auto parc) __attribute__((always_inline)) {
         constexpr int T = decltype(tc)::value, PAR = decltype(parc)::value;
-        const bool issue_w = !(final_ && T >= 4), issue_h = T == 0 && !final_;
+        // planes 2 T + 5 (index 11 of this chunk at T = 3: the walk wraps behind it) and 2 T + 6; the workgroup's last chunk has no planes >= 12
+        const bool issue_a = !(final_ && T >= 4), issue_b = !(final_ && T >= 3), issue_h = T == 0 && !final_;
         const int fcc = tile_end ? 0 : cc + 1;  // chunk (of the fetch tile) staged at step 0
-        const int adv = (T + 2) % 6 == 5 ? (tile_end ? w_tile_wrap : w_wrap) : w_step;
+        const int adv_a = T == 3 ? (tile_end ? w_tile_wrap : w_wrap) : w_step;
         const bool dma_first = second_half && !(T == 5 && tile_end);
         if (dma_first) {
-            if (issue_w) stage_w((T + 2) % 3, adv);
+            if (issue_a) stage_plane((2 * T + 5) % 6, adv_a);
+            if (issue_b) stage_plane((2 * T + 6) % 6, w_step);
             if (issue_h) stage_halo(fcc);
         }
         __builtin_amdgcn_sched_barrier(0);
-        load_frags(f, tc, parc);
-        mfma16(f, tc);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!final_) {  // B^T d of the next chunk (uniform branches)
-            if (T == 3) transform_item(PAR ^ 1, wave * 64 + h6_lane_now());
-            if (T == 4 && wave == 0) transform_item(PAR ^ 1, 512 + h6_lane_now());
+        if (T == 3 && !final_) {
+            // the next chunk's B^T d: the item's four raw reads go out with plane 2 s + 1's fragment reads, its ~70 VALU instructions run next to the
+            // first half's MFMAs
+            TItem ti;
+            const int item = wave * 64 + h6_lane_now();
+            transform_load(ti, item);
+            load_half(f1, IC<2 * T + 1>{}, parc);
+            mfma8(f0, IC<2 * (T & 1)>{});
+            transform_finish(ti, PAR ^ 1, item);
+        } else {
+            load_half(f1, IC<2 * T + 1>{}, parc);
+            mfma8(f0, IC<2 * (T & 1)>{});
         }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool prefetch = !(T == 5 && tile_end);  // (tile end: after the epilogue; the workgroup's last step: nothing follows)
+        if (prefetch) load_half(f0, IC<2 * T + 2>{}, parc);
+        mfma8(f1, IC<2 * (T & 1) + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (T == 4 && !final_ && wave == 0) transform_item(PAR ^ 1, 512 + h6_lane_now());  // the 64 left-over items (uniform branch)
         if (T == 5 && tile_end) {
             __builtin_amdgcn_s_barrier();  // every wave holds its last fragments: the finished chunk's V buffer becomes the staging area
             wait_vm<0>();
             epilogue(v_base + PAR * V_BUF + wave * 4096);
+            if (!final_) load_half(f0, IC<12>{}, parc);  // plane 0 of the next tile (landed: vmcnt(0) above), its V in the other buffer
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!dma_first) {
-            if (issue_w) stage_w((T + 2) % 3, adv);
+            if (issue_a) stage_plane((2 * T + 5) % 6, adv_a);
+            if (issue_b) stage_plane((2 * T + 6) % 6, w_step);
             if (issue_h) stage_halo(fcc);
         }
+        // barrier(s+1): planes 2 s + 3 and 2 s + 4 (and every halo issued before them) must have landed; the two planes of this step and, while it
+        // was issued in step 0 of this chunk, the halo of the next chunk may stay in flight.  The workgroup's last chunk stops issuing: drain.
         if (T == 5 && final_) return;
-        if (T <= 1) { if (!final_) wait_vm<A_IT + B_IT>(); else wait_vm<B_IT>(); }
-        else if (T < 4) wait_vm<B_IT>();
-        else if (T == 4) { if (final_) wait_vm<0>(); else wait_vm<B_IT>(); }
-        else if (!tile_end) wait_vm<B_IT>();  // (tile end: certified by the vmcnt(0) ahead of the epilogue)
+        if (final_ && T >= 3) wait_vm<0>();
+        else if (T <= 1) { if (!final_) wait_vm<A_IT + B_IT>(); else wait_vm<B_IT>(); }
+        else if (!(T == 5 && tile_end)) wait_vm<B_IT>();  // (tile end: certified by the vmcnt(0) ahead of the epilogue)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
