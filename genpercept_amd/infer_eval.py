@@ -132,23 +132,53 @@ def valid_mask_of(depth: np.ndarray, min_depth: float, max_depth: float, eval_cr
 
 def run_inference(pipe, base_dir: str, samples: Sequence[Sequence[str]], output_dir: str, name_mode: FileNameMode, mode: str = "depth",
                   denoise_steps: int = 1, ensemble_size: int = 1, processing_res: int = 0, match_input_res: bool = True,
-                  resample_method: str = "bilinear", fix_timesteps=None, prompt: str = "", rgb_crop: Optional[Callable[[np.ndarray], np.ndarray]] = None) -> List[str]:
-    """infer.py:408-447.  Returns the paths written.  rgb_crop: e.g. kitti_benchmark_crop (applied to the [3, H, W] image)."""
+                  resample_method: str = "bilinear", fix_timesteps=None, prompt: str = "", rgb_crop: Optional[Callable[[np.ndarray], np.ndarray]] = None,
+                  prefetch: int = 2) -> List[str]:
+    """infer.py:408-447.  Returns the paths written.  rgb_crop: e.g. kitti_benchmark_crop (applied to the [3, H, W] image).
+    prefetch > 0: the next `prefetch` images are decoded (and cropped) by a helper thread while the engine works on the current one, and the .npy
+    files are written by another -- the role the DataLoader workers play in the reference's loop; order and results are those of prefetch = 0."""
     written = []
     samples = [s for s in samples if len(s) < 2 or s[1] != "None"]  # kitti_dataset.py:47: entries without ground truth are skipped
-    for s in samples:
-        rgb_rel = s[0]
+
+    def load(rgb_rel):
         img = Image.open(os.path.join(base_dir, rgb_rel)).convert("RGB")
         if rgb_crop is not None:  # KITTI: the benchmark crop is applied to the RGB as well (kitti_dataset.py:70-74)
             img = Image.fromarray(np.ascontiguousarray(np.moveaxis(rgb_crop(np.moveaxis(np.asarray(img), -1, 0)), 0, -1)))
-        out = pipe(img, denoising_steps=denoise_steps, ensemble_size=ensemble_size, processing_res=processing_res, match_input_res=match_input_res,
-                   batch_size=0, color_map=None, show_progress_bar=False, resample_method=resample_method, mode=mode,
-                   fix_timesteps=fix_timesteps, prompt=prompt)
+        return img
+
+    def save(rgb_rel, pred_np):
         scene_dir = os.path.join(output_dir, os.path.dirname(rgb_rel))
         os.makedirs(scene_dir, exist_ok=True)
         save_to = os.path.join(scene_dir, get_pred_name(os.path.basename(rgb_rel), name_mode, suffix=".npy"))
-        np.save(save_to, out.pred_np)
-        written.append(save_to)
+        np.save(save_to, pred_np)
+        return save_to
+
+    def infer(img):
+        return pipe(img, denoising_steps=denoise_steps, ensemble_size=ensemble_size, processing_res=processing_res, match_input_res=match_input_res,
+                    batch_size=0, color_map=None, show_progress_bar=False, resample_method=resample_method, mode=mode,
+                    fix_timesteps=fix_timesteps, prompt=prompt)
+
+    if prefetch <= 0 or len(samples) < 2:
+        for s in samples:
+            written.append(save(s[0], infer(load(s[0])).pred_np))
+        return written
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=1) as loader, ThreadPoolExecutor(max_workers=1) as writer:
+        pending, saves = deque(), []
+        it = iter(samples)
+        for s in it:
+            pending.append((s[0], loader.submit(load, s[0])))
+            if len(pending) > prefetch:
+                break
+        while pending:
+            rgb_rel, fut = pending.popleft()
+            img = fut.result()                       # (a decode error surfaces here, at the image it belongs to)
+            nxt = next(it, None)
+            if nxt is not None:
+                pending.append((nxt[0], loader.submit(load, nxt[0])))
+            saves.append(writer.submit(save, rgb_rel, infer(img).pred_np))
+        written = [f.result() for f in saves]
     return written
 
 

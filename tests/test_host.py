@@ -278,6 +278,16 @@ def test_infer_eval_driver_matches_reference(tmp_path):
     FakePipe.i = 0
     written = ie.run_inference(FakePipe(), str(base), samples, str(outd), ie.FileNameMode.rgb_id, mode="depth")
     assert [os.path.relpath(w, outd) for w in written] == [f"test/room_{i:04d}/pred_{i:04d}.npy" for i in range(3)]
+    # the decode-ahead / write-behind threads change neither order nor results (prefetch = 0 is the plain loop)
+    FakePipe.i = 0
+    outd0 = tmp_path / "pred_serial"
+    written0 = ie.run_inference(FakePipe(), str(base), samples, str(outd0), ie.FileNameMode.rgb_id, mode="depth", prefetch=0)
+    assert [os.path.relpath(w, outd0) for w in written0] == [os.path.relpath(w, outd) for w in written]
+    for a, b in zip(written, written0):
+        assert np.array_equal(np.load(a), np.load(b))
+    FakePipe.i = 0
+    with pytest.raises(FileNotFoundError):  # a missing image surfaces as the loader's exception, not as a hang
+        ie.run_inference(FakePipe(), str(base), samples[:1] + [["test/none.png", "x"]] + samples[1:], str(tmp_path / "pred_bad"), ie.FileNameMode.rgb_id)
     res = ie.evaluate_predictions(str(outd), str(base), samples, dataset="nyu", alignment="least_square", output_dir=str(tmp_path / "eval"))
     assert res["abs_relative_difference"] < 1e-3 and res["delta1_acc"] > 0.999
     assert os.path.exists(tmp_path / "eval" / "eval_metrics-least_square.txt")
