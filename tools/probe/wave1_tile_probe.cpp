@@ -7,6 +7,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probe/wave1_tile_probe.cpp -o tools/probe/wave1_tile_probe ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef short h16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -76,6 +77,86 @@ __global__ __launch_bounds__(256 * WPS) void probe(float* __restrict__ out, int 
     out[(long long)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// conv3x3_halo3_kernel's inner loop (the library's gp_mfma_lds_probe, mode 0): TWO waves per SIMD, per iteration 16 independent v_mfma_f32_16x16x32 on a
+// 64 x 64 register tile (64 accumulators) and NR ds_read_b128 refilling the other fragment set (NR = 8: 0.5 reads per MFMA)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <int NR>
+__global__ __launch_bounds__(512) void probe64(float* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef const volatile __attribute__((address_space(3))) h16x8_t* vfrag_ptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        h16x8_t v;
+        for (int e = 0; e < 8; ++e) v[e] = (short)(0x3c00 + ((lane * 8 + e) % 97));
+        for (int f = 0; f < 8; ++f) *(h16x8_t*)(smem + wave * 8192 + f * 1024 + lane * 16) = v;
+    }
+    __syncthreads();
+    const unsigned base = (unsigned)(unsigned long long)smem + (unsigned)(wave * 8192 + lane * 16);
+    h16x8_t fa[2][4], fb[2][4];
+    for (int s = 0; s < 2; ++s)
+        for (int f = 0; f < 4; ++f) { fa[s][f] = *(vfrag_ptr)(base + f * 1024); fb[s][f] = *(vfrag_ptr)(base + (4 + f) * 1024); }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto step = [&](auto curc) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(curc)::value, NXT = CUR ^ 1;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            if (f < NR / 2) fa[NXT][f] = *(vfrag_ptr)(base + f * 1024);
+            if (f < NR / 2) fb[NXT][f] = *(vfrag_ptr)(base + (4 + f) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[CUR][i]), __builtin_bit_cast(bf16x8_t, fb[CUR][j]), acc[i][j], 0, 0, 0);
+        if (NR > 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int i = 0; i < iters; ++i) {
+        step(IC<0>{});
+        step(IC<1>{});
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += acc[i][j].x + acc[i][j].y + acc[i][j].z + acc[i][j].w;
+    out[(long long)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// sustained mode: launch the kernel back to back for `seconds`, print TFLOP/s per ~0.5 s window with wall-clock stamps (to line up with rocm-smi samples)
+#include <chrono>
+template <typename L>
+static void sustain(const char* name, double flop_per_iter, int seconds, L launch) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    int iters = 1000;
+    { hipEventRecord(e0, 0); launch(iters); hipEventRecord(e1, 0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); iters = (int)(iters * 100.0 / ms); }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (true) {
+        hipEventRecord(e0, 0);
+        for (int k = 0; k < 5; ++k) launch(iters);   // ~0.5 s
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const double now = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+        printf("{\"config\": \"%s\", \"unix_time\": %.2f, \"elapsed_s\": %.2f, \"tflops\": %.1f}\n", name, now, el, flop_per_iter * iters * 5 / (ms * 1e-3) / 1e12);
+        fflush(stdout);
+        if (el > seconds) break;
+    }
+}
+
 template <int NR, int WPS>
 static void run(int ncu) {
     const int threads = 256 * WPS, lds = 128 * 1024;
@@ -100,10 +181,23 @@ static void run(int ncu) {
     printf("{\"reads_per_16_mfma_32x32x16\": %d, \"waves_per_simd\": %d, \"tflops\": %.1f}\n", NR, WPS, best);
     hipFree(out);
 }
-int main() {
+int main(int argc, char** argv) {
     hipDeviceProp_t pr;
     hipGetDeviceProperties(&pr, 0);
     const int ncu = pr.multiProcessorCount;
+    if (argc > 1) {  // sustained runs: wave1_tile_probe <seconds>
+        const int sec = atoi(argv[1]);
+        float* out;
+        hipMalloc(&out, (size_t)ncu * 512 * 4);
+        const int lds = 128 * 1024;
+        (void)hipFuncSetAttribute((const void*)probe<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)probe64<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)probe64<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        sustain("tile64x64_2waves_reads8", (double)ncu * 8 * 32 * 2.0 * 16 * 16 * 32, sec, [&](int it) { hipLaunchKernelGGL((probe64<8>), dim3(ncu), dim3(512), lds, 0, out, it); });
+        sustain("tile128x128_1wave_reads8", (double)ncu * 4 * 32 * 2.0 * 32 * 32 * 16, sec, [&](int it) { hipLaunchKernelGGL((probe<8, 1>), dim3(ncu), dim3(256), lds, 0, out, it); });
+        sustain("tile64x64_2waves_mfma_only", (double)ncu * 8 * 32 * 2.0 * 16 * 16 * 32, sec, [&](int it) { hipLaunchKernelGGL((probe64<0>), dim3(ncu), dim3(512), lds, 0, out, it); });
+        return 0;
+    }
     run<0, 1>(ncu); run<4, 1>(ncu); run<8, 1>(ncu); run<16, 1>(ncu);  // (two waves per SIMD cannot hold 256 accumulators each)
     return 0;
 }
