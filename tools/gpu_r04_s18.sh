@@ -5,6 +5,6 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r04s18; rm -rf $O; mkdir -p $O
 ( while true; do echo "{\"unix_time\": $(date +%s.%N), \"smi\": $(rocm-smi --showpower --showclocks --json 2>/dev/null | tr -d '\n')}" >> $O/smi.jsonl; sleep 0.25; done ) & SMI=$!
-timeout 60 tools/probe/wave1_tile_probe 4 > $O/sustained.jsonl 2> $O/err.log
+timeout 60 tools/probe/wave1_tile_probe 3 > $O/sustained.jsonl 2> $O/err.log
 kill $SMI; wait $SMI 2>/dev/null
 cat $O/sustained.jsonl | tail -30; wc -l $O/smi.jsonl

@@ -80,15 +80,25 @@ __global__ __launch_bounds__(256 * WPS) void probe(float* __restrict__ out, int 
 // conv3x3_halo3_kernel's inner loop (the library's gp_mfma_lds_probe, mode 0): TWO waves per SIMD, per iteration 16 independent v_mfma_f32_16x16x32 on a
 // 64 x 64 register tile (64 accumulators) and NR ds_read_b128 refilling the other fragment set (NR = 8: 0.5 reads per MFMA)
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-template <int NR>
+template <int NR, int RND = 0>
 __global__ __launch_bounds__(512) void probe64(float* __restrict__ out, int iters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef const volatile __attribute__((address_space(3))) h16x8_t* vfrag_ptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
-        h16x8_t v;
-        for (int e = 0; e < 8; ++e) v[e] = (short)(0x3c00 + ((lane * 8 + e) % 97));
-        for (int f = 0; f < 8; ++f) *(h16x8_t*)(smem + wave * 8192 + f * 1024 + lane * 16) = v;
+        for (int f = 0; f < 8; ++f) {
+            h16x8_t v;
+            for (int e = 0; e < 8; ++e) {
+                if (RND) {  // every fragment different: random sign and mantissa, exponent in [2^-4, 2^0) -- what activations / weights look like to the multipliers
+                    unsigned x = (unsigned)(((wave * 8 + f) * 64 + lane) * 8 + e) * 2654435761u;
+                    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+                    v[e] = (short)((x & 0x807f) | ((0x7b + ((x >> 16) & 3)) << 7));
+                } else {
+                    v[e] = (short)(0x3c00 + ((lane * 8 + e) % 97));
+                }
+            }
+            *(h16x8_t*)(smem + wave * 8192 + f * 1024 + lane * 16) = v;
+        }
     }
     __syncthreads();
     const unsigned base = (unsigned)(unsigned long long)smem + (unsigned)(wave * 8192 + lane * 16);
@@ -196,6 +206,11 @@ int main(int argc, char** argv) {
         sustain("tile64x64_2waves_reads8", (double)ncu * 8 * 32 * 2.0 * 16 * 16 * 32, sec, [&](int it) { hipLaunchKernelGGL((probe64<8>), dim3(ncu), dim3(512), lds, 0, out, it); });
         sustain("tile128x128_1wave_reads8", (double)ncu * 4 * 32 * 2.0 * 32 * 32 * 16, sec, [&](int it) { hipLaunchKernelGGL((probe<8, 1>), dim3(ncu), dim3(256), lds, 0, out, it); });
         sustain("tile64x64_2waves_mfma_only", (double)ncu * 8 * 32 * 2.0 * 16 * 16 * 32, sec, [&](int it) { hipLaunchKernelGGL((probe64<0>), dim3(ncu), dim3(512), lds, 0, out, it); });
+        // the same two loops with every fragment holding different random bits (the runs above feed identical fragments: no operand toggling at all)
+        (void)hipFuncSetAttribute((const void*)probe64<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)probe64<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        sustain("random_bits_mfma_only", (double)ncu * 8 * 32 * 2.0 * 16 * 16 * 32, sec, [&](int it) { hipLaunchKernelGGL((probe64<0, 1>), dim3(ncu), dim3(512), lds, 0, out, it); });
+        sustain("random_bits_reads8", (double)ncu * 8 * 32 * 2.0 * 16 * 16 * 32, sec, [&](int it) { hipLaunchKernelGGL((probe64<8, 1>), dim3(ncu), dim3(512), lds, 0, out, it); });
         return 0;
     }
     run<0, 1>(ncu); run<4, 1>(ncu); run<8, 1>(ncu); run<16, 1>(ncu);  // (two waves per SIMD cannot hold 256 accumulators each)
