@@ -34,7 +34,7 @@ GP_DEV unsigned pack_h16x2_ns(float lo, float hi) {
 }
 // Saturation is never silent: a saturating conversion that actually clips sets this TRANSLATION UNIT's flag word (one
 // plain store on the clipping path only); the engine collects the flags of every translation unit into its counter at the end of each call
-// (engine.hip: collect_saturation_kernel; gp_saturation_events / gp_timings.sat_events; the pipeline logs a warning).  Hot epilogues carry
+// (engine.hip: collect_saturation_kernel; gp_saturation_events; the pipeline logs a warning).  Hot epilogues carry
 // the running max |value| of what they pack in a register (sat_track: one v_max3_f32 per pair, no branch) and report once per tile.
 static __device__ unsigned gp_sat_flag;
 GP_DEV float sat_track(float m, float a, float b) { return __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b))); }

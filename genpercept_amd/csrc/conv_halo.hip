@@ -992,50 +992,16 @@ static bool halo_persistent(const IGemmParams& p) {
     const bool slots_ok = (p.n_store & 7) == 0 && (p.ldo & 7) == 0 && (!p.res || ((p.ldres & 7) == 0 && p.ldres >= p.n_store));
     return slots_ok && !(p.dbg & 256);
 }
-// Which persistent kernel takes this problem (*kind = 3, 4 or 5), and with how many workgroups per image (a multiple of tiles_n):
-// conv3x3_halo3_kernel by default; conv3x3_halo4_kernel (32 x 16 tiles, conv_halo4.hip) where it applies, is enabled and fills the grid as well as
-// the 16 x 16 tiling; conv3x3_halo5_kernel (conv_halo5.hip: 16 x 16 tiles, TWO workgroups per CU) where it applies and is enabled.  One function for
-// the launch AND for the statistics-row count the engine allocates.  p.dbg (kbench / tests): bits 20-21 = 1 forces halo4 where it applies, 2 forbids
-// it; bits 28-29 the same for halo5.
-static int halo_plan(const IGemmParams& p, int* kind) {
-    const int ncols = p.N > p.n_store ? p.N : p.n_store;
-    const int tiles_n = (ncols + 127) / 128, tiles_sp = ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
-    int J = halo3_wgs_per_image(p, halo_ncu());
-    const int h4 = (p.dbg >> 20) & 3, h5 = (p.dbg >> 28) & 3;
-    *kind = 3;
-    if ((h5 == 3 || gp_sw().wino) && h5 != 2 && conv_halo6_applicable(p)) {  // bits 28-29 = 3: the Winograd kernel (one workgroup per CU, halo3's grid)
-        *kind = 6;
-        return J;
-    }
-    if (h5 != 2 && h5 != 3 && (h5 == 1 || gp_sw().halo5) && conv_halo5_applicable(p)) {
-        const int J2 = halo3_wgs_per_image(p, 2 * halo_ncu());  // (every workgroup has at least one tile: capped at the tile count)
-        // twice the workgroups quantise the tile count more coarsely (96 x 96 maps, batch 4: 36 tiles on 32 slots = two rounds, against three
-        // rounds of 16): without the force bit only where the last round is filled as well as halo3's
-        const int s3 = J / tiles_n, s5 = J2 / tiles_n;
-        const double e3 = (double)tiles_sp / (double)(((tiles_sp + s3 - 1) / s3) * s3), e5 = (double)tiles_sp / (double)(((tiles_sp + s5 - 1) / s5) * s5);
-        if (h5 == 1 || e5 >= 0.97 * e3) {
-            *kind = 5;
-            return J2;
-        }
-    }
-    if (h4 != 2 && conv_halo4_applicable(p)) {
-        const int t4 = ((p.Wo + 31) / 32) * ((p.Ho + 15) / 16);
-        if (h4 == 1) {
-            *kind = 4;
-            if (J > t4 * tiles_n) J = t4 * tiles_n;  // (every workgroup needs at least one tile)
-        } else if (conv_halo4_preferred(p, J)) {
-            *kind = 4;
-        }
-    }
-    return J;
-}
+// workgroups per image (a multiple of tiles_n) of the persistent kernel: one function for the launch AND for the statistics-row count the engine
+// allocates.  (r4's alternative structures -- 32 x 16 tiles, two workgroups per CU, Winograd F(2,3) along x -- measured 0-10 % slower and live in
+// tools/experiments/ with their tests and profiles since r5.)
+static int halo_plan(const IGemmParams& p) { return halo3_wgs_per_image(p, halo_ncu()); }
 // statistics rows per image the halo kernel will write for this problem (per-workgroup partials + counts, "mode 2"); 0 = one row per
 // 16x16 tile ("mode 1", conv3x3_halo2_kernel)
 int conv_halo_stat_rows(const IGemmParams& p) {
     if (!halo_persistent(p)) return 0;
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
-    int kind;
-    return halo_plan(p, &kind) / ((ncols + 127) / 128);
+    return halo_plan(p) / ((ncols + 127) / 128);
 }
 
 void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
@@ -1048,12 +1014,7 @@ void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
     });
     // (conv_halo_applicable guarantees whole 128-row weight tiles)
     if (halo_persistent(p)) {
-        int kind;
-        const int J = halo_plan(p, &kind);
-        if (kind == 6) launch_conv_halo6(p, p.B * J, s);
-        else if (kind == 5) launch_conv_halo5(p, p.B * J, s);
-        else if (kind == 4) launch_conv_halo4(p, p.B * J, s);
-        else launch_halo3(p, p.B * J, s);
+        launch_halo3(p, p.B * halo_plan(p), s);
         return;
     }
     const int tiles = tiles_sp * p.B * tiles_n;

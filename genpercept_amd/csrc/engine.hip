@@ -1539,13 +1539,6 @@ gp_status gp_get_timings(gp_engine* e, gp_timings* out) {
     if (!e || !out) return GP_ERR_INVALID;
     return guard(e, [&] {
         e->collect_profile();
-        e->tm.sat_events = 0;
-        if (e->sat_dev) {
-            unsigned n = 0;
-            HIPCHK(hipStreamSynchronize(e->st));
-            HIPCHK(hipMemcpy(&n, e->sat_dev, sizeof(n), hipMemcpyDeviceToHost));
-            e->tm.sat_events = (long long)n;
-        }
         *out = e->tm;
     });
 }
@@ -1560,6 +1553,9 @@ gp_status gp_saturation_events(gp_engine* e, long long* events, int reset) {
         if (!e->sat_dev) return;
         HIPCHK(hipSetDevice(e->cfg.device));
         unsigned n = 0;
+        // the flag words are per translation unit, process and device: a per-kernel entry point (gp_conv2d, gp_gemm, ... never collect) or another
+        // engine on this device may have left one set.  Collect before reading so that a reset really starts from clean flags.
+        e->collect_saturation();
         HIPCHK(hipStreamSynchronize(e->st));
         HIPCHK(hipMemcpy(&n, e->sat_dev, sizeof(n), hipMemcpyDeviceToHost));
         *events = (long long)n;

@@ -18,6 +18,7 @@
 //    a lane ends up with 8 consecutive output channels of one pixel: bias is two float4 loaded before the K loop, the
 //    bf16 store is 16 bytes per lane, the residual one 16-byte load.
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 #include "epilogue.h"
@@ -64,13 +65,13 @@ void gp_switches_reload() {
     s.no_pgemm = flag("GENPERCEPT_NO_PGEMM");
     s.gn_apply_old = flag("GENPERCEPT_GN_APPLY_OLD");
     s.xfold_lds = num("GENPERCEPT_XFOLD_LDS", -1);       // 0 = the r2 cross-attention fold kernel
-    s.no_halo4 = flag("GENPERCEPT_NO_HALO4");            // 512-pixel-tile conv off: conv3x3_halo3_kernel everywhere
     s.no_fin_fuse = flag("GENPERCEPT_NO_FIN_FUSE");
     s.pgemm_ring3 = flag("GENPERCEPT_PGEMM_RING3");       // A/B: the 128-row persistent GEMM with the 3-deep ring of r2 / r3 (default since r4: 4-deep)
-    s.halo4_auto = flag("GENPERCEPT_HALO4");              // let the launcher pick the 512-pixel-tile conv where its tile count fits (off: r4 kbench has it 5 % behind halo3)      // GroupNorm statistics finalised by their own launch again
-    s.wino = flag("GENPERCEPT_WINO");                     // Winograd F(2,3)-along-x conv (conv_halo6.hip) where it applies
-    s.halo5 = flag("GENPERCEPT_HALO5");                   // two-workgroups-per-CU conv (conv_halo5.hip) where it applies
-    g_switches = s;
+    // Engines on other host threads read g_switches on their launch paths: write it only when the environment really changed (tests / A/B
+    // scripts, between calls), under a lock, so that concurrent engine creation with an unchanged environment never stores to it.
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (memcmp(&g_switches, &s, sizeof(s)) != 0) g_switches = s;
 }
 
 constexpr bool PRIO = true;   // s_setprio around the MFMA cluster made hipcc wait lgkmcnt(0) before the first MFMA

@@ -61,7 +61,7 @@ struct IGemmParams {
 struct GpSwitches {
     int flash_ring3, no_flash512, f5_dbg, no_conv_few, no_conv_img, conv_img_s, no_cross_fold, no_gn_fusion, gn_fuse_max_slices,
         gn_fuse_below_px, no_stats_fusion, vt_tile, no_gn_small, fp32_scores, no_qkv_fuse, qkv_fuse_max_rows, no_rgb_conv, igemm_dbg, no_splitk,
-        no_halo, no_pgemm, gn_apply_old, xfold_lds, no_halo4, no_fin_fuse, halo4_auto, pgemm_ring3, halo5, wino;
+        no_halo, no_pgemm, gn_apply_old, xfold_lds, no_fin_fuse, pgemm_ring3;
 };
 const GpSwitches& gp_sw();
 void gp_switches_reload();
@@ -74,10 +74,7 @@ void* gp_sat_flag_addr_conv_few();
 void* gp_sat_flag_addr_norm();
 void* gp_sat_flag_addr_attention();
 void* gp_sat_flag_addr_elementwise();
-void* gp_sat_flag_addr_conv_halo4();
-void* gp_sat_flag_addr_conv_halo5();
-void* gp_sat_flag_addr_conv_halo6();
-#define GP_SAT_TUS {gp_sat_flag_addr_igemm, gp_sat_flag_addr_conv_halo, gp_sat_flag_addr_pgemm, gp_sat_flag_addr_conv_few, gp_sat_flag_addr_norm, gp_sat_flag_addr_attention, gp_sat_flag_addr_elementwise, gp_sat_flag_addr_conv_halo4, gp_sat_flag_addr_conv_halo5, gp_sat_flag_addr_conv_halo6}
+#define GP_SAT_TUS {gp_sat_flag_addr_igemm, gp_sat_flag_addr_conv_halo, gp_sat_flag_addr_pgemm, gp_sat_flag_addr_conv_few, gp_sat_flag_addr_norm, gp_sat_flag_addr_attention, gp_sat_flag_addr_elementwise}
 
 // tile_hint: 0 auto (halo conv / persistent GEMM / split-K / generic tile by heuristic), 1 = 128x128, 2 = 64x64, 3 = 256x32, 4 = 256x128,
 //            5 = conv_halo.hip, 6 = 128x64, 7 = pgemm.hip
@@ -108,16 +105,6 @@ bool conv_halo_applicable(const IGemmParams& p);   // includes the Cin <= 2560 l
 void launch_conv_halo(const IGemmParams& p, hipStream_t s);
 bool conv_uses_halo(const IGemmParams& p, int tile_hint);
 int conv_halo_stat_rows(const IGemmParams& p);     // > 0: statistics rows per image (per-workgroup partials + pixel counts, mode 2)
-// conv_halo4.hip: the same convs on 32 x 16-pixel tiles (plain input, no activation); chosen inside launch_conv_halo
-bool conv_halo4_applicable(const IGemmParams& p);
-bool conv_halo4_preferred(const IGemmParams& p, int wgs_per_image);
-void launch_conv_halo4(const IGemmParams& p, int grid, hipStream_t s);
-// conv_halo5.hip: the same convs (halo4's set) on 16 x 16 tiles with TWO workgroups per CU (128 registers per wave, <= 80 KiB LDS each)
-bool conv_halo5_applicable(const IGemmParams& p);
-void launch_conv_halo5(const IGemmParams& p, int grid, hipStream_t s);
-// conv_halo6.hip (r4 experiment): the same convs as Winograd F(2, 3) along x -- 2/3 of the MFMA work; weights transformed on first use
-bool conv_halo6_applicable(const IGemmParams& p);
-void launch_conv_halo6(const IGemmParams& p, int grid, hipStream_t s);
 // Statistics layout launch_igemm(p, tile_hint) will write: mode 0 = rows of BM consecutive pixels, mode 1 = 16x16 halo tiles per image,
 // mode 2 = *bm rows per image, each with its own pixel count appended after the [rows][N][2] sums; returns the number of rows (callers
 // allocate rows * (2 N + 1) floats), or 0 when that kernel path cannot produce stats_out (direct epilogue, GEGLU, fp32 output, ...).

@@ -66,7 +66,7 @@ class GpTimings(C.Structure):
         ("flops_igemm", C.c_double), ("flops_attn", C.c_double),
         ("ms_igemm", C.c_float), ("ms_attn", C.c_float),
         ("n_igemm", C.c_int), ("n_attn", C.c_int), ("n_launches", C.c_int),
-        ("flops_halo", C.c_double), ("ms_halo", C.c_float), ("n_halo", C.c_int), ("sat_events", C.c_longlong),
+        ("flops_halo", C.c_double), ("ms_halo", C.c_float), ("n_halo", C.c_int),
     ]
 
 

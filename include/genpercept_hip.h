@@ -76,8 +76,7 @@ typedef struct gp_timings {
     double flops_halo;                             /* the dominant kernel alone: conv3x3_halo3_kernel (a subset of the igemm figures) */
     float ms_halo;
     int n_halo;
-    long long sat_events;                          /* fp16 library: see gp_saturation_events (same counter, not reset by reading it here) */
-} gp_timings;
+} gp_timings;   /* (frozen layout: new counters get their own entry point, e.g. gp_saturation_events, never a field appended here) */
 
 void gp_default_config(gp_config* cfg);                                  /* SD2.1 values */
 gp_status gp_create(const gp_config* cfg, gp_engine** out);

@@ -1,6 +1,6 @@
 """Range stress of the fp16 library.  fp16 storage overflows at 65504; the reference's own `--half_precision`
 (run.py:273-281) then produces inf / NaN.  This engine's conversions saturate instead -- which must never be SILENT: every call in which a
-conversion actually clipped is counted (`gp_saturation_events`, `gp_timings.sat_events`; the pipeline logs a warning).
+conversion actually clipped is counted (`gp_saturation_events`; the pipeline logs a warning).
 
 Full SD2.1 widths, 64x64 input.  Weights are the benign variance-preserving synthetic ones with ONE tensor scaled so that a chosen class of
 activations leaves the fp16 range in the fp32 oracle (asserted on the oracle's own tensors):
@@ -100,10 +100,9 @@ def test_fp16_saturation_is_never_silent(case, setup, metric_log):
     eng = _engine(setup, usd, vsd)
     try:
         eng.infer(setup["rgb"].to(d), "depth")
-        eng.saturation_events(reset=True)  # (discards flags left behind by per-kernel test entry points earlier in this process)
+        eng.saturation_events(reset=True)  # (collects and discards flags left behind by per-kernel test entry points earlier in this process)
         out = eng.infer(setup["rgb"].to(d), "depth")[0].cpu().numpy()
         events = eng.saturation_events()
-        assert eng.timings()["sat_events"] == events
         assert eng.saturation_events(reset=True) == events and eng.saturation_events() == 0
     finally:
         eng.close()

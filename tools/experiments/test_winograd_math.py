@@ -6,11 +6,11 @@ import re
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def _src():
-    return open(os.path.join(ROOT, "genpercept_amd", "csrc", "conv_halo6.hip")).read()
+    return open(os.path.join(ROOT, "tools", "experiments", "conv_halo6.hip")).read()
 
 
 def test_source_uses_these_transforms():
