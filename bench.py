@@ -24,6 +24,7 @@ inside the timed region, its own cost reported as `gather_ms`.  Rank 0 prints ON
                per-launch-instrumented pass whose ~500 event pairs cost ~7 % and must not leak into `unet_mfma_util`.
 """
 import argparse
+import contextlib
 import json
 import os
 import socket
@@ -102,22 +103,96 @@ def device_sync(dev):
         torch.cuda.synchronize()
 
 
-def timed_steps(step, warmup: int, steps: int, dev):
+class ClockPowerSampler:
+    """Socket power and shader clock of the benched GPU, read from the amdgpu hwmon files while the timed steps run (a thread that sleeps 20 ms
+    between two small sysfs reads: nothing on the launch path).  The pool's boxes differ by more than a round's gains and the chip is
+    power-limited under this load (profiles/r04_power_samples.json), so the line carries the clock / power it was measured at: a +-2 % change
+    can then be told from a slower box.  Every field is null where the files are not readable."""
+
+    def __init__(self, dev):
+        self.rows, self.stop, self.thread, self.files = [], False, None, None
+        try:
+            import glob
+            want = None
+            try:
+                pr = torch.cuda.get_device_properties(torch.device(dev))
+                want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+            except Exception:
+                pass
+            cands = []
+            for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+                pw = next((f for f in (hw + "/power1_average", hw + "/power1_input") if os.path.exists(f)), None)
+                fq = hw + "/freq1_input"
+                if pw and os.path.exists(fq):
+                    bdf = os.path.basename(os.path.realpath(os.path.join(hw, "..", "..")))
+                    cands.append((bdf, pw, fq))
+            pick = [c for c in cands if want and c[0].startswith(want)] or cands
+            if pick:
+                self.files = pick[0]
+        except Exception:
+            self.files = None
+
+    def _run(self):
+        _, pw, fq = self.files
+        while not self.stop:
+            try:
+                self.rows.append((int(open(pw).read()) / 1e6, int(open(fq).read()) / 1e6))
+            except Exception:
+                pass
+            time.sleep(0.02)
+
+    def __enter__(self):
+        if self.files:
+            import threading
+            self.thread = threading.Thread(target=self._run, daemon=True)
+            self.thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        if self.thread:
+            self.thread.join(timeout=1.0)
+
+    def summary(self):
+        if not self.rows:
+            return {"samples": 0, "power_w_mean": None, "sclk_mhz_mean": None, "note": "amdgpu hwmon power1_average / freq1_input not readable here"}
+        pw, fq = [r[0] for r in self.rows], [r[1] for r in self.rows]
+        return {"samples": len(self.rows), "power_w_mean": round(sum(pw) / len(pw), 1), "power_w_max": round(max(pw), 1),
+                "sclk_mhz_mean": round(sum(fq) / len(fq), 1), "sclk_mhz_min": round(min(fq), 1), "source": "amdgpu hwmon (sysfs), every 20 ms over the timed steps"}
+
+
+def timed_steps(step, warmup: int, steps: int, dev, stats: dict = None):
     """The timing contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + device synchronize on both sides; the
-    elapsed time is the MAX over ranks.  Returns (seconds, last step's result)."""
+    elapsed time is the MAX over ranks.  Returns (seconds, last step's result).  With `stats` (a dict) on a GPU, ONE event is recorded per step
+    on the stream the engine launches on (torch's current stream) -- not per launch -- and the per-step durations (this rank's) and the
+    clock / power samples of the timed region are left in it."""
     from genpercept_amd import distributed as gd
     o = None
     for _ in range(warmup):
         o = step()
+    on_gpu = torch.device(dev).type == "cuda"
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if (on_gpu and stats is not None) else None
     device_sync(dev)
     gd.barrier()
     device_sync(dev)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        o = step()
-    device_sync(dev)
-    gd.barrier()
-    return gd.max_over_ranks(time.perf_counter() - t0, dev), o
+    with ClockPowerSampler(dev) if evs is not None else contextlib.nullcontext() as smp:
+        t0 = time.perf_counter()
+        if evs is not None:
+            evs[0].record()
+        for i in range(steps):
+            o = step()
+            if evs is not None:
+                evs[i + 1].record()
+        device_sync(dev)
+        gd.barrier()
+        el = time.perf_counter() - t0
+    if evs is not None:
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+        stats["ms_per_step_min"] = round(per[0], 3)
+        stats["ms_per_step_median"] = round(per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2]), 3)
+        stats["ms_per_step_max"] = round(per[-1], 3)
+        stats["clock_power"] = smp.summary()
+    return gd.max_over_ranks(el, dev), o
 
 
 def main(argv=None, engine_factory=None, device=None):
@@ -202,7 +277,9 @@ def main(argv=None, engine_factory=None, device=None):
             if do_gather:
                 return gd.gather_results(o, n_total, dst=0)  # rank 0: [N*B, C, H, W]; others: None
             return o
-        el, o = timed_steps(step, args.warmup, args.steps, dev)
+        st = {}
+        el, o = timed_steps(step, args.warmup, args.steps, dev, st)
+        timed.stats = st
         if o is not None:
             assert torch.isfinite(o).all()
             if do_gather:
@@ -210,6 +287,7 @@ def main(argv=None, engine_factory=None, device=None):
         return el, o
 
     elapsed, out = timed(eng)
+    step_stats = timed.stats
     ms_per_step = elapsed / args.steps * 1e3
     images = n_total * args.steps
     value = images / elapsed
@@ -294,7 +372,8 @@ def main(argv=None, engine_factory=None, device=None):
         el16, o16 = timed(eng)
         if o16 is not None and rank == 0:
             out0_f16 = o16[0].float().cpu()
-        fp16 = {"value_fp16": round(images / el16, 3), "ms_per_step_fp16": round(el16 / args.steps * 1e3, 3)}
+        fp16 = {"value_fp16": round(images / el16, 3), "ms_per_step_fp16": round(el16 / args.steps * 1e3, 3),
+                "ms_per_step_fp16_min": timed.stats.get("ms_per_step_min"), "ms_per_step_fp16_median": timed.stats.get("ms_per_step_median")}
         if rank == 0:  # the chip's own back-to-back-MFMA rate with fp16 operands (the bf16 figure is roofline.peak_measured): same instruction
             pk16 = ge.mfma_peak_tflops(local_rank, "fp16")  # count, lower sustained clock -- the guide's micro-benchmarks show the same 6-9 % gap
             fp16["peak_measured_fp16"] = round(pk16, 1) if pk16 and pk16 > 0 else None
@@ -342,7 +421,12 @@ def main(argv=None, engine_factory=None, device=None):
         head_name = "DPT disparity head" if dpt else f"{args.mode} head"
         cfg_idx = 3 if dpt else (1 if args.mode == "depth" else 2)
         line = {"metric": f"images/sec at 768x768 bf16 ({'depth' if not dpt and args.mode == 'depth' else head_name})", "value": round(value, 3), "unit": "images/sec", "n_gpus": n_gpus,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+                # per-step durations from one event per step (rank 0's stream) and the clock / power the timed region ran at: resolution below the
+                # pool's box-to-box spread (ms_per_step stays the contract's wall-clock figure, max over ranks)
+                "ms_per_step_min": step_stats.get("ms_per_step_min"), "ms_per_step_median": step_stats.get("ms_per_step_median"),
+                "ms_per_step_max": step_stats.get("ms_per_step_max"), "clock_power": step_stats.get("clock_power"),
+                "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                 "config": {"workload": (f"{head_name}, SD2.1 VAE-enc + UNet(t=1) + " + ("DPT neck/head" if dpt else "VAE-dec") +
                                         f", {args.res}x{args.res}, batch {args.batch}/GPU (BASELINE.json configs[{cfg_idx}]" +

@@ -68,5 +68,53 @@ def build_library(force: bool = False, verbose: bool = True, precisions=("bf16",
     return LIB
 
 
+ASAN_LIB = os.path.join(LIBDIR, "asan", "libgenpercept_hip_asan.so")
+
+
+def asan_runtime() -> str:
+    """clang's shared AddressSanitizer runtime of the ROCm toolchain (LD_PRELOAD it into the process that loads ASAN_LIB)."""
+    import glob
+    c = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not c:
+        raise RuntimeError("libclang_rt.asan-x86_64.so not found under /opt/rocm/lib/llvm")
+    return c[-1]
+
+
+def build_asan_host_library(verbose: bool = False) -> str:
+    """SURVEY.md section 5 ("Race detection / sanitizers"): an `-fsanitize=address` HOST build of the C-ABI shim.  Only the host side is
+    instrumented (`-Xarch_host -fsanitize=address`: the kernels are validated by goldens on the GPU, not by a sanitizer), -O1, same sources and the same header as the
+    product library; tests/test_asan_host.py drives its host paths (argument checks, tensor registration and dtype conversion, struct layouts,
+    error strings, log buffers) under the sanitizer.  Never loaded by the product (`engine.load_library` knows only LIBS)."""
+    hipcc = _hipcc()
+    objdir = os.path.join(LIBDIR, "asan")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [os.path.join(os.path.dirname(HERE), "include", "genpercept_hip.h")]
+    # (device code is compiled too -- unsanitised, -O1: the host objects reference their fat binary, and HIP registers it when the library loads)
+    flags = ["--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fno-omit-frame-pointer",
+             "-Xarch_host", "-g", "-w"]
+    objs, jobs = [], []
+    for src in SOURCES:
+        s, o = os.path.join(CSRC, src), os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(o)
+        if _stale(o, [s] + headers):
+            jobs.append([hipcc, *flags, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4) or 1) as ex:
+        list(ex.map(run, jobs))
+    if jobs or not os.path.exists(ASAN_LIB):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address", "-shared-libsan", *objs, "-o", ASAN_LIB])
+    return ASAN_LIB
+
+
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv))
+    if "--asan" in sys.argv:
+        print(build_asan_host_library(verbose=True))
+    else:
+        print(build_library(force="--force" in sys.argv))

@@ -475,7 +475,10 @@ class GenPerceptPipeline:
 
     def _run(self, rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt, opts=None) -> List[GenPerceptOutput]:
         from .engine import RESAMPLE_CODE
-        if (rgb.dtype == torch.uint8 or rgb.is_floating_point()) and resample in RESAMPLE_CODE and not os.environ.get("GENPERCEPT_HOST_PREPOST"):
+        # device pre / post for uint8 and fp32 images; fp16 / bf16 / fp64 tensors keep the host recipe, which -- like the reference
+        # (genpercept_pipeline.py:240-247, image_util.py:75-105) -- resizes in the tensor's OWN dtype before the normalisation (the
+        # device path would promote them to fp32 first and deviate slightly)
+        if rgb.dtype in (torch.uint8, torch.float32) and resample in RESAMPLE_CODE and not os.environ.get("GENPERCEPT_HOST_PREPOST"):
             return self._run_device(rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt, opts)
         return self._run_host(rgb, processing_res, match_input_res, resample, color_map, fix_timesteps, prompt, opts)
 
@@ -528,7 +531,7 @@ class GenPerceptPipeline:
         if rgb.dtype == torch.uint8:
             rgb_in = rgb  # x/255*2-1 happens in the engine's prologue kernel (same fp32 formula)
         else:
-            rgb_in = rgb.float() / 255.0 * 2.0 - 1.0
+            rgb_in = (rgb / 255.0 * 2.0 - 1.0).float()  # in the tensor's own dtype first, like genpercept_pipeline.py:245
             assert rgb_in.min() >= -1.0 and rgb_in.max() <= 1.0
         pred = self._predict(rgb_in, fix_timesteps, prompt, opts)
         self._warn_if_saturated()

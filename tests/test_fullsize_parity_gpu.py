@@ -29,6 +29,17 @@ MAP_TOL = {"fp16": {"depth": 1e-3, "normal": 1e-3, "disparity": 2e-3}, "bf16": {
 ABSREL_TOL = {"fp16": 4e-3, "bf16": 3e-2}
 # rel-RMS of the same maps: regression gates (~1.5x the simulated engine rows of profiles/r04_precision_ablation.json), NOT the contract
 RELRMS_TOL = {"fp16": {"depth": 8e-3, "normal": 8e-3, "disparity": 8e-3}, "bf16": {"depth": 6e-2, "normal": 6e-2, "disparity": 6e-2}}
+# what the regression-gated tests above measured, keyed (precision, head): read by test_contract_1e3 below (same maps, no second engine run)
+_MEASURED = {}
+# north_star's tolerance itself -- "outputs within 1e-3 rel of the reference" -- per library, head and reading.  Where the build is KNOWN to
+# be outside it the case is xfail(strict=True): the state of the contract is then in the GPU test record (xfailed = known miss, failed = a
+# regression of a case that held, XPASS(strict) = a miss that was fixed and must be promoted), not in prose.  Why the
+# misses cannot be bought back cheaply: profiles/r05_precision_attribution.json (the error is spread evenly over ~84 units; protecting the
+# best 10 % of the FLOPs with split operands moves rel_rms from 5.0e-3 to 3.4e-3).
+CONTRACT = 1e-3
+CONTRACT_KNOWN_MISS = {("fp16", "depth", "rel_rms"), ("fp16", "normal", "rel_rms"), ("fp16", "disparity", "rel_rms"),
+                       ("bf16", "depth", "mean_abs"), ("bf16", "normal", "mean_abs"), ("bf16", "disparity", "mean_abs"),
+                       ("bf16", "depth", "rel_rms"), ("bf16", "normal", "rel_rms"), ("bf16", "disparity", "rel_rms")}
 
 
 def _rel_rms(out, ref):
@@ -110,6 +121,7 @@ def test_768_depth_and_normal_vs_live_oracle(precision, full, metric_log):
             rec = dict(mean_abs=float(err.mean()), max_abs=float(err.max()), rel_rms=_rel_rms(out, ref), absrel_ls=_absrel_ls(out[0], ref[0]))
             rec["within_1e-3_mean_abs"], rec["within_1e-3_rel_rms"] = rec["mean_abs"] <= 1e-3, rec["rel_rms"] <= 1e-3
             metric_log(f"full768_{mode}_vs_oracle[{precision}]", **rec)
+            _MEASURED[(precision, mode)] = (rec["mean_abs"], rec["rel_rms"])
             assert out.shape == ref.shape and np.isfinite(out).all()
             assert rec["mean_abs"] <= MAP_TOL[precision][mode], rec
             assert rec["rel_rms"] <= RELRMS_TOL[precision][mode], rec
@@ -143,11 +155,40 @@ def test_768_dpt_disparity_vs_live_oracle(precision, full, metric_log):
         err = np.abs(out - ref)
         rr = _rel_rms(out, ref)
         metric_log(f"full768_disparity_dpt_vs_oracle[{precision}]", mean_abs=float(err.mean()), max_abs=float(err.max()), rel_rms=rr)
+        _MEASURED[(precision, "disparity")] = (float(err.mean()), rr)
         assert out.shape == ref.shape and np.isfinite(out).all() and abs(float(out.min())) < 1e-6 and abs(float(out.max()) - 1) < 1e-6
         assert float(err.mean()) <= MAP_TOL[precision]["disparity"], float(err.mean())
         assert rr <= RELRMS_TOL[precision]["disparity"], rr
     finally:
         eng.close()
+
+
+def _contract_cases():
+    for prec in ("fp16", "bf16"):
+        for head in ("depth", "normal", "disparity"):
+            for metric in ("mean_abs", "rel_rms"):
+                marks = [pytest.mark.xfail(strict=True, reason=f"known: the {prec} library is outside 1e-3 under {metric} on the {head} map "
+                                                              "(DESIGN.md section 4, profiles/r05_precision_attribution.json)")] \
+                    if (prec, head, metric) in CONTRACT_KNOWN_MISS else []
+                yield pytest.param(prec, head, metric, marks=marks, id=f"{prec}-{head}-{metric}")
+
+
+@pytest.mark.parametrize("precision,head,metric", list(_contract_cases()))
+def test_contract_1e3(precision, head, metric, full, metric_log):
+    """north_star: "depth/normal outputs within 1e-3 rel of the reference" at 768x768, image 0 of the benched batch, vs the live fp32 oracle --
+    asserted AT 1e-3 for every (library, head, reading); known misses are strict xfails (see CONTRACT_KNOWN_MISS)."""
+    if (precision, head) not in _MEASURED:  # (run alone, e.g. with -k: measure here)
+        d = torch.device("cuda", 0)
+        eng = _engine(full, precision, dpt=head == "disparity")
+        try:
+            out = eng.infer(full["rgb8"][:1].to(d), head)[0].cpu().numpy()
+        finally:
+            eng.close()
+        ref = full["ref"][head]
+        _MEASURED[(precision, head)] = (float(np.abs(out - ref).mean()), _rel_rms(out, ref))
+    value = _MEASURED[(precision, head)][0 if metric == "mean_abs" else 1]
+    metric_log(f"contract_1e-3[{precision}-{head}-{metric}]", value=value, within=value <= CONTRACT)
+    assert value <= CONTRACT, f"{precision} {head} {metric} = {value:.3e} > 1e-3"
 
 
 def test_384_image_through_the_pipeline_vs_live_oracle(full, metric_log):

@@ -159,6 +159,14 @@ if rank == 0:
     ok = ok and full.shape == (n_total, 1, 4, 6) and all(float(full[i].mean()) == i for i in range(n_total))
 else:
     ok = ok and full is None
+# second call with other values: the preallocated buffers are reused (same storage on the receiving rank), the values are the new ones
+full2 = gd.gather_results(local_out + 10.0, n_total, dst=0)
+if rank == 0:
+    ok = ok and full2.data_ptr() == full.data_ptr() and all(float(full2[i].mean()) == i + 10.0 for i in range(n_total))
+# equal shards: the receive buffer is the result (a view, no compaction copy)
+eq = gd.gather_results(torch.full((2, 1, 4, 6), float(rank)), 2 * world, dst=None)
+ok = ok and eq.shape[0] == 2 * world and all(float(eq[2 * r].mean()) == r and float(eq[2 * r + 1].mean()) == r for r in range(world))
+ok = ok and len(gd._gatherers) == 3 and not gd._gatherers[((1, 4, 6), torch.float32, "cpu", 2 * world, None)].ragged
 mx = gd.max_over_ranks(float(rank + 1), torch.device("cpu"))
 ok = ok and mx == float(world)
 print("RANK", rank, "OK" if ok else "FAIL", flush=True)
