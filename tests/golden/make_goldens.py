@@ -21,6 +21,8 @@ Fixtures are data (seeds, inputs, expected outputs) — never reference source.
   refexec_tiny.npz   outputs of the REFERENCE's CustomUNet2DConditionModel.forward and GenPerceptPipeline.__call__ / single_infer /
                      encode_rgb / decode_pred EXECUTED over stub diffusers base classes whose blocks are the oracle's functions (tiny configs,
                      the inputs of e2e_tiny.npz / e2e_multistep.npz; needs those two files: run after "e2e" and "multistep").
+  refexec_v1_tiny.npz  outputs of GenPercept_v1's single_infer (pipeline_genpercept.py:263-309: timesteps=[1], pred_latent = -unet_pred) EXECUTED
+                     over the same stub bases, with the v1 tree's own empty_text_embed.npy as context (all 77 rows, and rows [0:2]).
   e2e_multistep.npz  oracle goldens of the multi-step archs (marigold: noise + 8-channel conv_in; rgb_blending) on the tiny configs.
   e2e_tiny.npz       end-to-end goldens of the fp32 oracle (oracle/) on the tiny configs: inputs + expected outputs
                      for every stage (latent, unet out, feats, decode, final) — what the HIP path is checked against
@@ -839,6 +841,80 @@ def make_refexec_golden():
     print("refexec_tiny.npz", os.path.getsize(os.path.join(HERE, "refexec_tiny.npz")) // 1024, "KiB;", len(out), "arrays; oracle == reference-executed on every stage")
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# refexec_v1_tiny.npz: the SECOND statement of the one-step math the reference's tree holds -- GenPercept_v1/genpercept/pipeline_genpercept.py
+# `single_infer` (:263-309: `timesteps = torch.tensor([1])`, `pred_latent = - unet_pred`, no scheduler object at all), `encode_rgb` (:312-336) and
+# `decode_pred` (:338-356) -- EXECUTED over the same stub bases as refexec_tiny.npz.  Its text context is the file the v1 tree
+# ships, GenPercept_v1/empty_text_embed.npy ([77, 1024] fp16: CLIP's embedding of the empty prompt padded to 77 tokens): used whole (what v1 does)
+# and as rows [0:2] (BOS, EOS: what v2's `padding="do_not_pad"` tokenisation produces, genpercept_pipeline.py:360-372 -- SURVEY F6's "[B, 2, 1024]").
+# The UNet is the tiny topology with cross_attention_dim = 1024 so that the real embedding rows are its context.
+# ---------------------------------------------------------------------------------------------------------------------------
+V1 = os.path.join(REF, "GenPercept_v1")
+
+
+def make_refexec_v1_golden():
+    import importlib
+    gpp2, cu, dh, d, saved = _refexec_import()        # v2's custom_unet.py supplies the executed UNet forward (v1 calls a plain diffusers UNet)
+    path0 = list(sys.path)
+    try:
+        for name in [m for m in sys.modules if m == "genpercept" or m.startswith("genpercept.")]:
+            if name != "genpercept.models.custom_unet":
+                del sys.modules[name]
+        sys.path[:] = [V1] + [p for p in sys.path if os.path.abspath(p or ".") != ROOT]
+        v1 = importlib.import_module("genpercept.pipeline_genpercept")
+        assert v1.__file__.startswith(V1)
+        sys.path[:] = path0
+        embed = np.load(os.path.join(V1, "empty_text_embed.npy"))
+        assert embed.shape == (77, 1024) and embed.dtype == np.float16
+        uc = osd.UNetCfg(block_out_channels=(64, 128, 256, 256), num_heads=(1, 2, 4, 4), cross_attention_dim=1024)
+        vc = osd.VAECfg.tiny()
+        usd = osd.synth_state_dict(osd.unet_manifest(uc), 21)
+        vsd = osd.synth_state_dict(osd.vae_manifest(vc), 2)
+        e2e = np.load(os.path.join(HERE, "e2e_tiny.npz"))
+
+        class VAE:  # pipeline_genpercept.py:327-328,352-353 call vae.encoder / quant_conv / post_quant_conv / decoder separately
+            @staticmethod
+            def encoder(x):
+                sd_ = dict(vsd)
+                sd_["quant_conv.weight"] = torch.eye(2 * vc.latent_channels)[:, :, None, None]
+                sd_["quant_conv.bias"] = torch.zeros(2 * vc.latent_channels)
+                return osd.vae_encode_moments(sd_, vc, x)
+
+            quant_conv = staticmethod(lambda h: osd._conv(h, vsd, "quant_conv", padding=0))
+            post_quant_conv = staticmethod(lambda z: osd._conv(z, vsd, "post_quant_conv", padding=0))
+
+            @staticmethod
+            def decoder(z):
+                sd_ = dict(vsd)
+                sd_["post_quant_conv.weight"] = torch.eye(vc.latent_channels)[:, :, None, None]
+                sd_["post_quant_conv.bias"] = torch.zeros(vc.latent_channels)
+                return osd.vae_decode(sd_, vc, z)
+
+        out = {"embed_rows_0_2": embed[:2].copy(), "embed_77": embed.copy()}
+        with torch.no_grad():
+            for tag in ("sq", "odd"):
+                rgb_u8 = torch.as_tensor(e2e[f"{tag}_rgb_u8"])
+                rgb_norm = rgb_u8.float() / 255.0 * 2.0 - 1.0
+                out[f"{tag}_rgb_u8"] = rgb_u8.numpy()
+                for cname, ctx in (("ctx2", torch.as_tensor(embed[:2]).float()), ("ctx77", torch.as_tensor(embed).float())):
+                    for mode in ("depth", "normal"):
+                        p = v1.GenPerceptPipeline(unet=_refexec_unet(cu, usd, uc), vae=VAE, customized_head=None, empty_text_embed=ctx[None])
+                        pred = p.single_infer(rgb_norm, mode=mode)             # clipped to [-1, 1]; v1 shifts / min-maxes in __call__
+                        out[f"{tag}_{cname}_{mode}"] = pred.numpy()
+                        ref = opipe.single_infer(vsd, vc, usd, uc, rgb_norm, ctx, mode)   # the oracle's [0, 1] map
+                        np.testing.assert_allclose((pred.numpy() + 1.0) / 2.0, ref.numpy(), rtol=0, atol=1e-5,
+                                                   err_msg=f"oracle single_infer != GenPercept_v1 single_infer ({tag}, {cname}, {mode})")
+                # v1's latent (encode_rgb) is v2's
+                p = v1.GenPerceptPipeline(unet=None, vae=VAE, customized_head=None, empty_text_embed=None)
+                np.testing.assert_allclose(p.encode_rgb(rgb_norm).numpy(), osd.encode_rgb(vsd, vc, rgb_norm).numpy(), rtol=0, atol=1e-5)
+    finally:
+        sys.path[:] = path0
+        _refexec_cleanup(saved)
+    np.savez_compressed(os.path.join(HERE, "refexec_v1_tiny.npz"), **out)
+    print("refexec_v1_tiny.npz", os.path.getsize(os.path.join(HERE, "refexec_v1_tiny.npz")) // 1024, "KiB;", len(out),
+          "arrays; oracle == GenPercept_v1 single_infer executed, with the shipped empty_text_embed.npy (77 rows and rows [0:2])")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dpt", "metrics", "e2e", "batchsize", "infer_eval", "image_util", "datasets", "scheduler", "ensemble", "multistep", "refexec"]
     if "scheduler" in which:
@@ -865,3 +941,5 @@ if __name__ == "__main__":
         make_datasets_golden()
     if "refexec" in which:
         make_refexec_golden()
+    if "refexec" in which or "refexec_v1" in which:
+        make_refexec_v1_golden()

@@ -183,3 +183,29 @@ def test_oracle_matches_reference_executed_orchestration():
             np.testing.assert_allclose(got, r[f"{tag}_marigold_4"], **tol)
             got = opipe.multi_step_infer(vsd, vc, usd, uc, x, ctx, "depth", opipe.DDIM(**sched), 4).numpy()
             np.testing.assert_allclose(got, r[f"{tag}_blend_4"], **tol)
+
+
+def test_oracle_matches_genpercept_v1_single_infer_executed():
+    """tests/golden/refexec_v1_tiny.npz: the SECOND statement of the one-step math in the reference's tree -- GenPercept_v1's `single_infer`
+    (pipeline_genpercept.py:263-309: `timesteps = [1]`, `pred_latent = - unet_pred`, encode_rgb / decode_pred :312-356, no scheduler object) --
+    EXECUTED over the stub bases with the v1 tree's own `empty_text_embed.npy` as context: all 77 rows (what v1 feeds) and rows [0:2] (BOS, EOS:
+    what v2's "do_not_pad" tokenisation feeds, genpercept_pipeline.py:360-372).  v1 returns the clipped [-1, 1] prediction (the shift to [0, 1] is
+    in its __call__), the oracle the [0, 1] map of v2's single_infer (:469-472): they must agree through (x + 1) / 2."""
+    r = np.load(os.path.join(GOLD, "refexec_v1_tiny.npz"))
+    assert r["embed_77"].shape == (77, 1024) and np.array_equal(r["embed_rows_0_2"], r["embed_77"][:2])
+    uc = osd.UNetCfg(block_out_channels=(64, 128, 256, 256), num_heads=(1, 2, 4, 4), cross_attention_dim=1024)
+    vc = osd.VAECfg.tiny()
+    usd = osd.synth_state_dict(osd.unet_manifest(uc), 21)
+    vsd = osd.synth_state_dict(osd.vae_manifest(vc), 2)
+    with torch.no_grad():
+        for tag in ("sq", "odd"):
+            rgb = opipe.normalize_rgb(torch.as_tensor(r[f"{tag}_rgb_u8"]))
+            for cname, ctx in (("ctx2", r["embed_rows_0_2"]), ("ctx77", r["embed_77"])):
+                for mode in ("depth", "normal"):
+                    out = opipe.single_infer(vsd, vc, usd, uc, rgb, torch.as_tensor(ctx).float(), mode).numpy()
+                    v1 = r[f"{tag}_{cname}_{mode}"]
+                    assert v1.min() >= -1.0 and v1.max() <= 1.0 and v1.shape == out.shape
+                    np.testing.assert_allclose(out, (v1 + 1.0) / 2.0, rtol=0, atol=2e-5)
+            # the 77-row context is NOT the 2-row context (75 padding keys take part in the softmax): the two fixtures differ, the engine has
+            # to honour the context it is given (gp_set_context folds L = 2 and keeps the general kernel for other lengths)
+            assert np.abs(r[f"{tag}_ctx2_depth"] - r[f"{tag}_ctx77_depth"]).max() > 1e-4

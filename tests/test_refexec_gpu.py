@@ -111,3 +111,39 @@ def test_pipeline_call_vs_reference_call(tag, tiny_weights, refexec, inputs, met
     finally:
         if pipe._engine is not None:
             pipe._engine.close()
+
+
+@pytest.fixture(scope="module")
+def v1_weights():
+    """the tiny topology with cross_attention_dim = 1024 (the width of the v1 tree's empty_text_embed.npy), seeds of make_goldens.py: refexec_v1"""
+    from oracle import dpt as odpt
+    from oracle import sd21 as osd
+    uc = osd.UNetCfg(block_out_channels=(64, 128, 256, 256), num_heads=(1, 2, 4, 4), cross_attention_dim=1024)
+    vc = osd.VAECfg.tiny()
+    return dict(uc=uc, vc=vc, dc=odpt.DPTCfg.tiny(), usd=osd.synth_state_dict(osd.unet_manifest(uc), 21), vsd=osd.synth_state_dict(osd.vae_manifest(vc), 2),
+                dsd=None)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("cname", ["ctx2", "ctx77"])
+def test_engine_vs_genpercept_v1_single_infer(cname, precision, v1_weights, metric_log):
+    """HIP engine against what GenPercept_v1's `single_infer` (pipeline_genpercept.py:263-309) computes when EXECUTED
+    (tests/golden/refexec_v1_tiny.npz), with the v1 tree's shipped empty-prompt embedding as context: rows [0:2] take the folded 2-token
+    cross-attention path, all 77 rows the general cross-attention kernel."""
+    g = np.load(os.path.join(GOLD, "refexec_v1_tiny.npz"))
+    ctx = g["embed_rows_0_2"] if cname == "ctx2" else g["embed_77"]
+    d = torch.device("cuda", 0)
+    tol = TOLS[precision]
+    eng = _engine(v1_weights, False, ctx.astype(np.float32), precision)
+    try:
+        for tag in ("sq", "odd"):
+            rgb = torch.as_tensor(g[f"{tag}_rgb_u8"]).to(d)
+            for mode in ("depth", "normal"):
+                out = eng.infer(rgb, mode).cpu().numpy()
+                ref = (g[f"{tag}_{cname}_{mode}"] + 1.0) / 2.0   # v1 returns the clipped [-1, 1] map; the shift is in its __call__
+                assert out.shape == ref.shape
+                e = float(np.abs(out - ref).mean())
+                metric_log(f"refexec_v1_{mode}[{tag},{cname},{precision}]", mean_abs=e, max_abs=float(np.abs(out - ref).max()))
+                assert e <= tol["map_mean"]
+    finally:
+        eng.close()
