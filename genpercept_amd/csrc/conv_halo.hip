@@ -27,13 +27,16 @@ GP_DEV void halo_wait_vm() { wait_vm<N>(); }
 constexpr int GN_MAXC = 2560;      // fused input transform: per-channel scale/shift of one image live in 20 KiB of LDS (widest UNet up-block input)
 constexpr int HALO_NB = 3;         // weight ring depth
 
-template <bool UPS>
+// TR: output-pixel rows per wave row group (4 row groups per workgroup): 4 = the 16 x 16 tile; 3 = a 12-row x 16-column tile (r5, plain stride-1
+// convs only: conv3x3_halo3_kernel<false, 0, 0, 3>, chosen where 16-row tiles quantise badly over the persistent grid, see halo_plan)
+template <bool UPS, int TR = 4>
 struct HaloGeom {
-    static constexpr int HW_ = UPS ? 10 : 18;              // halo edge (source pixels)
-    static constexpr int HROWS = HW_ * HW_;                // 100 / 324 halo pixels = LDS rows of 128 B
-    static constexpr int GROUPS = (HROWS + 7) / 8;         // 13 / 41 DMA groups of 8 rows
-    static constexpr int A_IT = (GROUPS + 7) / 8;          // 2 / 6 DMA instructions per wave per halo (extra ones hit the dump)
-    static constexpr int A_BUF = GROUPS * 1024;            // 13 / 41 KiB
+    static constexpr int HW_ = UPS ? 10 : 18;              // halo width (source pixels)
+    static constexpr int HH_ = UPS ? 10 : 4 * TR + 2;      // halo height
+    static constexpr int HROWS = HH_ * HW_;                // 100 / 324 (252 for 12-row tiles) halo pixels = LDS rows of 128 B
+    static constexpr int GROUPS = (HROWS + 7) / 8;         // 13 / 41 (32) DMA groups of 8 rows
+    static constexpr int A_IT = (GROUPS + 7) / 8;          // 2 / 6 (4) DMA instructions per wave per halo (extra ones hit the dump)
+    static constexpr int A_BUF = GROUPS * 1024;            // 13 / 41 (32) KiB
     static constexpr int B_OFF = 2 * A_BUF;
     static constexpr int DUMP_OFF = B_OFF + HALO_NB * 16384;
     static constexpr int GN_OFF = DUMP_OFF + 1024;
@@ -331,9 +334,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const IGemmParams p)
 //   * the epilogue is per WAVE: four passes of [16 px][64 ch] fp32 through a private 4 KiB LDS window (the halo buffer the
 //     finished chunk just released), no workgroup barrier; residual rows are prefetched before the first pass;
 //   * GroupNorm partial statistics: per-wave sums -> 4 KiB LDS -> combined after the step barrier that follows.
-template <bool UPS>
+template <bool UPS, int TR = 4>
 struct Halo3Geom {
-    static constexpr int A_BUF = HaloGeom<UPS>::A_BUF;
+    static constexpr int A_BUF = HaloGeom<UPS, TR>::A_BUF;
     static constexpr int B_OFF = 2 * A_BUF;
     static constexpr int DUMP_OFF = B_OFF + 3 * 16384;
     static constexpr int GN_OFF = DUMP_OFF + 1024;
@@ -346,11 +349,13 @@ struct Halo3Geom {
 // FUSED: 0 plain input, 1 input transform x * scale[b][c] + shift[b][c] (GroupNorm apply), 2 the same followed by SiLU.
 // ABL: compile-time ablations for profiling (2 no MFMA, 4 no output stores, 8 no halo DMA, 16 no weight DMA, 32 no waits for the DMA,
 // 64 / 128 every wave issues its DMA before / after its MFMAs, 256 every other step barrier, 512 no step barrier, 1024 no epilogue; >= 2 except 64 / 128: garbage results)
-template <bool UPS, int FUSED, int ABL = 0>
+template <bool UPS, int FUSED, int ABL = 0, int TR = 4>
 __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p) {
-    using G = HaloGeom<UPS>;
-    using G3 = Halo3Geom<UPS>;
-    constexpr int BN = 128, NW = 8, TN = 64, FM = 4, FN = 4, FP = 2;
+    using G = HaloGeom<UPS, TR>;
+    using G3 = Halo3Geom<UPS, TR>;
+    static_assert(TR == 4 || (TR == 3 && !UPS && FUSED == 0), "12-row tiles: plain stride-1 convs only");
+    constexpr int BN = 128, NW = 8, TN = 64, FM = TR, FN = 4, FP = 2;
+    constexpr int TH = 4 * TR;  // output rows of a tile (16 columns always)
     constexpr int HW_ = G::HW_, HROWS = G::HROWS, A_IT = G::A_IT, A_BUF = G::A_BUF;
     constexpr int B_STAGE = BN * 128, B_IT = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     const int a15 = lane & 15;
 
     const int Ho = p.Ho, Wo = p.Wo, Hi = p.Hi, Wi = p.Wi, Cin = p.Cin;
-    const int tiles_x = (Wo + 15) >> 4, tiles_y = (Ho + 15) >> 4, tiles_sp = tiles_x * tiles_y;
+    const int tiles_x = (Wo + 15) >> 4, tiles_y = (Ho + TH - 1) / TH, tiles_sp = tiles_x * tiles_y;
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
     const int tiles_n = (ncols + BN - 1) / BN;
     const int J = gridDim.x / p.B;                  // workgroups per image, a multiple of tiles_n
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     unsigned h_ok = 0, t_ok = 0;
     auto setup_fetch = [&](int sp) __attribute__((always_inline)) {
         const int fty = sp / tiles_x, ftx = sp - fty * tiles_x;
-        const int sy0 = UPS ? fty * 8 - 1 : fty * 16 - 1, sx0 = UPS ? ftx * 8 - 1 : ftx * 16 - 1;
+        const int sy0 = UPS ? fty * 8 - 1 : fty * TH - 1, sx0 = UPS ? ftx * 8 - 1 : ftx * 16 - 1;
         h_ok = 0;
         t_ok = 0;
         int lane_o = lane, tid_o = tid;
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int hx = UPS ? ((a15 + kx - 1) >> 1) + 1 : a15 + kx;
-                const int hy0 = UPS ? 2 * wm : 4 * wm;
+                const int hy0 = UPS ? 2 * wm : TR * wm;
                 xb[kx][kk] = a_base + (hy0 * HW_ + hx) * 128 + ((sl ^ halo_key<UPS>(hx)) << 4);
             }
         }
@@ -591,6 +596,19 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            return;
+        }
+        if (FM == 3) {  // 12 MFMAs, 7 fragment reads (4 weight + 3 pixel)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
             return;
         }
 #pragma unroll
@@ -647,7 +665,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         for (int j = 0; j < FM; ++j)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {  // residual rows first: their latency hides under the LDS round trips
-                const int oy = ty * 16 + 4 * wm + j, ox = tx * 16 + pl + 8 * h;
+                const int oy = ty * TH + TR * wm + j, ox = tx * 16 + pl + 8 * h;
                 m2[j][h] = (oy < Ho && ox < Wo && col_ok) ? (b * Ho + oy) * Wo + ox : -1;
                 if (RES) {
                     rv[j][h] = make_uint4(0u, 0u, 0u, 0u);
@@ -731,7 +749,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     int run_px = 0;
     auto flush_stats = [&]() __attribute__((always_inline)) {  // after a workgroup barrier that follows epilogue(): waves (wm, wn) -> channel sums
         const int ty = sp_cur / tiles_x, tx = sp_cur - ty * tiles_x;
-        run_px += min(16, Ho - 16 * ty) * min(16, Wo - 16 * tx);
+        run_px += min(TH, Ho - TH * ty) * min(16, Wo - 16 * tx);
         if (tid < BN) {
             // (inline asm: a compiler-visible LDS read here would make hipcc drain the DMA ring first, see tp_load)
             const unsigned a = st_base + (unsigned)tid * 8u;  // [(wm * 2 + wn) * 64 + ch][2] floats, tid = wn * 64 + ch
@@ -924,18 +942,20 @@ bool conv_halo_applicable(const IGemmParams& p) {
     return p.Ho >= 16 && p.Wo >= 16;
 }
 
-template <bool UPS, int FUSED, int ABL>
+template <bool UPS, int FUSED, int ABL, int TR = 4>
 static void launch_halo3_one(const IGemmParams& p, int grid, hipStream_t s) {
     static unsigned long long attr_mask = 0;
+    constexpr int lds = Halo3Geom<UPS, TR>::LDS;
     gp_once_per_device(&attr_mask, [&] {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<UPS, FUSED, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo3Geom<UPS>::LDS);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<UPS, FUSED, ABL, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
-    hipLaunchKernelGGL((conv3x3_halo3_kernel<UPS, FUSED, ABL>), dim3(grid), dim3(512), Halo3Geom<UPS>::LDS, s, p);
+    hipLaunchKernelGGL((conv3x3_halo3_kernel<UPS, FUSED, ABL, TR>), dim3(grid), dim3(512), lds, s, p);
 }
 
-static void launch_halo3(const IGemmParams& p, int grid, hipStream_t s) {
+static void launch_halo3(const IGemmParams& p, int grid, int tr, hipStream_t s) {
     const int abl = (p.dbg >> 9) & 2047;  // profiling ablations (GENPERCEPT_IGEMM_DBG = 512 * ABL), plain convs only
     const int fused = !p.in_scale ? 0 : p.in_silu ? 2 : 1;
+    if (tr == 3) { launch_halo3_one<false, 0, 0, 3>(p, grid, s); return; }  // (halo_plan: plain stride-1 convs only)
     if (p.ups) {
         if (fused == 2) launch_halo3_one<true, 2, 0>(p, grid, s);
         else if (fused == 1) launch_halo3_one<true, 1, 0>(p, grid, s);
@@ -977,10 +997,10 @@ static int halo_ncu() {
     }
     return ncu;
 }
-// persistent kernel: B x J workgroups, J = workgroups per image (a multiple of tiles_n, about #CU / B)
-static int halo3_wgs_per_image(const IGemmParams& p, int ncu) {
+// persistent kernel: B x J workgroups, J = workgroups per image (a multiple of tiles_n, about #CU / B); th = output rows of a tile (16 or 12)
+static int halo3_wgs_per_image(const IGemmParams& p, int ncu, int th = 16) {
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
-    const int tiles_n = (ncols + 127) / 128, tiles_sp = ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
+    const int tiles_n = (ncols + 127) / 128, tiles_sp = ((p.Wo + 15) / 16) * ((p.Ho + th - 1) / th);
     int per_img = ncu / p.B;
     if (per_img < 1) per_img = 1;
     int J = (per_img / tiles_n) * tiles_n;
@@ -995,13 +1015,38 @@ static bool halo_persistent(const IGemmParams& p) {
 // workgroups per image (a multiple of tiles_n) of the persistent kernel: one function for the launch AND for the statistics-row count the engine
 // allocates.  (r4's alternative structures -- 32 x 16 tiles, two workgroups per CU, Winograd F(2,3) along x -- measured 0-10 % slower and live in
 // tools/experiments/ with their tests and profiles since r5.)
-static int halo_plan(const IGemmParams& p) { return halo3_wgs_per_image(p, halo_ncu()); }
+//
+// r5: 12-row x 16-column tiles (TR = 3) where the 16 x 16 tiling quantises badly over the persistent grid.  The makespan of a launch is
+// ceil(tiles / slots) rounds of one tile, slots = workgroups per (image, channel slice).  At 96 x 96 with 512 output channels and batch 4 (the VAE
+// encoder's last level / mid block and the decoder's first: 19 launches, 3.3 ms of a 45-ms pass) that is 36 tiles on 16 slots = 3 rounds for 2.25
+// rounds of work (~1000 TFLOP/s against ~1400 for the well-quantised 192 x 192 shapes); 12-row tiles give 48 tiles = exactly 3 rounds of tiles 3/4
+// the size.  A 12-row tile does 12 MFMAs per 7 fragment reads and per weight tile instead of 16 per 8, so it is priced at 0.80 of a 16-row tile,
+// not 0.75, and taken only for a >= 5 % shorter makespan.  p.dbg bits 20-21 (tests / kbench): 1 forces TR = 3 where it applies, 2 forbids it.
+static int halo_plan(const IGemmParams& p, int* tr) {
+    const int ncols = p.N > p.n_store ? p.N : p.n_store;
+    const int tiles_n = (ncols + 127) / 128;
+    const int J16 = halo3_wgs_per_image(p, halo_ncu(), 16);
+    *tr = 4;
+    const int force = (p.dbg >> 20) & 3;
+    const bool can12 = !p.ups && !p.in_scale && force != 2 && !((p.dbg >> 9) & 2047) && p.Ho >= 12;
+    if (!can12) return J16;
+    const int J12 = halo3_wgs_per_image(p, halo_ncu(), 12);
+    const int t16 = ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16), t12 = ((p.Wo + 15) / 16) * ((p.Ho + 11) / 12);
+    const int s16 = J16 / tiles_n, s12 = J12 / tiles_n;
+    const double c16 = (double)((t16 + s16 - 1) / s16), c12 = 0.80 * (double)((t12 + s12 - 1) / s12);
+    if (force == 1 || c12 <= 0.95 * c16) {
+        *tr = 3;
+        return J12;
+    }
+    return J16;
+}
 // statistics rows per image the halo kernel will write for this problem (per-workgroup partials + counts, "mode 2"); 0 = one row per
 // 16x16 tile ("mode 1", conv3x3_halo2_kernel)
 int conv_halo_stat_rows(const IGemmParams& p) {
     if (!halo_persistent(p)) return 0;
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
-    return halo_plan(p) / ((ncols + 127) / 128);
+    int tr;
+    return halo_plan(p, &tr) / ((ncols + 127) / 128);
 }
 
 void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
@@ -1014,7 +1059,9 @@ void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
     });
     // (conv_halo_applicable guarantees whole 128-row weight tiles)
     if (halo_persistent(p)) {
-        launch_halo3(p, p.B * halo_plan(p), s);
+        int tr;
+        const int J = halo_plan(p, &tr);
+        launch_halo3(p, p.B * J, tr, s);
         return;
     }
     const int tiles = tiles_sp * p.B * tiles_n;

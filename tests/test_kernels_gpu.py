@@ -194,6 +194,74 @@ def test_conv_epilogue_groupnorm_statistics(case, metric_log):
     assert e_sc < 2e-4 and e_sh < 2e-4, (e_sc, e_sh)
 
 
+# conv3x3_halo3_kernel<false, 0, 0, 3>: 12-row x 16-column tiles (r5; chosen by halo_plan where 16 x 16 tiles quantise badly over the persistent grid,
+# e.g. 4 x 96 x 96 x 512 -> 512).  Forced through IGemmParams::dbg bits 20-21 (GENPERCEPT_IGEMM_DBG = 1 << 20; 2 << 20 forbids it): heights that
+# are / are not multiples of 12 and 16, ragged right edges, one and several tiles per workgroup, several channel slices incl. a ragged one,
+# chunk counts 1 .. 8, with and without residual.  Every output pixel is accumulated in the same (chunk, tap, k) order as in the 16-row kernel, so
+# the two must agree BIT FOR BIT.
+TR3_CASES = [
+    # B, H, W, Cin, Cout, residual
+    (1, 16, 16, 64, 128, False), (2, 24, 48, 64, 128, True), (1, 48, 96, 128, 256, True), (1, 17, 33, 64, 64, True), (3, 40, 72, 192, 320, False),
+    (1, 19, 40, 320, 200, True), (4, 96, 96, 512, 512, True), (2, 31, 95, 256, 128, True), (4, 144, 160, 64, 128, False),
+]
+
+
+@pytest.mark.parametrize("case", TR3_CASES)
+def test_conv3x3_halo3_12row_tiles(case, metric_log, monkeypatch):
+    e = _eng()
+    b, h, w, cin, cout, with_res = case
+    g = torch.Generator().manual_seed(sum(int(v) for v in case[:5]) + 12)
+    x = rbf(torch.randn(b, cin, h, w, generator=g))
+    wt = rbf(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, bias, padding=1)
+    res = rbf(torch.randn(ref.shape, generator=g)) if with_res else None
+    if with_res:
+        ref = ref + res
+    d = _dev()
+    args = (e.to_nhwc_bf16(x.to(d)), e.pack_weight(wt, device=d), bias.to(d), cout, 3)
+    kw = dict(residual=e.to_nhwc_bf16(res.to(d)) if with_res else None, tile=5)
+    monkeypatch.setenv("GENPERCEPT_IGEMM_DBG", str(1 << 20))
+    y12 = e.conv2d(*args, **kw)
+    check(f"conv_halo3_tr3{case}", nhwc_to_nchw(y12), ref, metric_log)
+    monkeypatch.setenv("GENPERCEPT_IGEMM_DBG", str(2 << 20))
+    y16 = e.conv2d(*args, **kw)
+    assert torch.equal(y12, y16), "12-row and 16-row tiles must give identical outputs (same per-pixel summation order)"
+    monkeypatch.setenv("GENPERCEPT_IGEMM_DBG", str(1 << 20))
+    assert torch.equal(e.conv2d(*args, **kw), y12)
+
+
+@pytest.mark.parametrize("case", [(2, 24, 64, 128, 128, True), (1, 40, 72, 64, 192, False), (4, 96, 96, 64, 256, True), (1, 17, 33, 64, 320, True)])
+def test_conv_halo3_12row_tiles_groupnorm_statistics(case, metric_log, monkeypatch):
+    """the statistics the 12-row-tile kernel leaves for the next GroupNorm (per-workgroup partial rows + pixel counts) are those of the tensor it stored"""
+    monkeypatch.setenv("GENPERCEPT_IGEMM_DBG", str(1 << 20))
+    e = _eng()
+    b, h, w, cin, cout, with_res = case
+    groups, eps = 32, 1e-6
+    g = torch.Generator().manual_seed(cin + cout + h + 12)
+    x = rbf(torch.randn(b, cin, h, w, generator=g))
+    wt = rbf(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
+    bias = torch.randn(cout, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(cout, generator=g), 0.3 * torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, bias, padding=1)
+    res = rbf(torch.randn(ref.shape, generator=g)) if with_res else None
+    if with_res:
+        ref = ref + res
+    d = _dev()
+    y, scale, shift = e.conv2d_stats(e.to_nhwc_bf16(x.to(d)), e.pack_weight(wt, device=d), bias.to(d), cout, 3, gamma.to(d), beta.to(d), groups, eps,
+                                     ups=False, residual=e.to_nhwc_bf16(res.to(d)) if with_res else None, tile=5)
+    check(f"conv_halo3_tr3_stats_out{case}", nhwc_to_nchw(y), ref, metric_log)
+    yg = nhwc_to_nchw(y).float().cpu().reshape(b, groups, -1)
+    mean, var = yg.mean(dim=2), yg.var(dim=2, unbiased=False)
+    cpg = cout // groups
+    sc_ref = gamma[None, :] * (var + eps).rsqrt().repeat_interleave(cpg, dim=1)
+    sh_ref = beta[None, :] - mean.repeat_interleave(cpg, dim=1) * sc_ref
+    e_sc = ((scale.cpu() - sc_ref).abs() / sc_ref.abs().clamp_min(1e-3)).max().item()
+    e_sh = (shift.cpu() - sh_ref).abs().max().item()
+    metric_log(f"conv_halo3_tr3_stats{case}", scale_rel=e_sc, shift_abs=e_sh)
+    assert e_sc < 2e-4 and e_sh < 2e-4, (e_sc, e_sh)
+
+
 @pytest.mark.parametrize("case", [(2, 32, 32, 128, 128, False, True), (1, 40, 24, 320, 192, False, True), (2, 16, 16, 64, 128, False, False),
                                   (1, 12, 16, 256, 128, True, True), (1, 17, 21, 960, 64, False, True), (1, 24, 24, 2560, 128, False, True),
                                   (4, 48, 48, 1920, 128, False, True)])

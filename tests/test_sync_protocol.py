@@ -116,7 +116,7 @@ def simulate(cpt, ntiles, a_it=6, b_it=2, fused=True):
 
 @pytest.mark.parametrize("cpt", [1, 2, 3, 5, 8])
 @pytest.mark.parametrize("ntiles", [1, 2, 3])
-@pytest.mark.parametrize("geom", [(6, 2), (2, 2)])  # (halo DMA instructions per wave, weight DMA instructions per wave): 18x18 / 10x10 halo
+@pytest.mark.parametrize("geom", [(6, 2), (2, 2), (4, 2)])  # (halo DMA instructions per wave, weight DMA instructions per wave): 18x18 / 10x10 / 14x18 (12-row tiles) halo
 def test_ring_protocol_is_safe(cpt, ntiles, geom):
     simulate(cpt, ntiles, a_it=geom[0], b_it=geom[1], fused=True)
     simulate(cpt, ntiles, a_it=geom[0], b_it=geom[1], fused=False)
