@@ -452,7 +452,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     // their zeros through a select.  LDS accesses by integer address (see common.h).
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) u32x4_t* lds_u4_ptr;
-    struct TPart { u32x4_t raw; float v[8]; unsigned addr; bool ok; };
+    struct TPart { u32x4_t raw; f32x2_t v[4]; unsigned addr; bool ok; };
     const unsigned dump_base = (unsigned)(unsigned long long)dump;
     // A thread always handles the same LOGICAL channel slot c = tid & 7 of its halo rows (physical 16-byte slot c ^ key(column)), so scale / shift
     // of its eight channels are read once per chunk into registers (tbl_load) instead of four 16-byte LDS reads per item.
@@ -481,24 +481,39 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         t.raw = *(lds_u4_ptr)t.addr;
     };
     // arithmetic in two halves so that it can sit under BOTH MFMA batches of the step (one VALU pipe per SIMD, two waves on it: with
-    // all of it under the second batch that batch was VALU-bound while the first one had idle VALU slots)
+    // all of it under the second batch that batch was VALU-bound while the first one had idle VALU slots).
+    // r5: two channels per instruction -- v_pk_fma_f32 for x * scale + shift, v_pk_mul_f32 / v_pk_add_f32 around the two transcendentals of the
+    // SiLU (x * rcp(1 + exp2(-x log2 e))): per 8-channel item 16 packed + 8 unpack + 8 pack / select instructions and 16 quarter-rate
+    // transcendentals instead of 48 + 16 (the transform's VALU time, which the two waves of a SIMD spend with the matrix pipe half idle, -14 %)
+    auto silu_pk = [&](f32x2_t v) __attribute__((always_inline)) {
+        const f32x2_t nl2e = {-1.44269504088896340736f, -1.44269504088896340736f}, one = {1.f, 1.f};
+        f32x2_t e = v * nl2e;
+        e.x = __builtin_amdgcn_exp2f(e.x);
+        e.y = __builtin_amdgcn_exp2f(e.y);
+        e = e + one;
+        e.x = __builtin_amdgcn_rcpf(e.x);
+        e.y = __builtin_amdgcn_rcpf(e.y);
+        return v * e;
+    };
     auto tp_mid = [&](TPart& t) __attribute__((always_inline)) {
-        t.v[0] = h16_lo(t.raw.x) * gs0.x + gh0.x; t.v[1] = h16_hi(t.raw.x) * gs0.y + gh0.y;
-        t.v[2] = h16_lo(t.raw.y) * gs0.z + gh0.z; t.v[3] = h16_hi(t.raw.y) * gs0.w + gh0.w;
-        t.v[4] = h16_lo(t.raw.z) * gs1.x + gh1.x; t.v[5] = h16_hi(t.raw.z) * gs1.y + gh1.y;
-        t.v[6] = h16_lo(t.raw.w) * gs1.z + gh1.z; t.v[7] = h16_hi(t.raw.w) * gs1.w + gh1.w;
+        const f32x2_t x0 = {h16_lo(t.raw.x), h16_hi(t.raw.x)}, x1 = {h16_lo(t.raw.y), h16_hi(t.raw.y)};
+        const f32x2_t x2 = {h16_lo(t.raw.z), h16_hi(t.raw.z)}, x3 = {h16_lo(t.raw.w), h16_hi(t.raw.w)};
+        t.v[0] = __builtin_elementwise_fma(x0, f32x2_t{gs0.x, gs0.y}, f32x2_t{gh0.x, gh0.y});
+        t.v[1] = __builtin_elementwise_fma(x1, f32x2_t{gs0.z, gs0.w}, f32x2_t{gh0.z, gh0.w});
+        t.v[2] = __builtin_elementwise_fma(x2, f32x2_t{gs1.x, gs1.y}, f32x2_t{gh1.x, gh1.y});
+        t.v[3] = __builtin_elementwise_fma(x3, f32x2_t{gs1.z, gs1.w}, f32x2_t{gh1.z, gh1.w});
         if (FUSED == 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t.v[e] = silu_f(t.v[e]);
+            t.v[0] = silu_pk(t.v[0]);
+            t.v[1] = silu_pk(t.v[1]);
         }
     };
     auto tp_finish = [&](TPart& t) __attribute__((always_inline)) {
         if (FUSED == 2) {
-#pragma unroll
-            for (int e = 4; e < 8; ++e) t.v[e] = silu_f(t.v[e]);
+            t.v[2] = silu_pk(t.v[2]);
+            t.v[3] = silu_pk(t.v[3]);
         }
         // (normalised activations: |x| stays within a few tens, no saturation needed in the fp16 build)
-        u32x4_t ov = {pack_h16x2_ns(t.v[0], t.v[1]), pack_h16x2_ns(t.v[2], t.v[3]), pack_h16x2_ns(t.v[4], t.v[5]), pack_h16x2_ns(t.v[6], t.v[7])};
+        u32x4_t ov = {pack_h16x2_ns(t.v[0].x, t.v[0].y), pack_h16x2_ns(t.v[1].x, t.v[1].y), pack_h16x2_ns(t.v[2].x, t.v[2].y), pack_h16x2_ns(t.v[3].x, t.v[3].y)};
         ov = t.ok ? ov : t.raw;
         *(lds_u4_ptr)t.addr = ov;
     };

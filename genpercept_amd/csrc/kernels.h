@@ -61,7 +61,7 @@ struct IGemmParams {
 struct GpSwitches {
     int flash_ring3, no_flash512, f5_dbg, no_conv_few, no_conv_img, conv_img_s, no_cross_fold, no_gn_fusion, gn_fuse_max_slices,
         gn_fuse_below_px, no_stats_fusion, vt_tile, no_gn_small, fp32_scores, no_qkv_fuse, qkv_fuse_max_rows, no_rgb_conv, igemm_dbg, no_splitk,
-        no_halo, no_pgemm, gn_apply_old, xfold_lds, no_fin_fuse, pgemm_ring3;
+        no_halo, no_pgemm, gn_apply_old, xfold_lds, no_fin_fuse, pgemm_ring3, gn_small_old;
 };
 const GpSwitches& gp_sw();
 void gp_switches_reload();

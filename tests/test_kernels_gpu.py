@@ -491,6 +491,21 @@ def test_groupnorm(case, metric_log):
         check(f"groupnorm{case}eps{eps}", nhwc_to_nchw(y), ref, metric_log)
 
 
+@pytest.mark.parametrize("case", [(4, 1280, 144, True), (4, 2560, 144, True), (2, 1280, 576, False), (4, 256, 37, True), (1, 1280, 600, True)])
+def test_groupnorm_small_register_kernel_equals_three_pass_kernel(case, metric_log, monkeypatch):
+    """gn_small_reg_kernel (r5: the workgroup's slice stays in registers between the mean, variance and apply passes) keeps gn_small_kernel's
+    summation order: bit-identical outputs (GENPERCEPT_GN_SMALL_OLD=1 selects the three-pass kernel)."""
+    e = _eng()
+    b, c, hw, silu = case
+    g = torch.Generator().manual_seed(c + hw + 5)
+    x = e.to_nhwc_bf16((rbf(torch.randn(b, c, hw, 1, generator=g) * 2.0 + 0.7)).to(_dev()))
+    gamma, beta = (1 + 0.2 * torch.randn(c, generator=g)).to(_dev()), (0.3 * torch.randn(c, generator=g)).to(_dev())
+    y_new = e.groupnorm(x, gamma, beta, 32, 1e-5, silu)
+    monkeypatch.setenv("GENPERCEPT_GN_SMALL_OLD", "1")
+    y_old = e.groupnorm(x, gamma, beta, 32, 1e-5, silu)
+    assert torch.equal(y_new, y_old)
+
+
 @pytest.mark.parametrize("case", [(100, 64), (577, 320), (64, 640), (1000, 1280), (3, 2560)])
 def test_layernorm(case, metric_log):
     e = _eng()
