@@ -753,6 +753,12 @@ template <int VPT, int HEADS>
 static void launch_cross_fold_r(const h16_t* y, h16_t* y_out, h16_t* n3_out, const float* U, const float* u0, const float* G, const float* c0,
                                 const float* g3, const float* b3, int rows, int C, float eps, hipStream_t s) {
     // rows per wave: 4 (the U / G rows a wave streams are reused four times) once that still leaves >= 2 waves per SIMD on the chip
+    // r5: at C = 1280 (VPT 3, 20 heads) only U fits the LDS and every wave streams the 100 KiB of G from L2 per row GROUP: three rows per wave on the
+    // 24 x 24 maps (2304 rows: 236 -> 78 MB of L2 reads per launch, 55 us before), two on the 12 x 12 maps (576 rows)
+    if constexpr (VPT == 3) {
+        if (rows >= 2048 && rows < 4096) { launch_cross_fold_one<VPT, 3, HEADS>(y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, eps, s); return; }
+        if (rows >= 512 && rows < 4096) { launch_cross_fold_one<VPT, 2, HEADS>(y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, eps, s); return; }
+    }
     if (rows >= 16384 && VPT * HEADS <= 20) launch_cross_fold_one<VPT, 4, HEADS>(y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, eps, s);
     else if (rows >= 4096) launch_cross_fold_one<VPT, 2, HEADS>(y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, eps, s);
     else launch_cross_fold_one<VPT, 1, HEADS>(y, y_out, n3_out, U, u0, G, c0, g3, b3, rows, C, eps, s);

@@ -704,7 +704,9 @@ def test_heaviest_layers_batch4_vs_fp32(case, metric_log):
     check(f"heavy_b4{case}", yc, ref, metric_log)
 
 
-@pytest.mark.parametrize("case", [(150, 320, 5), (37, 640, 10), (64, 1280, 20), (5, 256, 4), (20000, 320, 5), (5000, 128, 2)])
+@pytest.mark.parametrize("case", [(150, 320, 5), (37, 640, 10), (64, 1280, 20), (5, 256, 4), (20000, 320, 5), (5000, 128, 2),
+                                  # C = 1280: two rows per wave from 512 rows, three from 2048 (r5; ragged row counts)
+                                  (577, 1280, 20), (2304, 1280, 20), (2050, 1280, 20), (9217, 640, 10)])
 def test_cross_attention_two_token_fold(case, metric_log):
     """attn2 of the BasicTransformerBlock against a 2-token context (GenPercept's empty prompt, genpercept_pipeline.py:425-429) folded into
     per-head vectors: the kernel must equal LayerNorm -> to_q -> softmax(q k^T / 8) v -> to_out -> + residual, then norm3, computed
