@@ -330,14 +330,22 @@ def main(argv=None, engine_factory=None, device=None):
             bid = source_build_id()
             traffic, traffic_note = None, f"null: no PMC summary of this build ({bid}) under profiles/ (tools/gpu_pmc_traffic.sh collects it)"
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic_summary.json")))
-                if tj.get("build_id") == bid:
+                import glob
+                cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_summary*.json")), reverse=True)  # newest round first
+                seen = []
+                for tf in cands:
+                    tj = json.load(open(tf))
+                    seen.append(f"{os.path.basename(tf)}: {tj.get('build_id')}")
+                    if tj.get("build_id") != bid:
+                        continue
                     sel = lambda d: sum(v["sum_kb"] for k, v in d.items() if "conv3x3_halo3" in k)  # noqa: E731
                     nd = sum(v["dispatches"] for k, v in tj["FETCH_SIZE"].items() if "conv3x3_halo3" in k)
                     traffic = round((2.0 * sel(tj["FETCH_SIZE"]) + sel(tj["WRITE_SIZE"])) * 1024.0 / max(nd, 1))
-                    traffic_note = f"HBM bytes per launch, PMC (2*FETCH_SIZE + WRITE_SIZE), same build ({bid}), profiles/r04_pmc_traffic_summary.json"
+                    traffic_note = f"HBM bytes per launch, PMC (2*FETCH_SIZE + WRITE_SIZE), same build ({bid}), profiles/{os.path.basename(tf)}"
+                    break
                 else:
-                    traffic_note = f"null: profiles/r04_pmc_traffic_summary.json is of build {tj.get('build_id')}, this is {bid}"
+                    if seen:
+                        traffic_note = f"null: no PMC summary under profiles/ is of this build ({bid}); newest: {seen[0]}"
             except Exception:
                 pass
             roofline = {"bound": "mfma", "kernel": f"conv3x3_halo3_kernel (3x3 stride-1 convs of the large maps, v_mfma_f32_16x16x32_{'f16' if args.precision == 'fp16' else 'bf16'})",

@@ -827,63 +827,61 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         // role split: waves 4-7 issue their DMA before the MFMAs, waves 0-3 after -- except in a tile's last step, where a DMA
         // issued first would sit under the epilogue's vmcnt(0)
         const bool dma_first = ((ABL & 64) ? true : (ABL & 128) ? false : second_half) && !(TAP == 8 && tile_end);
-        if (fused && issue_h) stage_halo(PAR ^ 1, fcc);
         if (dma_first) {
             if (issue_w) stage_w(TAP % 3, adv);
-            if (!fused && issue_h) stage_halo(PAR ^ 1, fcc);
+            if (issue_h) stage_halo(PAR ^ 1, fcc);
         }
         __builtin_amdgcn_sched_barrier(0);
-        // transform parts of this step.  r5: the fused kernels issue the halo of chunk cc+1 FIRST in tap 0 (every wave, ahead of its weight tile), so
-        // in-order completion certifies it with tile s+3 at the barrier that ends tap 1 -- one step earlier than r4; it is first read in tap 8.
-        // 18x18 halo: 2592 items = 5 full parts (taps 3..7, one each) + 32 items left over, handled as a sixth part in tap 2, where nobody
-        // has transform work, INTERLEAVED with the MFMAs (r4: by wave 0 alone in tap 3 AFTER its MFMAs, ~500 serial cycles per chunk that all
-        // eight waves waited for at the barrier).  The scale / shift table of the chunk is read in tap 2 as well.  10x10 halo: two parts (taps 3, 4).
+        // transform parts of this step (halo of chunk cc+1: complete for everybody from the barrier before tap 3, first read in tap 8)
+        // 18x18 halo: 2592 items = 5 full parts (taps 3..7, one each) + 32 items left over, which only wave 0 handles (in tap 3, after the
+        // MFMAs): as a sixth part for everybody they cost 1/6 of the transform's VALU time for 1 % of its work.  10x10 halo: two parts.
         constexpr int T_FULL = (HROWS * 8) / 512, T_TAIL_WAVES = ((HROWS * 8) % 512 + 63) / 64;  // 5, 1  /  1, 5
         constexpr int NP = !fused ? 0 : T_IT == 6 ? ((TAP >= 3 && TAP <= 7) ? 1 : 0) : ((TAP == 3 || TAP == 4) ? 1 : 0);
         constexpr int P0 = TAP - 3;
-        // one K-step's two MFMA batches with NPX (0 / 1) transform items of part PX and, where TBL, the chunk's table reads among them
-        auto xstep = [&](auto npc, auto pxc, auto tblc) __attribute__((always_inline)) {
-            constexpr int NPX = decltype(npc)::value, PX = decltype(pxc)::value;
-            constexpr bool TBL = decltype(tblc)::value != 0;
-            TPart tp;
-            if constexpr (TBL) tbl_load(fcc);
-            if constexpr (NPX > 0) tp_load(tp, PAR ^ 1, PX);
+        if constexpr (TAP < 8) {
+            TPart tp[NP > 0 ? NP : 1];
+            if constexpr (NP > 0) {
+                if constexpr (TAP == 3) tbl_load(fcc);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) tp_load(tp[u], PAR ^ 1, P0 + u);
+            }
             load_half(nxt1, IC<TAP1>{}, IC<PAR1>{}, IC<1>{});
-            if constexpr (NPX > 0) tp_mid(tp);
+            if constexpr (NP > 0) {
+#pragma unroll
+                for (int u = 0; u < NP; ++u) tp_mid(tp[u]);
+            }
             mfma16(f0);
-            if constexpr (NPX == 0 && !TBL) {
+            if constexpr (NP == 0) {
                 interleave();
-            } else if constexpr (NPX == 0) {  // 16 MFMAs, 8 fragment reads + the 4 table reads
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { sgb<0x008, 2>(); sgb<0x100, 2>(); }
-#pragma unroll
-                for (int q = 4; q < 8; ++q) { sgb<0x008, 2>(); sgb<0x100, 1>(); }
-            } else {  // 16 MFMAs; 8 fragment reads + the item (+ the 4 table reads) under the first five, then ~18 VALU + 8 transcendentals
+            } else {  // 16 MFMAs; 8 fragment reads + the item (+ the 4 table reads of the chunk in tap 3) under the first five, then ~28 VALU + 8 transcendentals
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { sgb<0x008, 1>(); sgb<0x100, 2>(); }
-                sgb<0x008, 1>(); sgb<0x100, TBL ? 5 : 1>();
+                sgb<0x008, 1>(); sgb<0x100, TAP == 3 ? 5 : 1>();
 #pragma unroll
-                for (int q = 5; q < 16; ++q) { sgb<0x008, 1>(); sgb<0x002, 2>(); sgb<0x400, 1>(); }
+                for (int q = 5; q < 16; ++q) { sgb<0x008, 1>(); sgb<0x002, 3>(); sgb<0x400, 1>(); }
             }
             __builtin_amdgcn_sched_barrier(0);
             load_half(f0, IC<TAP1>{}, IC<PAR1>{}, IC<0>{});
-            if constexpr (NPX > 0) tp_finish(tp);
-            mfma16(cur1);
-            if constexpr (NPX == 0) {
-                interleave();
-            } else {  // 16 MFMAs, 8 LDS reads, ~14 VALU + 8 transcendentals, the item's LDS write
+            if constexpr (NP > 0) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { sgb<0x008, 2>(); sgb<0x100, 1>(); sgb<0x002, 2>(); sgb<0x400, 1>(); }
-                sgb<0x200, 1>();
+                for (int u = 0; u < NP; ++u) tp_finish(tp[u]);
             }
-        };
-        if constexpr (TAP < 8) {
-            if constexpr (fused && T_IT == 6 && TAP == 2) {
-                // every wave runs the sixth part (waves 1-7: items beyond the halo, i.e. the dump KiB): a uniform branch here put two copies of the MFMA
-                // batches into the step and the register allocator spilled 211 registers at their merge; the VALU slots of tap 2 are free anyway
-                xstep(IC<1>{}, IC<T_FULL>{}, IC<1>{});
-            } else {
-                xstep(IC<NP>{}, IC<(P0 >= 0 ? P0 : 0)>{}, IC<(fused && T_IT != 6 && TAP == 3) ? 1 : 0>{});
+            mfma16(cur1);
+            if constexpr (NP == 0) {
+                interleave();
+            } else {  // 16 MFMAs, 8 LDS reads, ~24 NP VALU + 8 NP transcendentals, NP LDS writes
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { sgb<0x008, 2>(); sgb<0x100, 1>(); sgb<0x002, 3 * NP>(); sgb<0x400, NP>(); }
+                sgb<0x200, NP>();
+            }
+            if constexpr (fused && T_IT == 6 && TAP == 3) {  // the 32 left-over items (uniform branch: wave 0 only)
+                __builtin_amdgcn_sched_barrier(0);
+                if (wave < T_TAIL_WAVES) {
+                    TPart t;
+                    tp_load(t, PAR ^ 1, T_FULL);
+                    tp_mid(t);
+                    tp_finish(t);
+                }
             }
         } else {
             mfma16(f0);
@@ -907,12 +905,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         __builtin_amdgcn_sched_barrier(0);
         if (!dma_first) {
             if (issue_w) stage_w(TAP % 3, adv);
-            if (!fused && issue_h) stage_halo(PAR ^ 1, fcc);
+            if (issue_h) stage_halo(PAR ^ 1, fcc);
         }
         if (TAP == 8 && final_) return;
         if (ABL & 32) {}  // (no waits for the DMA: results are garbage)
-        else if (TAP == 0 || (TAP == 1 && !fused)) { if (!final_) halo_wait_vm<A_IT + B_IT>(); else halo_wait_vm<B_IT>(); }
-        else if (TAP == 1) halo_wait_vm<B_IT>();  // fused: the halo was issued ahead of tile s+3, so it has landed with it
+        else if (TAP <= 1) { if (!final_) halo_wait_vm<A_IT + B_IT>(); else halo_wait_vm<B_IT>(); }
         else if (TAP < 6) halo_wait_vm<B_IT>();
         else if (TAP < 8) { if (final_) halo_wait_vm<0>(); else halo_wait_vm<B_IT>(); }
         else if (!tile_end) halo_wait_vm<B_IT>();  // (tile end: certified by the vmcnt(0) ahead of the epilogue)

@@ -80,12 +80,9 @@ def simulate(cpt, ntiles, a_it=6, b_it=2, fused=True):
         def dma(w):
             if issue_w:
                 issue(w, ("W", s + 3), b_it, s)
-            if issue_h and not fused:
+            if issue_h:
                 issue(w, ("H", c + 1), a_it, s)
         dma_first = [w >= NW // 2 and not (tap == 8 and tile_end) for w in range(NW)]
-        if fused and issue_h:   # r5: the fused kernels issue the halo FIRST (every wave, ahead of its weight tile and its MFMAs): in-order completion
-            for w in range(NW):  # then certifies it together with tile s+3 at the end of tap 1, one step earlier
-                issue(w, ("H", c + 1), a_it, s)
         for w in range(NW):
             if dma_first[w]:
                 dma(w)
@@ -93,7 +90,7 @@ def simulate(cpt, ntiles, a_it=6, b_it=2, fused=True):
         if not (tap == 8 and final):
             read(("W", s + 1), s, "fragment prefetch")
             read(("H", (s + 1) // 9), s, "fragment prefetch")
-        if fused and not final and 2 <= tap <= 7:   # (tap 2: the 32 left-over items, wave 0; taps 3..7: the five full parts)
+        if fused and not final and 3 <= tap <= 7:
             read(("H", c + 1), s, "input transform")
         if tap == 8 and tile_end:
             for w in range(NW):
@@ -105,10 +102,8 @@ def simulate(cpt, ntiles, a_it=6, b_it=2, fused=True):
         if tap == 8 and final:
             break
         for w in range(NW):
-            if tap == 0 or (tap == 1 and not fused):
+            if tap <= 1:
                 wait(w, a_it + b_it if not final else b_it)
-            elif tap == 1:
-                wait(w, b_it)
             elif tap < 6:
                 wait(w, b_it)
             elif tap < 8:
@@ -143,9 +138,7 @@ def test_model_matches_source():
     s = open(os.path.join(ROOT, "genpercept_amd", "csrc", "conv_halo.hip")).read()
     for line in ["const bool issue_w = !(final_ && TAP >= 6), issue_h = TAP == 0 && !final_;",
                  "const bool dma_first = ((ABL & 64) ? true : (ABL & 128) ? false : second_half) && !(TAP == 8 && tile_end);",
-                 "if (TAP == 0 || (TAP == 1 && !fused)) { if (!final_) halo_wait_vm<A_IT + B_IT>(); else halo_wait_vm<B_IT>(); }",
-                 "else if (TAP == 1) halo_wait_vm<B_IT>();",
-                 "if (fused && issue_h) stage_halo(PAR ^ 1, fcc);",
+                 "if (TAP <= 1) { if (!final_) halo_wait_vm<A_IT + B_IT>(); else halo_wait_vm<B_IT>(); }",
                  "else if (TAP < 6) halo_wait_vm<B_IT>();",
                  "else if (TAP < 8) { if (final_) halo_wait_vm<0>(); else halo_wait_vm<B_IT>(); }",
                  "else if (!tile_end) halo_wait_vm<B_IT>();",
