@@ -115,25 +115,6 @@ GP_DEV float gelu_erf_f(float x) {
     return 0.5f * x * (x >= 0.f ? 2.f - e : e);
 }
 
-// Two GELUs per instruction (r5; the GEGLU epilogue of pgemm_kernel runs after the K loop with the matrix pipe idle: its VALU time is kernel time).
-// Same formula as gelu_erf_f with the constants folded -- t = 1 / (1 + (p / sqrt 2) |x|), exp(-z^2) = exp2(x * x * (-log2(e) / 2)) -- on
-// v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: 16 plain + 4 transcendental instructions per PAIR instead of ~16 + 2 per element.
-GP_DEV f32x2_t gelu_erf_pk(f32x2_t x) {
-    const f32x2_t ax = {fabsf(x.x), fabsf(x.y)};
-    const f32x2_t den = __builtin_elementwise_fma(ax, f32x2_t{0.3275911f * 0.70710678118654752440f, 0.3275911f * 0.70710678118654752440f}, f32x2_t{1.f, 1.f});
-    const f32x2_t t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-    f32x2_t p = __builtin_elementwise_fma(f32x2_t{1.061405429f, 1.061405429f}, t, f32x2_t{-1.453152027f, -1.453152027f});
-    p = __builtin_elementwise_fma(p, t, f32x2_t{1.421413741f, 1.421413741f});
-    p = __builtin_elementwise_fma(p, t, f32x2_t{-0.284496736f, -0.284496736f});
-    p = __builtin_elementwise_fma(p, t, f32x2_t{0.254829592f, 0.254829592f});
-    const f32x2_t arg = (x * x) * f32x2_t{-0.5f * 1.44269504088896340736f, -0.5f * 1.44269504088896340736f};
-    const f32x2_t ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
-    const f32x2_t e = (p * t) * ex;
-    const f32x2_t ce = f32x2_t{2.f, 2.f} - e;
-    const f32x2_t w = {x.x >= 0.f ? ce.x : e.x, x.y >= 0.f ? ce.y : e.y};
-    return (x * f32x2_t{0.5f, 0.5f}) * w;
-}
-
 // Asynchronous 16-byte-per-lane global -> LDS copy (LDS-DMA).  The LDS destination is wave-uniform base + lane*16,
 // the global source is per lane; swizzles therefore go on the SOURCE address (cdna guide, rule 21).
 GP_DEV void glds16(const void* gsrc, void* lds_wave_base) {

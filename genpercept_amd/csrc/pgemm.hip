@@ -324,8 +324,7 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const IGemmParams p) {
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
                 const f32x4_t val = acc[2 * ip][j] + bl, gate = acc[2 * ip + 1][j] + bh;
-                const f32x2_t g01 = gelu_erf_pk(f32x2_t{gate.x, gate.y}) * f32x2_t{val.x, val.y}, g23 = gelu_erf_pk(f32x2_t{gate.z, gate.w}) * f32x2_t{val.z, val.w};
-                float v[4] = {g01.x, g01.y, g23.x, g23.y};
+                float v[4] = {val.x * gelu_erf_f(gate.x), val.y * gelu_erf_f(gate.y), val.z * gelu_erf_f(gate.z), val.w * gelu_erf_f(gate.w)};
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (col + r >= n_half) v[r] = 0.f;
