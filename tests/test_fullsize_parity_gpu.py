@@ -191,6 +191,38 @@ def test_contract_1e3(precision, head, metric, full, metric_log):
     assert value <= CONTRACT, f"{precision} {head} {metric} = {value:.3e} > 1e-3"
 
 
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_nyu_480x640_depth_vs_live_oracle(precision, full, metric_log):
+    """The NYU evaluation resolution (north_star: "AbsRel unchanged on NYU eval split"; config/dataset/eval/data_nyu_test.yaml, infer.py:408-447 with
+    processing_res = 0): 480 x 640 -> latent 60 x 80, neither a multiple of the 16- nor of the 12-row tiles, full SD2.1 widths, batch 2 (ragged
+    tiles, several tiles per workgroup, the 12-row variant on the 60 x 80 x 512 maps).  Image 0 against the live fp32 oracle: mean |delta| at the
+    library's map gate, and AbsRel after the reference's least-squares alignment (the evaluation protocol's metric, src/util/metric.py)."""
+    from oracle import pipeline as opipe
+    from oracle import sd21 as osd
+    g = torch.Generator().manual_seed(480640)
+    noise = torch.randint(0, 256, (2, 3, 480, 640), generator=g, dtype=torch.uint8).float()
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, 480), torch.linspace(0, 1, 640), indexing="ij")
+    rgb8 = (0.5 * noise + 0.5 * torch.stack([yy, xx, (yy + xx) / 2])[None] * 255.0).round().clamp(0, 255).to(torch.uint8)
+    if "depth_nyu" not in full["ref"]:
+        with torch.no_grad():
+            full["ref"]["depth_nyu"] = opipe.single_infer(full["vsd"], osd.VAECfg(), full["usd"], osd.UNetCfg(), opipe.normalize_rgb(rgb8[:1]), full["ctx"],
+                                                          "depth")[0].numpy()
+    ref = full["ref"]["depth_nyu"]
+    d = torch.device("cuda", 0)
+    eng = _engine(full, precision, dpt=False)
+    try:
+        out = eng.infer(rgb8.to(d), "depth")
+        assert out.shape == (2, 1, 480, 640) and torch.isfinite(out).all()
+        assert torch.equal(eng.infer(rgb8.to(d), "depth"), out), "not deterministic"
+        o0 = out[0].cpu().numpy()
+        rec = dict(mean_abs=float(np.abs(o0 - ref).mean()), max_abs=float(np.abs(o0 - ref).max()), rel_rms=_rel_rms(o0, ref), absrel_ls=_absrel_ls(o0[0], ref[0]))
+        metric_log(f"nyu480x640_depth_vs_oracle[{precision}]", **rec)
+        assert rec["mean_abs"] <= MAP_TOL[precision]["depth"], rec
+        assert rec["absrel_ls"] <= ABSREL_TOL[precision], rec
+    finally:
+        eng.close()
+
+
 def test_384_image_through_the_pipeline_vs_live_oracle(full, metric_log):
     """configs[0]'s shape (one 384x384 RGB image, depth, the reference's fp32 run) through GenPerceptPipeline.__call__ on the HIP path:
     torch_dtype=float32 selects the fp16 library (there is no fp32-storage engine)."""
