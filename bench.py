@@ -158,7 +158,8 @@ class ClockPowerSampler:
             return {"samples": 0, "power_w_mean": None, "sclk_mhz_mean": None, "note": "amdgpu hwmon power1_average / freq1_input not readable here"}
         pw, fq = [r[0] for r in self.rows], [r[1] for r in self.rows]
         return {"samples": len(self.rows), "power_w_mean": round(sum(pw) / len(pw), 1), "power_w_max": round(max(pw), 1),
-                "sclk_mhz_mean": round(sum(fq) / len(fq), 1), "sclk_mhz_min": round(min(fq), 1), "source": "amdgpu hwmon (sysfs), every 20 ms over the timed steps"}
+                "sclk_mhz_mean": round(sum(fq) / len(fq), 1), "sclk_mhz_min": round(min(fq), 1),
+                "source": f"amdgpu hwmon (sysfs) of PCI device {self.files[0]}, every 20 ms over the timed steps"}
 
 
 def timed_steps(step, warmup: int, steps: int, dev, stats: dict = None):
