@@ -659,27 +659,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
             for (int j = 0; j < FM; ++j) acc[i][j] = bv;
         }
     };
-    // r5: the residual rows of a tile are requested BEFORE the 32 MFMAs of the tile's last step (res_prefetch, called from tap 8) instead of at the
-    // start of the epilogue: their L2 / HBM latency then runs under those MFMAs -- in tap 8 the next step's fragment registers are not yet
-    // loaded, so the 32 registers are free -- and the vmcnt(0) ahead of the epilogue finds them landed.
-    struct ResRows { uint4 r[FM][2]; };   // (lives inside tap 8 only: as a kernel-scope variable it stayed live across the whole tile loop and spilled 292 registers)
-    auto res_prefetch = [&](ResRows& rvp) __attribute__((always_inline)) {
-        const int ty = sp_cur / tiles_x, tx = sp_cur - ty * tiles_x;
-        int lane_o = lane;
-        asm volatile("" : "+v"(lane_o));
-        const int pl = lane_o >> 3, sl8 = lane_o & 7;
-        const int col = n0 + wn * TN + 8 * sl8;
-        const bool col_ok = col < p.n_store;
-#pragma unroll
-        for (int j = 0; j < FM; ++j)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int oy = ty * TH + TR * wm + j, ox = tx * 16 + pl + 8 * h;
-                rvp.r[j][h] = make_uint4(0u, 0u, 0u, 0u);
-                if (oy < Ho && ox < Wo && col_ok) rvp.r[j][h] = *(const uint4*)(p.res + (long long)((b * Ho + oy) * Wo + ox) * p.ldres + col);
-            }
-    };
-    auto epilogue_body = [&](unsigned stg, const ResRows& rvp, auto actc, auto resc, auto statc) __attribute__((always_inline)) {
+    auto epilogue_body = [&](unsigned stg, auto actc, auto resc, auto statc) __attribute__((always_inline)) {
         constexpr bool ACT = decltype(actc)::value != 0, RES = decltype(resc)::value != 0, STATS = decltype(statc)::value != 0;
         const int ty = sp_cur / tiles_x, tx = sp_cur - ty * tiles_x;
         int lane_o = lane;
@@ -702,8 +682,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
             for (int h = 0; h < 2; ++h) {  // residual rows first: their latency hides under the LDS round trips
                 const int oy = ty * TH + TR * wm + j, ox = tx * 16 + pl + 8 * h;
                 m2[j][h] = (oy < Ho && ox < Wo && col_ok) ? (b * Ho + oy) * Wo + ox : -1;
-                if (RES) rv[j][h] = p.res ? rvp.r[j][h] : make_uint4(0u, 0u, 0u, 0u);  // (requested by res_prefetch before the last step's MFMAs; the
-                                                                                       // activation variant is compiled with RES and may run without a residual)
+                if (RES) {
+                    rv[j][h] = make_uint4(0u, 0u, 0u, 0u);
+                    if (m2[j][h] >= 0 && p.res) rv[j][h] = *(const uint4*)(p.res + (long long)m2[j][h] * p.ldres + col);
+                }
             }
         float st_s[8], st_q[8];
         float satm = 0.f;  // fp16 build: max |value| this thread packs in this tile (common.h: sat_track / sat_report)
@@ -764,14 +746,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         }
     };
     const int ep_variant = (p.act != GP_ACT_NONE ? 4 : 0) | (p.res ? 2 : 0) | (want_stats ? 1 : 0);
-    auto epilogue = [&](unsigned stg, const ResRows& rvp) __attribute__((always_inline)) {
+    auto epilogue = [&](unsigned stg) __attribute__((always_inline)) {
         // (a direct form -- 16-byte stores straight from the MFMA layout, no LDS round trip -- measured 15 % slower end to end)
         switch (ep_variant) {
-            case 0: epilogue_body(stg, rvp, IC<0>{}, IC<0>{}, IC<0>{}); break;
-            case 1: epilogue_body(stg, rvp, IC<0>{}, IC<0>{}, IC<1>{}); break;
-            case 2: epilogue_body(stg, rvp, IC<0>{}, IC<1>{}, IC<0>{}); break;
-            case 3: epilogue_body(stg, rvp, IC<0>{}, IC<1>{}, IC<1>{}); break;
-            default: epilogue_body(stg, rvp, IC<1>{}, IC<1>{}, IC<1>{}); break;  // (rare: activation fused into a halo conv)
+            case 0: epilogue_body(stg, IC<0>{}, IC<0>{}, IC<0>{}); break;
+            case 1: epilogue_body(stg, IC<0>{}, IC<0>{}, IC<1>{}); break;
+            case 2: epilogue_body(stg, IC<0>{}, IC<1>{}, IC<0>{}); break;
+            case 3: epilogue_body(stg, IC<0>{}, IC<1>{}, IC<1>{}); break;
+            default: epilogue_body(stg, IC<1>{}, IC<1>{}, IC<1>{}); break;  // (rare: activation fused into a halo conv)
         }
         acc_init();
     };
@@ -902,9 +884,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
                 }
             }
         } else {
-            ResRows rvp;
-            if (tile_end && p.res && !(ABL & 1025)) res_prefetch(rvp);
-            __builtin_amdgcn_sched_barrier(0);
             mfma16(f0);
             mfma16(cur1);
             __builtin_amdgcn_sched_barrier(0);
@@ -916,7 +895,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
 #pragma unroll
                         for (int j = 0; j < FM; ++j) asm volatile("" ::"v"(acc[i][j]));
                     acc_init();
-                } else if (!(ABL & 1)) epilogue((UPS ? a_base + G3::EP_OFF : a_base + PAR * A_BUF) + wave * 4096, rvp);
+                } else if (!(ABL & 1)) epilogue((UPS ? a_base + G3::EP_OFF : a_base + PAR * A_BUF) + wave * 4096);
             }
             if (!final_) {
                 load_half(f0, IC<TAP1>{}, IC<PAR1>{}, IC<0>{});
