@@ -334,13 +334,22 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const IGemmParams p)
 //   * the epilogue is per WAVE: four passes of [16 px][64 ch] fp32 through a private 4 KiB LDS window (the halo buffer the
 //     finished chunk just released), no workgroup barrier; residual rows are prefetched before the first pass;
 //   * GroupNorm partial statistics: per-wave sums -> 4 KiB LDS -> combined after the step barrier that follows.
-template <bool UPS, int TR = 4>
+// PH (r5): the x2-nearest-upsample conv as FOUR PHASE convolutions on the source map.  Output pixel (2y + a, 2x + b) of conv3x3(upsample2(s)) reads the
+// source pixels {y - 1 + a, y + a} x {x - 1 + b, x + b} only -- the rows 2y + a - 1 ... 2y + a + 1 of the upsampled map fall onto two source rows -- with the
+// kernel rows that land on the same source row SUMMED: phase a = 0: {w[0]}, {w[1] + w[2]}; a = 1: {w[0] + w[1]}, {w[2]} (same along x).  That is a 2 x 2-tap
+// convolution per phase: 4 MFMA steps per 64-channel chunk instead of 9 for the same outputs (4/9 of the flops; the zero padding of the UPSAMPLED map
+// is the zero padding of the source map).  In the 18 x 18 source halo of a 16 x 16 block of source positions phase (a, b) reads taps (a + ty, b + tx)
+// of the plain kernel's 3 x 3 tap grid, so the variant is the plain kernel with: units = (tile, phase), four taps, fragment bases shifted by
+// (a, b), a 4-deep weight ring (slot = tap) over [Cout][phase][2 x 2][Cin] weights summed once at load (engine: pack_phases), and an epilogue that
+// writes output pixel (2y + a, 2x + b).
+template <bool UPS, int TR = 4, bool PH = false>
 struct Halo3Geom {
     static constexpr int A_BUF = HaloGeom<UPS, TR>::A_BUF;
     static constexpr int B_OFF = 2 * A_BUF;
-    static constexpr int DUMP_OFF = B_OFF + 3 * 16384;
+    static constexpr int NBR = PH ? 4 : 3;                   // weight ring depth
+    static constexpr int DUMP_OFF = B_OFF + NBR * 16384;
     static constexpr int GN_OFF = DUMP_OFF + 1024;
-    static constexpr int ST_OFF = GN_OFF + 2 * GN_MAXC * 4;  // [8 waves][64 ch][sum, sumsq]
+    static constexpr int ST_OFF = GN_OFF + (PH ? 0 : 2 * GN_MAXC * 4);  // [8 waves][64 ch][sum, sumsq] (PH: never fused, no scale / shift table)
     static constexpr int BIAS_OFF = ST_OFF + 4096;           // [128] bias of the workgroup's channel slice
     static constexpr int EP_OFF = BIAS_OFF + 512;            // x2-upsample geometry: its halo buffers are smaller than 32 KiB
     static constexpr int LDS = UPS ? EP_OFF + 32768 : EP_OFF;
@@ -349,11 +358,14 @@ struct Halo3Geom {
 // FUSED: 0 plain input, 1 input transform x * scale[b][c] + shift[b][c] (GroupNorm apply), 2 the same followed by SiLU.
 // ABL: compile-time ablations for profiling (2 no MFMA, 4 no output stores, 8 no halo DMA, 16 no weight DMA, 32 no waits for the DMA,
 // 64 / 128 every wave issues its DMA before / after its MFMAs, 256 every other step barrier, 512 no step barrier, 1024 no epilogue; >= 2 except 64 / 128: garbage results)
-template <bool UPS, int FUSED, int ABL = 0, int TR = 4>
+template <bool UPS, int FUSED, int ABL = 0, int TR = 4, bool PH = false>
 __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p) {
     using G = HaloGeom<UPS, TR>;
-    using G3 = Halo3Geom<UPS, TR>;
+    using G3 = Halo3Geom<UPS, TR, PH>;
     static_assert(TR == 4 || (TR == 3 && !UPS && FUSED == 0), "12-row tiles: plain stride-1 convs only");
+    static_assert(!PH || (!UPS && FUSED == 0 && TR == 4 && ABL == 0), "phase mode: its own geometry");
+    constexpr int NT = PH ? 4 : 9;        // taps (K-steps) per 64-channel chunk
+    constexpr int NBR = G3::NBR;          // weight ring depth
     constexpr int BN = 128, NW = 8, TN = 64, FM = TR, FN = 4, FP = 2;
     constexpr int TH = 4 * TR;  // output rows of a tile (16 columns always)
     constexpr int HW_ = G::HW_, HROWS = G::HROWS, A_IT = G::A_IT, A_BUF = G::A_BUF;
@@ -373,7 +385,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     const int a15 = lane & 15;
 
     const int Ho = p.Ho, Wo = p.Wo, Hi = p.Hi, Wi = p.Wi, Cin = p.Cin;
-    const int tiles_x = (Wo + 15) >> 4, tiles_y = (Ho + TH - 1) / TH, tiles_sp = tiles_x * tiles_y;
+    // PH: tiles are 16 x 16 blocks of SOURCE positions, a unit of work is (tile, phase): tiles_sp counts units
+    const int tiles_x = PH ? (Wi + 15) >> 4 : (Wo + 15) >> 4, tiles_y = PH ? (Hi + 15) >> 4 : (Ho + TH - 1) / TH;
+    const int tiles_sp = tiles_x * tiles_y * (PH ? 4 : 1);
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
     const int tiles_n = (ncols + BN - 1) / BN;
     const int J = gridDim.x / p.B;                  // workgroups per image, a multiple of tiles_n
@@ -399,6 +413,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     int h_off[A_IT];
     unsigned h_ok = 0, t_ok = 0;
     auto setup_fetch = [&](int sp) __attribute__((always_inline)) {
+        if (PH) sp >>= 2;
         const int fty = sp / tiles_x, ftx = sp - fty * tiles_x;
         const int sy0 = UPS ? fty * 8 - 1 : fty * TH - 1, sx0 = UPS ? ftx * 8 - 1 : ftx * 16 - 1;
         h_ok = 0;
@@ -433,7 +448,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         wq[i] = p.wt + (long long)(n0 + (wave + NW * i) * 8 + (lane >> 3)) * p.ldw + chunk_w * 8;
         w_lane[i] = (unsigned)(((n0 + (wave + NW * i) * 8 + (lane >> 3)) * p.ldw + chunk_w * 8) * 2);
     }
-    const int w_step = Cin, w_wrap = 64 - 8 * Cin, w_tile_wrap = -8 * Cin - (cpt - 1) * 64;  // next tap / next chunk / first tile again
+    const int w_step = Cin, w_wrap = 64 - (NT - 1) * Cin, w_tile_wrap = -(NT - 1) * Cin - (cpt - 1) * 64;  // next tap / next chunk / first tile again
 
     if (fused) {
         for (int c = tid; c < Cin; c += 512) {
@@ -567,9 +582,19 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
             }
         }
     }
+    // PH: pixel-fragment bases of the unit whose fragments are being read: phase (a, b) shifts the plain kernel's bases by a halo rows and b columns
+    // (the swizzle key follows the column, so the column shift is a choice between the precomputed bases of kx and kx + 1)
+    unsigned xs[2][2];
+    auto set_phase_bases = [&](int unit) __attribute__((always_inline)) {
+        const int a = (unit >> 1) & 1, bb = unit & 1;
+#pragma unroll
+        for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) xs[tx][kk] = (bb ? xb[tx + 1][kk] : xb[tx][kk]) + (unsigned)(a * HW_ * 128);
+    };
     auto load_half = [&](Half& f, auto tapc, auto parc, auto kkc) __attribute__((always_inline)) {
         constexpr int TAP = decltype(tapc)::value, PAR = decltype(parc)::value, KK = decltype(kkc)::value;
-        constexpr int KY = TAP / 3, KX = TAP % 3, SLOT = TAP % 3;
+        constexpr int KY = PH ? TAP / 2 : TAP / 3, KX = PH ? TAP % 2 : TAP % 3, SLOT = PH ? TAP : TAP % 3;
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
             if (ABL & 8192) asm volatile("" : "+v"(f.w[i]));  // r4 diagnostic: no weight-fragment reads (registers keep whatever they hold: garbage results)
@@ -584,7 +609,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         for (int j = 0; j < FM; ++j) {
             const int hy = UPS ? ((j + KY - 1) >> 1) + 1 : j + KY;
             if (ABL & 16384) asm volatile("" : "+v"(f.x[j]));  // ... no pixel-fragment reads
-            else f.x[j] = lds_frag(xb[KX][KK], PAR * A_BUF + hy * HW_ * 128);
+            else f.x[j] = lds_frag(PH ? xs[KX][KK] : xb[KX][KK], PAR * A_BUF + hy * HW_ * 128);
             typedef const volatile __attribute__((address_space(3))) h16x8_t* lds_frag_vptr;
             if (ABL & 32768) {
                 const h16x8_t t = *(lds_frag_vptr)(xb[KX][KK] + (unsigned)(PAR * A_BUF + hy * HW_ * 128));
@@ -661,7 +686,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     };
     auto epilogue_body = [&](unsigned stg, auto actc, auto resc, auto statc) __attribute__((always_inline)) {
         constexpr bool ACT = decltype(actc)::value != 0, RES = decltype(resc)::value != 0, STATS = decltype(statc)::value != 0;
-        const int ty = sp_cur / tiles_x, tx = sp_cur - ty * tiles_x;
+        const int tile_i = PH ? sp_cur >> 2 : sp_cur, ph_a = (sp_cur >> 1) & 1, ph_b = sp_cur & 1;  // (PH: unit = 4 * tile + 2 a + b)
+        const int ty = tile_i / tiles_x, tx = tile_i - ty * tiles_x;
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));  // opaque copy: keeps the address arithmetic below inside the epilogue (hoisted out of the
                                           // tile loop it occupied ~40 VGPRs for the whole K loop and pushed the kernel into spills)
@@ -680,7 +706,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         for (int j = 0; j < FM; ++j)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {  // residual rows first: their latency hides under the LDS round trips
-                const int oy = ty * TH + TR * wm + j, ox = tx * 16 + pl + 8 * h;
+                int oy = ty * TH + TR * wm + j, ox = tx * 16 + pl + 8 * h;
+                if (PH) { oy = 2 * oy + ph_a; ox = 2 * ox + ph_b; }  // source position (y, x) of phase (a, b) -> output pixel (2 y + a, 2 x + b); Ho = 2 Hi
                 m2[j][h] = (oy < Ho && ox < Wo && col_ok) ? (b * Ho + oy) * Wo + ox : -1;
                 if (RES) {
                     rv[j][h] = make_uint4(0u, 0u, 0u, 0u);
@@ -763,8 +790,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     float run_s = 0.f, run_q = 0.f;
     int run_px = 0;
     auto flush_stats = [&]() __attribute__((always_inline)) {  // after a workgroup barrier that follows epilogue(): waves (wm, wn) -> channel sums
-        const int ty = sp_cur / tiles_x, tx = sp_cur - ty * tiles_x;
-        run_px += min(TH, Ho - TH * ty) * min(16, Wo - 16 * tx);
+        const int tile_i = PH ? sp_cur >> 2 : sp_cur;
+        const int ty = tile_i / tiles_x, tx = tile_i - ty * tiles_x;
+        run_px += PH ? min(16, Hi - 16 * ty) * min(16, Wi - 16 * tx) : min(TH, Ho - TH * ty) * min(16, Wo - 16 * tx);
         if (tid < BN) {
             // (inline asm: a compiler-visible LDS read here would make hipcc drain the DMA ring first, see tp_load)
             const unsigned a = st_base + (unsigned)tid * 8u;  // [(wm * 2 + wn) * 64 + ch][2] floats, tid = wn * 64 + ch
@@ -789,6 +817,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     // ---- prologue (first tile) ---------------------------------------------------------------------------------------------------------
     acc_init();
     setup_fetch(sp_cur);
+    if (PH) {
+        w_uni = (unsigned)((sp_cur & 3) * NT * Cin * 2);  // weights [n][phase][2 x 2 taps][Cin]: this unit's phase
+        set_phase_bases(sp_cur);
+    }
     stage_halo(0, 0);
     stage_w(0, w_step);
     stage_w(1, w_step);
@@ -820,15 +852,18 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     bool final_ = tile_end && sp_cur + sp_stride >= tiles_sp;    // ... and of the workgroup
     auto kstep = [&](auto tapc, auto parc, Half& cur1, Half& nxt1) __attribute__((always_inline)) {
         constexpr int TAP = decltype(tapc)::value, PAR = decltype(parc)::value;
-        constexpr int TAP1 = (TAP + 1) % 9, PAR1 = TAP == 8 ? PAR ^ 1 : PAR;
-        const bool issue_w = !(final_ && TAP >= 6), issue_h = TAP == 0 && !final_;
+        constexpr int TAP1 = (TAP + 1) % NT, PAR1 = TAP == NT - 1 ? PAR ^ 1 : PAR;
+        constexpr int WSLOT = PH ? (TAP + 3) % 4 : TAP % 3;  // ring slot of tile s + 3 (3-deep ring: the slot of tile s)
+        const bool issue_w = !(final_ && TAP >= NT - 3), issue_h = TAP == 0 && !final_;
         const int fcc = tile_end ? 0 : cc + 1;  // chunk (of the fetch tile) staged at tap 0 and normalised in taps 3..7
-        const int adv = (TAP + 3) % 9 == 8 ? (tile_end ? w_tile_wrap : w_wrap) : w_step;
+        // after tile s + 3: next tap / first tap of the next chunk / first tile of the next unit (PH: of ITS phase)
+        int adv = (TAP + 3) % NT == NT - 1 ? (tile_end ? w_tile_wrap : w_wrap) : w_step;
+        if (PH && (TAP + 3) % NT == NT - 1 && tile_end) adv += (((sp_cur + sp_stride) & 3) - (sp_cur & 3)) * NT * Cin;
         // role split: waves 4-7 issue their DMA before the MFMAs, waves 0-3 after -- except in a tile's last step, where a DMA
         // issued first would sit under the epilogue's vmcnt(0)
-        const bool dma_first = ((ABL & 64) ? true : (ABL & 128) ? false : second_half) && !(TAP == 8 && tile_end);
+        const bool dma_first = ((ABL & 64) ? true : (ABL & 128) ? false : second_half) && !(TAP == NT - 1 && tile_end);
         if (dma_first) {
-            if (issue_w) stage_w(TAP % 3, adv);
+            if (issue_w) stage_w(WSLOT, adv);
             if (issue_h) stage_halo(PAR ^ 1, fcc);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -838,7 +873,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
         constexpr int T_FULL = (HROWS * 8) / 512, T_TAIL_WAVES = ((HROWS * 8) % 512 + 63) / 64;  // 5, 1  /  1, 5
         constexpr int NP = !fused ? 0 : T_IT == 6 ? ((TAP >= 3 && TAP <= 7) ? 1 : 0) : ((TAP == 3 || TAP == 4) ? 1 : 0);
         constexpr int P0 = TAP - 3;
-        if constexpr (TAP < 8) {
+        if constexpr (TAP < NT - 1) {
             TPart tp[NP > 0 ? NP : 1];
             if constexpr (NP > 0) {
                 if constexpr (TAP == 3) tbl_load(fcc);
@@ -898,17 +933,23 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
                 } else if (!(ABL & 1)) epilogue((UPS ? a_base + G3::EP_OFF : a_base + PAR * A_BUF) + wave * 4096);
             }
             if (!final_) {
+                if (PH && tile_end) set_phase_bases(sp_cur + sp_stride);  // the fragments read from here on belong to the next unit
                 load_half(f0, IC<TAP1>{}, IC<PAR1>{}, IC<0>{});
                 load_half(nxt1, IC<TAP1>{}, IC<PAR1>{}, IC<1>{});
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!dma_first) {
-            if (issue_w) stage_w(TAP % 3, adv);
+            if (issue_w) stage_w(WSLOT, adv);
             if (issue_h) stage_halo(PAR ^ 1, fcc);
         }
-        if (TAP == 8 && final_) return;
+        if (TAP == NT - 1 && final_) return;
         if (ABL & 32) {}  // (no waits for the DMA: results are garbage)
+        else if (PH) {  // four steps per chunk: the halo issued in tap 0 is read from tap 3 on; the workgroup's last three steps issue no tile
+            if (TAP <= 1) { if (!final_) halo_wait_vm<A_IT + B_IT>(); else if (TAP == 0) halo_wait_vm<B_IT>(); else halo_wait_vm<0>(); }
+            else if (TAP == 2) { if (final_) halo_wait_vm<0>(); else halo_wait_vm<B_IT>(); }
+            else if (!tile_end) halo_wait_vm<B_IT>();
+        }
         else if (TAP <= 1) { if (!final_) halo_wait_vm<A_IT + B_IT>(); else halo_wait_vm<B_IT>(); }
         else if (TAP < 6) halo_wait_vm<B_IT>();
         else if (TAP < 8) { if (final_) halo_wait_vm<0>(); else halo_wait_vm<B_IT>(); }
@@ -919,8 +960,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     auto chunk = [&](auto parc, Half& fa, Half& fb) __attribute__((always_inline)) {
         if (tile_end && !final_) setup_fetch(sp_cur + sp_stride);  // from here on halo staging / normalisation belong to the next tile
         kstep(IC<0>{}, parc, fa, fb); kstep(IC<1>{}, parc, fb, fa); kstep(IC<2>{}, parc, fa, fb);
-        kstep(IC<3>{}, parc, fb, fa); kstep(IC<4>{}, parc, fa, fb); kstep(IC<5>{}, parc, fb, fa);
-        kstep(IC<6>{}, parc, fa, fb); kstep(IC<7>{}, parc, fb, fa); kstep(IC<8>{}, parc, fa, fb);
+        kstep(IC<3>{}, parc, fb, fa);
+        if constexpr (!PH) {
+            kstep(IC<4>{}, parc, fa, fb); kstep(IC<5>{}, parc, fb, fa);
+            kstep(IC<6>{}, parc, fa, fb); kstep(IC<7>{}, parc, fb, fa); kstep(IC<8>{}, parc, fa, fb);
+        }
         if (tile_end) {
             if (want_stats) {
                 if (final_) __syncthreads();  // (nothing in flight any more)
@@ -938,7 +982,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     while (true) {
         chunk(IC<0>{}, f1a, f1b);
         if (sp_cur >= tiles_sp) break;
-        chunk(IC<1>{}, f1b, f1a);
+        if constexpr (PH) chunk(IC<1>{}, f1a, f1b);  // (an even number of steps per chunk: the fragment ping-pong is back where it started)
+        else chunk(IC<1>{}, f1b, f1a);
         if (sp_cur >= tiles_sp) break;
     }
 }
@@ -957,14 +1002,26 @@ bool conv_halo_applicable(const IGemmParams& p) {
     return p.Ho >= 16 && p.Wo >= 16;
 }
 
-template <bool UPS, int FUSED, int ABL, int TR = 4>
+template <bool UPS, int FUSED, int ABL, int TR = 4, bool PH = false>
 static void launch_halo3_one(const IGemmParams& p, int grid, hipStream_t s) {
     static unsigned long long attr_mask = 0;
-    constexpr int lds = Halo3Geom<UPS, TR>::LDS;
+    constexpr int lds = Halo3Geom<UPS, TR, PH>::LDS;
     gp_once_per_device(&attr_mask, [&] {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<UPS, FUSED, ABL, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<UPS, FUSED, ABL, TR, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
-    hipLaunchKernelGGL((conv3x3_halo3_kernel<UPS, FUSED, ABL, TR>), dim3(grid), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((conv3x3_halo3_kernel<UPS, FUSED, ABL, TR, PH>), dim3(grid), dim3(512), lds, s, p);
+}
+
+// x2-upsample conv as four phase convolutions (PH): p.wt_ph = [n_rows][4 phases][2 x 2 taps][Cin] weights (engine: pack_phases)
+static void launch_halo3_ph(const IGemmParams& p, int grid, hipStream_t s) {
+    IGemmParams q = p;
+    q.wt = p.wt_ph;
+    q.ldw = 16 * p.Cin;
+    launch_halo3_one<false, 0, 0, 4, true>(q, grid, s);
+}
+bool conv_halo_uses_phases(const IGemmParams& p) {
+    return p.ups && p.wt_ph && !p.in_scale && !gp_sw().no_up_phases && p.Ho == 2 * p.Hi && p.Wo == 2 * p.Wi &&
+           (long long)p.n_rows * 16 * p.Cin * 2 < 0xfffffff0ll;
 }
 
 static void launch_halo3(const IGemmParams& p, int grid, int tr, hipStream_t s) {
@@ -1076,7 +1133,8 @@ void launch_conv_halo(const IGemmParams& p, hipStream_t s) {
     if (halo_persistent(p)) {
         int tr;
         const int J = halo_plan(p, &tr);
-        launch_halo3(p, p.B * J, tr, s);
+        if (conv_halo_uses_phases(p)) launch_halo3_ph(p, p.B * J, s);
+        else launch_halo3(p, p.B * J, tr, s);
         return;
     }
     const int tiles = tiles_sp * p.B * tiles_n;

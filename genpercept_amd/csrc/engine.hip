@@ -130,6 +130,7 @@ struct Act {
 
 struct PackedW {
     h16_t* w = nullptr;   // [n_rows][taps][cin_pad]
+    h16_t* w_ph = nullptr;  // x2-upsample convs only: [n_rows][4 phases][2 x 2 taps][cin_pad], kernel rows / columns on the same source pixel summed (pack_phases)
     float* bias = nullptr; // [cout] or null
     int cout = 0, cin_pad = 0, ks = 1, n_rows = 0;
 };
@@ -271,6 +272,34 @@ struct gp_engine {
             for (int c = 0; c < cin; ++c)
                 for (int t = 0; t < taps; ++t) o[(size_t)t * cin_pad + c] = f_to_h16_host(wi[(size_t)c * taps + t]);
         }
+    }
+    // The x2-nearest-upsample 3x3 conv as four 2 x 2-tap phase convolutions on the source map (conv_halo.hip, PH): output pixel (2y + a, 2x + b) reads
+    // source rows {y - 1 + a, y + a} with the kernel rows that fall onto the same source row summed -- a = 0: {w[0]}, {w[1] + w[2]}; a = 1: {w[0] + w[1]},
+    // {w[2]} -- and the same along x.  Sums in fp32, ONE rounding to the element type.  Layout [n_rows][phase = 2 a + b][tap = 2 ty + tx][cin_pad].
+    static void pack_phase_rows(const float* w, int cout, int cin, int cin_pad, std::vector<h16_t>& out) {
+        static const int lo[2][2] = {{0, 1}, {0, 2}}, hi[2][2] = {{0, 2}, {1, 2}};  // [phase][tap]: kernel index range [lo, hi]
+        for (int n = 0; n < cout; ++n)
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b)
+                    for (int ty = 0; ty < 2; ++ty)
+                        for (int tx = 0; tx < 2; ++tx) {
+                            h16_t* o = out.data() + (((size_t)n * 4 + (2 * a + b)) * 4 + (2 * ty + tx)) * cin_pad;
+                            for (int c = 0; c < cin; ++c) {
+                                const float* wi = w + ((size_t)n * cin + c) * 9;
+                                float acc = 0.f;
+                                for (int ky = lo[a][ty]; ky <= hi[a][ty]; ++ky)
+                                    for (int kx = lo[b][tx]; kx <= hi[b][tx]; ++kx) acc += wi[ky * 3 + kx];
+                                o[c] = f_to_h16_host(acc);
+                            }
+                        }
+    }
+    void pack_phases(PackedW& pw, const std::string& name) {
+        const HostTensor& w = H(name + ".weight");
+        const int cout = (int)w.shape[0], cin = (int)w.shape[1];
+        if (w.shape.size() != 4 || w.shape[2] != 3 || w.shape[3] != 3) throw std::invalid_argument(name + ": not a 3x3 conv");
+        std::vector<h16_t> buf((size_t)pw.n_rows * 16 * pw.cin_pad, 0);
+        pack_phase_rows(w.v.data(), cout, cin, pw.cin_pad, buf);
+        pw.w_ph = upload(buf.data(), buf.size());
     }
     PackedW pack(const float* w, const float* bias, int cout, int cin, int ks, int cin_pad, bool geglu = false) {
         PackedW pw;
@@ -569,7 +598,11 @@ struct gp_engine {
             build_resnet("vae.decoder.mid_block.resnets.1", false);
             for (int i = 0; i < 4; ++i) {
                 for (int j = 0; j < cfg.vae_layers_per_block + 1; ++j) build_resnet("vae.decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), false);
-                if (i != 3) convs["vae.decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv"] = pack_named("vae.decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", 3);
+                if (i != 3) {
+                    const std::string un = "vae.decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
+                    convs[un] = pack_named(un, 3);
+                    pack_phases(convs[un], un);
+                }
             }
             norms["vae.decoder.conv_norm_out"] = norm_named("vae.decoder.conv_norm_out");
             convs["vae.decoder.conv_out"] = pack_named("vae.decoder.conv_out", 3);
@@ -599,7 +632,10 @@ struct gp_engine {
                     build_resnet(bp + ".resnets." + std::to_string(j), true);
                     if (attn) build_transformer(bp + ".attentions." + std::to_string(j), cfg.unet_num_heads[3 - i]);
                 }
-                if (i != 3) convs[bp + ".upsamplers.0.conv"] = pack_named(bp + ".upsamplers.0.conv", 3);
+                if (i != 3) {
+                    convs[bp + ".upsamplers.0.conv"] = pack_named(bp + ".upsamplers.0.conv", 3);
+                    pack_phases(convs[bp + ".upsamplers.0.conv"], bp + ".upsamplers.0.conv");
+                }
             }
             if (cfg.unet_has_out) {
                 norms["unet.conv_norm_out"] = norm_named("unet.conv_norm_out");
@@ -744,6 +780,7 @@ struct gp_engine {
         p.B = x.B; p.Hi = x.H; p.Wi = x.W; p.Ho = Ho; p.Wo = Wo;
         p.stride = o.stride; p.pad_t = w.ks == 3 ? o.pad_t : 0; p.pad_l = w.ks == 3 ? o.pad_l : 0;
         p.ups = o.ups_h ? 1 : 0; p.Hu = o.ups_h; p.Wu = o.ups_w;
+        p.wt_ph = o.ups_h ? w.w_ph : nullptr;  // (used where the size is exactly x2: conv_halo_uses_phases)
         p.lda = x.C; p.ldo = nst; p.ldres = nst; p.ldw = (w.ks == 3 ? 9 : 1) * w.cin_pad;
         p.n_store = nst; p.out_fp32 = 0; p.act = o.act; p.bias_mode = w.bias ? GP_BIAS_COL : GP_BIAS_NONE;
         p.batch = 1;
@@ -1844,6 +1881,36 @@ gp_status gp_conv2d(const void* in, const void* w_packed, const float* bias, con
         p.dbg = gp_sw().igemm_dbg;  // profiling ablations (tools/conv_bench.py)
         attach_splitk_scratch(p, tile_hint);
         launch_igemm(p, tile_hint, (hipStream_t)stream);
+        HIPCHK(hipGetLastError());
+        return GP_OK;
+    } catch (...) { return GP_ERR_HIP; }
+}
+
+gp_status gp_pack_weight_phases(const float* w, int cout, int cin, int cin_pad, void* dev_out) {
+    if (!w || !dev_out || cin_pad < cin || (cin_pad % 64)) return GP_ERR_INVALID;
+    try {
+        std::vector<h16_t> buf((size_t)gp_packed_rows(cout) * 16 * cin_pad, 0);
+        gp_engine::pack_phase_rows(w, cout, cin, cin_pad, buf);
+        HIPCHK(hipMemcpy(dev_out, buf.data(), buf.size() * 2, hipMemcpyHostToDevice));
+        return GP_OK;
+    } catch (...) { return GP_ERR_HIP; }
+}
+
+gp_status gp_conv2d_up2(const void* in, const void* w_packed, const void* w_phases, const float* bias, const void* residual, void* out, int B, int Hi, int Wi,
+                        int Cin, int Cout, void* stream) {
+    if (!in || !w_packed || !w_phases || !out || (Cin % 64) || (Cout % 8)) return GP_ERR_INVALID;
+    try {
+        KernelEntry lk;
+        IGemmParams p{};
+        p.in = (const h16_t*)in; p.wt = (const h16_t*)w_packed; p.wt_ph = (const h16_t*)w_phases; p.bias = bias; p.res = (const h16_t*)residual; p.out = out;
+        p.zero = zero_page();
+        p.M = B * 4 * Hi * Wi; p.N = Cout; p.Cin = Cin; p.n_rows = gp_packed_rows(Cout); p.ks = 3;
+        p.B = B; p.Hi = Hi; p.Wi = Wi; p.Ho = 2 * Hi; p.Wo = 2 * Wi; p.stride = 1; p.pad_t = 1; p.pad_l = 1;
+        p.ups = 1; p.Hu = 2 * Hi; p.Wu = 2 * Wi;
+        p.lda = Cin; p.ldo = Cout; p.ldres = Cout; p.ldw = 9 * Cin; p.n_store = Cout; p.bias_mode = bias ? GP_BIAS_COL : GP_BIAS_NONE; p.batch = 1;
+        p.dbg = gp_sw().igemm_dbg;
+        if (!conv_uses_halo(p, 5) || !conv_halo_uses_phases(p)) return GP_ERR_INVALID;  // (this entry point exists to test the phase kernel)
+        launch_igemm(p, 5, (hipStream_t)stream);
         HIPCHK(hipGetLastError());
         return GP_OK;
     } catch (...) { return GP_ERR_HIP; }

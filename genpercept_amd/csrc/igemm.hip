@@ -64,6 +64,7 @@ void gp_switches_reload() {
     s.no_halo = flag("GENPERCEPT_NO_HALO");              // generic implicit GEMM everywhere
     s.no_pgemm = flag("GENPERCEPT_NO_PGEMM");
     s.gn_apply_old = flag("GENPERCEPT_GN_APPLY_OLD");
+    s.no_up_phases = flag("GENPERCEPT_NO_UP_PHASES");      // A/B: the x2-upsample convs through the nine-tap upsample kernel instead of four phase convolutions (r5)
     s.gn_small_old = flag("GENPERCEPT_GN_SMALL_OLD");      // A/B: gn_small_kernel (three passes over L2) instead of gn_small_reg_kernel (r5)
     s.xfold_lds = num("GENPERCEPT_XFOLD_LDS", -1);       // 0 = the r2 cross-attention fold kernel
     s.no_fin_fuse = flag("GENPERCEPT_NO_FIN_FUSE");

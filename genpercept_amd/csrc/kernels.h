@@ -53,6 +53,9 @@ struct IGemmParams {
     // flash_attn64 reads its V^T operand in.  Columns [0, vt_col0) go to `out` as usual (n_store = ldo = vt_col0).  nullptr: plain GEMM.
     h16_t* vt_out;
     int vt_col0, vt_T, vt_Tpad;
+    // x2-nearest-upsample 3x3 conv as four 2 x 2-tap phase convolutions (conv_halo.hip, PH): weights [n_rows][phase][2 x 2][Cin] with the kernel rows /
+    // columns that fall onto the same source pixel summed (engine: pack_phases); nullptr: the nine-tap upsample kernel
+    const h16_t* wt_ph;
 };
 
 // A/B and profiling switches (GENPERCEPT_* environment variables).  Read from the environment in ONE place, gp_switches_reload(), which
@@ -61,7 +64,7 @@ struct IGemmParams {
 struct GpSwitches {
     int flash_ring3, no_flash512, f5_dbg, no_conv_few, no_conv_img, conv_img_s, no_cross_fold, no_gn_fusion, gn_fuse_max_slices,
         gn_fuse_below_px, no_stats_fusion, vt_tile, no_gn_small, fp32_scores, no_qkv_fuse, qkv_fuse_max_rows, no_rgb_conv, igemm_dbg, no_splitk,
-        no_halo, no_pgemm, gn_apply_old, xfold_lds, no_fin_fuse, pgemm_ring3, gn_small_old;
+        no_halo, no_pgemm, gn_apply_old, xfold_lds, no_fin_fuse, pgemm_ring3, gn_small_old, no_up_phases;
 };
 const GpSwitches& gp_sw();
 void gp_switches_reload();
@@ -104,6 +107,7 @@ bool igemm_uses_pgemm(const IGemmParams& p, int tile_hint);
 bool conv_halo_applicable(const IGemmParams& p);   // includes the Cin <= 2560 limit when in_scale is set
 void launch_conv_halo(const IGemmParams& p, hipStream_t s);
 bool conv_uses_halo(const IGemmParams& p, int tile_hint);
+bool conv_halo_uses_phases(const IGemmParams& p);   // the x2-upsample conv will run as four phase convolutions (p.wt_ph set, exact x2, plain input)
 int conv_halo_stat_rows(const IGemmParams& p);     // > 0: statistics rows per image (per-workgroup partials + pixel counts, mode 2)
 // Statistics layout launch_igemm(p, tile_hint) will write: mode 0 = rows of BM consecutive pixels, mode 1 = 16x16 halo tiles per image,
 // mode 2 = *bm rows per image, each with its own pixel count appended after the [rows][N][2] sums; returns the number of rows (callers

@@ -106,6 +106,8 @@ SYMBOLS = {
     "gp_latent_size": (_i, [_i]),
     "gp_dpt_out_size": (_i, [_i]),
     "gp_pack_weight": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "gp_pack_weight_phases": (_i, [_vp, _i, _i, _i, _vp]),
+    "gp_conv2d_up2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gp_conv2d": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 17 + [_vp]),
     "gp_conv2d_gn": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 7 + [_vp, _vp, _i, _f, _i, _vp]),
     "gp_rgb_conv_in": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -422,6 +424,31 @@ def conv2d(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
                        pad_t if ks == 3 else 0, pad_l if ks == 3 else 0, ho, wo, uh, uw, ACT[act], nst, int(out_fp32), tile, _stream_ptr())
     if st != GP_OK:
         raise RuntimeError(f"gp_conv2d failed ({st})")
+    return out
+
+
+def pack_weight_phases(w: torch.Tensor, cin_pad: Optional[int] = None, device="cuda") -> torch.Tensor:
+    """[cout][cin][3][3] -> the phase-summed packing of the x2-upsample conv (`gp_pack_weight_phases`): [rows][4][4][cin_pad]."""
+    lib = load_library()
+    w = w.detach().float().cpu().contiguous()
+    cout, cin = w.shape[:2]
+    cp = cin_pad or ((cin + 63) // 64 * 64)
+    out = torch.empty((lib.gp_packed_rows(cout), 16, cp), dtype=act_dtype(), device=device)
+    st = lib.gp_pack_weight_phases(w.data_ptr(), cout, cin, cp, out.data_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_pack_weight_phases failed ({st})")
+    return out
+
+
+def conv2d_up2(x_nhwc: torch.Tensor, w_packed: torch.Tensor, w_phases: torch.Tensor, bias, cout: int, residual=None) -> torch.Tensor:
+    """conv3x3(nearest_upsample_x2(x)) through the four-phase kernel (`gp_conv2d_up2`)."""
+    lib = load_library()
+    b, hi, wi, cin = x_nhwc.shape
+    out = torch.empty((b, 2 * hi, 2 * wi, cout), dtype=act_dtype(), device=x_nhwc.device)
+    st = lib.gp_conv2d_up2(x_nhwc.data_ptr(), w_packed.data_ptr(), w_phases.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), b, hi, wi, cin, cout,
+                           _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_conv2d_up2 failed ({st})")
     return out
 
 

@@ -183,6 +183,13 @@ double gp_mfma_lds_probe(int device, int reads_per_16_mfma, int waves_per_simd, 
 /* Pack an OIHW fp32 HOST weight into the device layout [n_rows][taps][cin_pad] bf16 (n_rows = gp_packed_rows(cout)). */
 int gp_packed_rows(int cout);
 gp_status gp_pack_weight(const float* w_oihw_host, int cout, int cin, int ks, int cin_pad, int geglu, void* dev_out);
+/* x2-nearest-upsample 3x3 conv (Upsample2D, resnet.py of diffusers: F.interpolate(scale_factor=2, mode="nearest") then conv; call sites
+ * custom_unet.py:372-400 up blocks, VAE decoder up blocks) as four 2 x 2-tap phase convolutions on the source map: gp_pack_weight_phases sums the kernel
+ * rows / columns that fall onto the same source pixel ([rows][phase 2a+b][tap 2ty+tx][cin_pad], rows = gp_packed_rows(cout)); gp_conv2d_up2 runs
+ * the phase kernel (w_packed = the ordinary 3x3 packing of the same weight, for the launcher's checks).  Test entry points. */
+gp_status gp_pack_weight_phases(const float* w_oihw_host, int cout, int cin, int cin_pad, void* dev_out);
+gp_status gp_conv2d_up2(const void* in, const void* w_packed, const void* w_phases, const float* bias, const void* residual, void* out, int B, int Hi,
+                        int Wi, int Cin, int Cout, void* stream);
 gp_status gp_conv2d(const void* in, const void* w_packed, const float* bias, const void* residual, void* out, int B, int Hi, int Wi, int Cin,
                     int Cout, int ks, int stride, int pad_t, int pad_l, int Ho, int Wo, int ups_h, int ups_w, int act, int n_store,
                     int out_fp32, int tile_hint, void* stream);

@@ -194,6 +194,64 @@ def test_conv_epilogue_groupnorm_statistics(case, metric_log):
     assert e_sc < 2e-4 and e_sh < 2e-4, (e_sc, e_sh)
 
 
+# conv3x3_halo3_kernel<false, 0, 0, 4, PH = true> (r5): the x2-nearest-upsample 3x3 conv (diffusers Upsample2D) as four 2 x 2-tap phase convolutions on the
+# source map -- 4/9 of the MFMA work.  The reference is built from the SAME operands the kernel sees (source pixels and the phase-summed weights, each
+# rounded once to the element type), so the per-kernel tolerance applies; the un-decomposed conv of the upsampled map (fp32 weights) is checked beside it.
+UP2_CASES = [
+    # B, Hi, Wi, Cin, Cout, residual
+    (1, 16, 16, 64, 128, False), (2, 24, 40, 128, 128, True), (1, 17, 33, 64, 64, False), (2, 31, 47, 192, 320, True), (1, 48, 48, 512, 512, False),
+    (4, 96, 96, 128, 256, False), (1, 20, 16, 1280, 200, False),
+]
+
+
+def _phase_weights(wt):
+    """[O][C][3][3] -> {(a, b): [O][C][2][2]}: kernel rows / columns that fall onto the same source pixel summed (engine.hip: pack_phase_rows)"""
+    rng = {0: [(0, 0), (1, 2)], 1: [(0, 1), (2, 2)]}
+    out = {}
+    for a in (0, 1):
+        for b in (0, 1):
+            w = torch.zeros(wt.shape[0], wt.shape[1], 2, 2)
+            for ty, (y0, y1) in enumerate(rng[a]):
+                for tx, (x0, x1) in enumerate(rng[b]):
+                    w[:, :, ty, tx] = wt[:, :, y0:y1 + 1, x0:x1 + 1].sum(dim=(2, 3))
+            out[(a, b)] = w
+    return out
+
+
+@pytest.mark.parametrize("case", UP2_CASES)
+def test_conv_upsample_x2_phase_kernel(case, metric_log):
+    e = _eng()
+    b, h, w, cin, cout, with_res = case
+    g = torch.Generator().manual_seed(sum(int(v) for v in case[:5]) + 22)
+    x = rbf(torch.randn(b, cin, h, w, generator=g))
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    bias = torch.randn(cout, generator=g)
+    exact = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wt, bias, padding=1)   # the op itself, fp32 weights
+    ref = torch.empty_like(exact)                                                                # the same from the kernel's operands
+    for (a, bb), wp in _phase_weights(wt).items():
+        xp = F.pad(x, (1 - bb, bb, 1 - a, a))   # phase (a, b) reads source rows y - 1 + a .. y + a, columns x - 1 + b .. x + b
+        ref[:, :, a::2, bb::2] = F.conv2d(xp, rbf(wp), bias)
+    res = rbf(torch.randn(exact.shape, generator=g)) if with_res else None
+    if with_res:
+        ref, exact = ref + res, exact + res
+    d = _dev()
+    y = e.conv2d_up2(e.to_nhwc_bf16(x.to(d)), e.pack_weight(wt, device=d), e.pack_weight_phases(wt, device=d), bias.to(d), cout,
+                     residual=e.to_nhwc_bf16(res.to(d)) if with_res else None)
+    check(f"conv_up2_phases{case}", nhwc_to_nchw(y), ref, metric_log)
+    # against the un-decomposed conv: the only extra difference is where the weights are rounded (after the sum instead of before)
+    rel = ((nhwc_to_nchw(y).float().cpu() - exact).abs().mean() / exact.abs().mean()).item()
+    metric_log(f"conv_up2_vs_exact{case}", rel_mean=rel)
+    assert rel <= 3 * _tol16()[1], rel
+    # and against the nine-tap upsample kernel on the same input
+    y9 = e.conv2d(e.to_nhwc_bf16(x.to(d)), e.pack_weight(wt, device=d), bias.to(d), cout, 3, ups_hw=(2 * h, 2 * w),
+                  residual=e.to_nhwc_bf16(res.to(d)) if with_res else None, tile=5)
+    rel9 = ((nhwc_to_nchw(y).float() - nhwc_to_nchw(y9).float()).abs().mean() / exact.abs().mean()).item()
+    metric_log(f"conv_up2_vs_ninetap{case}", rel_mean=rel9)
+    assert rel9 <= 4 * _tol16()[1], rel9
+    assert torch.equal(e.conv2d_up2(e.to_nhwc_bf16(x.to(d)), e.pack_weight(wt, device=d), e.pack_weight_phases(wt, device=d), bias.to(d), cout,
+                                    residual=e.to_nhwc_bf16(res.to(d)) if with_res else None), y)
+
+
 # conv3x3_halo3_kernel<false, 0, 0, 3>: 12-row x 16-column tiles (r5; chosen by halo_plan where 16 x 16 tiles quantise badly over the persistent grid,
 # e.g. 4 x 96 x 96 x 512 -> 512).  Forced through IGemmParams::dbg bits 20-21 (GENPERCEPT_IGEMM_DBG = 1 << 20; 2 << 20 forbids it): heights that
 # are / are not multiples of 12 and 16, ragged right edges, one and several tiles per workgroup, several channel slices incl. a ragged one,

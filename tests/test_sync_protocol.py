@@ -22,10 +22,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NW = 8
 
 
-def simulate(cpt, ntiles, a_it=6, b_it=2, fused=True):
+def simulate(cpt, ntiles, a_it=6, b_it=2, fused=True, nt=9, nb=3):
     """Returns nothing; raises AssertionError with a description on the first protocol violation."""
+    # nt taps (K-steps) per chunk, nb weight-ring slots: 9 / 3 = the nine-tap kernels; 4 / 4 = the phase mode of the x2-upsample conv (r5: PH)
     nchunks = cpt * ntiles
-    nsteps = 9 * nchunks
+    nsteps = nt * nchunks
     fifo = [[] for _ in range(NW)]          # per wave: issued load ops, oldest first: ("W", step) or ("H", chunk), one entry per DMA instruction
     done = [set() for _ in range(NW)]       # per wave: resources guaranteed landed (all its parts)
     certified = set()                       # resources every wave has had certified before a barrier that was passed
@@ -36,7 +37,7 @@ def simulate(cpt, ntiles, a_it=6, b_it=2, fused=True):
         fifo[w].extend([res] * n)
         issue_step.setdefault(res, step)
         # WAR: the slot / buffer being overwritten
-        prev = ("W", res[1] - 3) if res[0] == "W" else ("H", res[1] - 2)
+        prev = ("W", res[1] - nb) if res[0] == "W" else ("H", res[1] - 2)
         if prev in last_read_step:
             assert last_read_step[prev] < step, f"{res} issued in step {step} while {prev} is still read in step {last_read_step[prev]}"
 
@@ -70,11 +71,11 @@ def simulate(cpt, ntiles, a_it=6, b_it=2, fused=True):
 
     # ---- main loop ----
     for s in range(nsteps):
-        c, tap = divmod(s, 9)
+        c, tap = divmod(s, nt)
         cc = c % cpt
         tile_end = cc == cpt - 1
         final = tile_end and c == nchunks - 1
-        issue_w = not (final and tap >= 6)
+        issue_w = not (final and tap >= nt - 3)
         issue_h = tap == 0 and not final
 
         def dma(w):
@@ -82,27 +83,34 @@ def simulate(cpt, ntiles, a_it=6, b_it=2, fused=True):
                 issue(w, ("W", s + 3), b_it, s)
             if issue_h:
                 issue(w, ("H", c + 1), a_it, s)
-        dma_first = [w >= NW // 2 and not (tap == 8 and tile_end) for w in range(NW)]
+        dma_first = [w >= NW // 2 and not (tap == nt - 1 and tile_end) for w in range(NW)]
         for w in range(NW):
             if dma_first[w]:
                 dma(w)
         # fragment prefetch of step s+1 (tap 8: after the epilogue, unless this is the workgroup's last step)
-        if not (tap == 8 and final):
+        if not (tap == nt - 1 and final):
             read(("W", s + 1), s, "fragment prefetch")
-            read(("H", (s + 1) // 9), s, "fragment prefetch")
+            read(("H", (s + 1) // nt), s, "fragment prefetch")
         if fused and not final and 3 <= tap <= 7:
             read(("H", c + 1), s, "input transform")
-        if tap == 8 and tile_end:
+        if tap == nt - 1 and tile_end:
             for w in range(NW):
                 wait(w, 0)                                  # vmcnt(0) ahead of the epilogue
             last_read_step[("H", c)] = max(last_read_step.get(("H", c), -1), s)   # epilogue staging window = this chunk's halo buffer
         for w in range(NW):
             if not dma_first[w]:
                 dma(w)
-        if tap == 8 and final:
+        if tap == nt - 1 and final:
             break
         for w in range(NW):
-            if tap <= 1:
+            if nt == 4:   # phase mode: the halo issued in tap 0 is read from tap 3 on; the workgroup's last three steps issue no tile
+                if tap <= 1:
+                    wait(w, a_it + b_it if not final else (b_it if tap == 0 else 0))
+                elif tap == 2:
+                    wait(w, 0 if final else b_it)
+                elif not tile_end:
+                    wait(w, b_it)
+            elif tap <= 1:
                 wait(w, a_it + b_it if not final else b_it)
             elif tap < 6:
                 wait(w, b_it)
@@ -122,6 +130,15 @@ def test_ring_protocol_is_safe(cpt, ntiles, geom):
     simulate(cpt, ntiles, a_it=geom[0], b_it=geom[1], fused=False)
 
 
+@pytest.mark.parametrize("cpt", [1, 2, 3, 4, 8, 20])
+@pytest.mark.parametrize("ntiles", [1, 2, 3, 5])
+def test_phase_mode_ring_protocol_is_safe(cpt, ntiles):
+    """conv3x3_halo3_kernel<..., PH = true> (x2-upsample conv as four phase convolutions): four steps per chunk, 4-deep weight ring"""
+    simulate(cpt, ntiles, a_it=6, b_it=2, fused=False, nt=4, nb=4)
+    with pytest.raises(AssertionError):   # with the nine-tap kernel's 3-deep ring the tile issued in step s would overwrite one still being read
+        simulate(2, 2, a_it=6, b_it=2, fused=False, nt=4, nb=2)
+
+
 def test_model_detects_a_weaker_wait():
     """The model is not vacuous: allowing one more weight tile in flight at taps 2..5 must be flagged."""
     import types
@@ -136,12 +153,15 @@ def test_model_detects_a_weaker_wait():
 
 def test_model_matches_source():
     s = open(os.path.join(ROOT, "genpercept_amd", "csrc", "conv_halo.hip")).read()
-    for line in ["const bool issue_w = !(final_ && TAP >= 6), issue_h = TAP == 0 && !final_;",
-                 "const bool dma_first = ((ABL & 64) ? true : (ABL & 128) ? false : second_half) && !(TAP == 8 && tile_end);",
+    for line in ["const bool issue_w = !(final_ && TAP >= NT - 3), issue_h = TAP == 0 && !final_;",
+                 "const bool dma_first = ((ABL & 64) ? true : (ABL & 128) ? false : second_half) && !(TAP == NT - 1 && tile_end);",
                  "if (TAP <= 1) { if (!final_) halo_wait_vm<A_IT + B_IT>(); else halo_wait_vm<B_IT>(); }",
                  "else if (TAP < 6) halo_wait_vm<B_IT>();",
                  "else if (TAP < 8) { if (final_) halo_wait_vm<0>(); else halo_wait_vm<B_IT>(); }",
                  "else if (!tile_end) halo_wait_vm<B_IT>();",
+                 "if (TAP <= 1) { if (!final_) halo_wait_vm<A_IT + B_IT>(); else if (TAP == 0) halo_wait_vm<B_IT>(); else halo_wait_vm<0>(); }",
+                 "else if (TAP == 2) { if (final_) halo_wait_vm<0>(); else halo_wait_vm<B_IT>(); }",
+                 "constexpr int WSLOT = PH ? (TAP + 3) % 4 : TAP % 3;",
                  "halo_wait_vm<0>();  // everything this wave has in flight has landed",
                  "halo_wait_vm<B_IT>();\n    __builtin_amdgcn_s_barrier();"]:
         assert line in s, line
