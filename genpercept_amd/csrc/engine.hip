@@ -219,6 +219,7 @@ struct gp_engine {
     float* dpt_w_dev = nullptr;  // head.head.4 weight [32]
     float dpt_b = 0.f;
     // fp16 build: saturating conversions that clipped (common.h: gp_sat_flag per translation unit), collected at the end of every call
+    double flops_halo_exec = 0.0;   // executed (not algorithmic) flops of the halo-conv launches, see gp_halo_executed_flops
     SatFlags sat_flags{};
     unsigned* sat_dev = nullptr;          // [1] events since the last reset
     void collect_saturation() {
@@ -736,7 +737,7 @@ struct gp_engine {
         const bool halo = conv_uses_halo(p, hint);
         tm.flops_igemm += fl;
         tm.n_igemm++;
-        if (halo) { tm.flops_halo += fl; tm.n_halo++; }
+        if (halo) { tm.flops_halo += fl; tm.n_halo++; flops_halo_exec += conv_halo_uses_phases(p) ? fl * (4.0 / 9.0) : fl; }
         if (prof >= 3) {
             const char* path = conv_uses_halo(p, hint) ? (p.in_scale ? (p.in_silu ? "halo+gn+silu" : "halo+gn") : "halo") : igemm_uses_pgemm(p, hint) ? "pgemm" : "igemm";
             mark(std::string(p.ks == 3 ? (p.ups ? "conv3x3up " : (p.stride == 2 ? "conv3x3s2 " : "conv3x3 ")) : (p.batch > 1 ? "bgemm " : "gemm ")) + path + " M=" + std::to_string(p.M) +
@@ -1569,7 +1570,16 @@ gp_status gp_set_profile(gp_engine* e, int level) {
 gp_status gp_reset_timings(gp_engine* e) {
     if (!e) return GP_ERR_INVALID;
     e->tm = gp_timings{};
+    e->flops_halo_exec = 0.0;
     e->ev_used = 0;
+    return GP_OK;
+}
+/* MFMA flops the halo-conv launches EXECUTED since gp_reset_timings.  gp_timings.flops_halo counts algorithmic flops (2 M N 9 Cin, what a roofline
+ * figure is quoted on); the two differ where a launch does less arithmetic than its algorithmic count: the x2-upsample convs run as four 2 x 2-tap phase
+ * convolutions, 4/9 of the flops (conv_halo.hip, PH).  (A new entry point, not a new field: gp_timings is frozen.) */
+gp_status gp_halo_executed_flops(gp_engine* e, double* flops) {
+    if (!e || !flops) return GP_ERR_INVALID;
+    *flops = e->flops_halo_exec;
     return GP_OK;
 }
 gp_status gp_get_timings(gp_engine* e, gp_timings* out) {

@@ -100,6 +100,7 @@ SYMBOLS = {
     "gp_set_profile": (_i, [_vp, _i]),
     "gp_get_timings": (_i, [_vp, C.POINTER(GpTimings)]),
     "gp_reset_timings": (_i, [_vp]),
+    "gp_halo_executed_flops": (_i, [_vp, C.POINTER(C.c_double)]),
     "gp_saturation_events": (_i, [_vp, C.POINTER(C.c_longlong), _i]),
     "gp_get_launch_log": (_i, [_vp, C.c_char_p, _i]),
     "gp_packed_rows": (_i, [_i]),
@@ -364,6 +365,13 @@ class Engine:
         t = GpTimings()
         self._check(self.lib.gp_get_timings(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in GpTimings._fields_}
+
+    def halo_executed_flops(self) -> float:
+        """MFMA flops the halo-conv launches executed since reset_timings (`gp_halo_executed_flops`): below timings()["flops_halo"] (algorithmic)
+        by the 5/9 the phase-decomposed x2-upsample convs do not execute."""
+        v = C.c_double(0.0)
+        self._check(self.lib.gp_halo_executed_flops(self._h, C.byref(v)))
+        return float(v.value)
 
     def saturation_events(self, reset: bool = False) -> int:
         """fp16 library: (call, kernel file) pairs since the last reset in which a saturating fp32 -> fp16 conversion actually clipped

@@ -140,6 +140,9 @@ gp_status gp_get_timings(gp_engine* e, gp_timings* out);
  * range) always reports 0.  Synchronises the engine's stream.  The Python pipeline logs a warning when a call raised events. */
 gp_status gp_saturation_events(gp_engine* e, long long* events, int reset);
 gp_status gp_reset_timings(gp_engine* e);
+/* executed (not algorithmic) MFMA flops of the halo-conv launches since gp_reset_timings: equals gp_timings.flops_halo except for launches that do
+ * less arithmetic than their algorithmic count (the x2-upsample convs as four 2x2-tap phase convolutions: 4/9) */
+gp_status gp_halo_executed_flops(gp_engine* e, double* flops);
 /* Profiling level 3: text log of the last gp_infer, one line "ms<TAB>algorithmic flops<TAB>description" per kernel launch
  * (ms = start-to-next-start on the stream: kernel time plus the gap behind it).  Returns the bytes needed (incl. NUL). */
 int gp_get_launch_log(gp_engine* e, char* buf, int cap);
