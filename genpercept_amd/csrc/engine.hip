@@ -648,6 +648,7 @@ struct gp_engine {
         // ---------------- DPT head ----------------
         if (cfg.dpt_enabled && has("dpt.neck.convs.0.weight")) {
             convs["dpt.feature_upsample_0.conv"] = pack_named("dpt.feature_upsample_0.conv", 3);
+            pack_phases(convs["dpt.feature_upsample_0.conv"], "dpt.feature_upsample_0.conv");  // (x2 nearest + 3x3: four phase convolutions, conv_halo.hip PH)
             for (int i = 0; i < 4; ++i) {
                 convs["dpt.neck.convs." + std::to_string(i)] = pack_named("dpt.neck.convs." + std::to_string(i), 3);
                 const std::string lp = "dpt.neck.fusion_stage.layers." + std::to_string(i);
@@ -1331,12 +1332,15 @@ struct gp_engine {
             }
             Act x2 = rcu(x, lp + ".residual_layer2");
             drop(x);
-            Act up = new_act(x2.B, x2.H * 2, x2.W * 2, x2.C);
-            mark("bilinear " + dims(up));
-            launch_bilinear(x2.p, up.p, x2.B, x2.H, x2.W, x2.H * 2, x2.W * 2, x2.C, 1, st);
+            // dpt_head.py:303-309 interpolates (bilinear x2, align_corners) and THEN applies the 1x1 projection.  The two commute -- the projection mixes
+            // channels per pixel, the interpolation mixes pixels per channel with weights that sum to one, so the bias passes through as well --
+            // and the projection on the SOURCE map is a quarter of the GEMM and of its HBM traffic (r5)
+            Act pr = linear(x2, convs.at(lp + ".projection"));
             drop(x2);
-            fused = linear(up, convs.at(lp + ".projection"));
-            drop(up);
+            fused = new_act(pr.B, pr.H * 2, pr.W * 2, pr.C);
+            mark("bilinear " + dims(fused));
+            launch_bilinear(pr.p, fused.p, pr.B, pr.H, pr.W, pr.H * 2, pr.W * 2, pr.C, 1, st);
+            drop(pr);
         }
         ConvOpt op;
         op.act = GP_ACT_RELU;
