@@ -75,6 +75,10 @@ for cap in (need, 1, 2):
     assert lib.gp_get_launch_log(hdl, buf, cap) == need
 if not has_gpu:   # finalize needs the device: the error path must leave the engine destroyable
     assert lib.gp_finalize(hdl) != 0 and lib.gp_last_error(hdl).decode() != ""
+fl = C.c_double(-1.0)
+assert lib.gp_halo_executed_flops(hdl, C.byref(fl)) == 0 and fl.value == 0.0 and lib.gp_halo_executed_flops(None, C.byref(fl)) != 0
+assert lib.gp_pack_weight_phases(None, 8, 4, 64, None) != 0 and lib.gp_pack_weight_phases(x32.ctypes.data, 8, 4, 3, x32.ctypes.data) != 0   # (bad cin_pad)
+assert lib.gp_conv2d_up2(None, None, None, None, None, None, 1, 16, 16, 64, 64, None) != 0
 ev = C.c_longlong(-1)
 lib.gp_saturation_events(hdl, C.byref(ev), 1)
 lib.gp_destroy(hdl)

@@ -209,3 +209,29 @@ def test_oracle_matches_genpercept_v1_single_infer_executed():
             # the 77-row context is NOT the 2-row context (75 padding keys take part in the softmax): the two fixtures differ, the engine has
             # to honour the context it is given (gp_set_context folds L = 2 and keeps the general kernel for other lengths)
             assert np.abs(r[f"{tag}_ctx2_depth"] - r[f"{tag}_ctx77_depth"]).max() > 1e-4
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 5, 7), (2, 16, 16, 16), (1, 4, 17, 33), (1, 3, 1, 1)])
+def test_upsample_conv_phase_identity(shape):
+    """The identity conv3x3_halo3_kernel<..., PH> is built on (genpercept_amd/csrc/conv_halo.hip; diffusers Upsample2D = nearest x2 then conv3x3, used by
+    custom_unet.py:372-400's up blocks and the VAE decoder): output pixel (2y + a, 2x + b) of conv3x3(upsample2(s)) is a 2 x 2-tap convolution of the
+    SOURCE map with the kernel rows / columns that fall onto the same source pixel summed -- a = 0: {w0}, {w1 + w2}; a = 1: {w0 + w1}, {w2} -- and the
+    zero padding of the upsampled map is the zero padding of the source map.  Checked in float64 on maps with odd sizes down to one pixel; the kernel's
+    own packing (engine.hip: pack_phase_rows) is checked against this construction on the GPU (tests/test_kernels_gpu.py)."""
+    import torch.nn.functional as F
+    b, c, h, w = shape
+    g = torch.Generator().manual_seed(h * 100 + w)
+    x = torch.randn(b, c, h, w, generator=g, dtype=torch.float64)
+    wt = torch.randn(5, c, 3, 3, generator=g, dtype=torch.float64)
+    bias = torch.randn(5, generator=g, dtype=torch.float64)
+    exact = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wt, bias, padding=1)
+    rng = {0: [(0, 0), (1, 2)], 1: [(0, 1), (2, 2)]}     # phase -> kernel index ranges of its two taps
+    out = torch.empty_like(exact)
+    for a in (0, 1):
+        for bb in (0, 1):
+            wp = torch.zeros(5, c, 2, 2, dtype=torch.float64)
+            for ty, (y0, y1) in enumerate(rng[a]):
+                for tx, (x0, x1) in enumerate(rng[bb]):
+                    wp[:, :, ty, tx] = wt[:, :, y0:y1 + 1, x0:x1 + 1].sum(dim=(2, 3))
+            out[:, :, a::2, bb::2] = F.conv2d(F.pad(x, (1 - bb, bb, 1 - a, a)), wp, bias)   # source rows y - 1 + a .. y + a, columns x - 1 + b .. x + b
+    assert float((out - exact).abs().max()) < 1e-12
