@@ -13,7 +13,7 @@ LIBDIR = os.path.join(HERE, "lib")
 # one library per 16-bit element type (csrc/common.h): same sources, same C-ABI, GP_F16 selects IEEE fp16 instead of bf16
 LIBS = {"bf16": os.path.join(LIBDIR, "libgenpercept_hip.so"), "fp16": os.path.join(LIBDIR, "libgenpercept_hip_f16.so")}
 LIB = LIBS["bf16"]
-SOURCES = ["igemm.hip", "conv_halo.hip", "pgemm.hip", "conv_few.hip", "conv_img.hip", "norm.hip", "attention.hip", "elementwise.hip", "prepost.hip", "microbench.hip", "engine.hip"]
+SOURCES = ["igemm.hip", "conv_halo.hip", "pgemm.hip", "conv_few.hip", "conv_img.hip", "contract.hip", "norm.hip", "attention.hip", "elementwise.hip", "prepost.hip", "microbench.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("GENPERCEPT_HIPCC_FLAGS", "").split()  # e.g. -DGP_HALO_ABLATIONS=1 for the profiling variants of conv_halo.hip
 

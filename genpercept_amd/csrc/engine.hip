@@ -76,6 +76,17 @@ inline float half_to_float(uint16_t h) {
     return f;
 }
 
+inline float h16_to_float_host(h16_t h) {
+#if GP_F16
+    return half_to_float(h);
+#else
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+
 struct HostTensor {
     std::vector<float> v;
     std::vector<int64_t> shape;
@@ -121,6 +132,9 @@ struct Pool {
 
 struct Act {
     h16_t* p = nullptr;
+    // contract precision (contract.hip): a STORED tensor is fp32 (`f`, C channels per pixel); a matrix-product operand is a split tensor (`p`, with
+    // C = 3 x the logical width: [hi | lo | hi] blocks).  Exactly one of p / f is set.
+    float* f = nullptr;
     int B = 0, H = 0, W = 0, C = 0;  // C = allocated channels (row stride)
     // GroupNorm partial statistics written by the producing conv's epilogue ([pixel tile][C][2] fp32; owned with p)
     float* st = nullptr;
@@ -162,6 +176,7 @@ struct TfW {
 struct VaeAttnW {
     NormW gn;
     PackedW qk, v, o;
+    PackedW qkv;  // contract precision: to_q | to_k | to_v stacked, unscaled (the softmax kernel applies 1 / sqrt(C))
     int C = 0;
 };
 
@@ -199,6 +214,9 @@ struct gp_engine {
     int gn_fuse_always_below_px = 0;   // GENPERCEPT_GN_FUSE_BELOW_PX: maps with fewer pixels per image fuse whatever the slice count (r1: 16384; r2 in-box
                                        // A/B with the faster apply / one-launch small-map GroupNorm: 0 is 1.3 ms per pass faster)
     bool fuse_stats = true;  // GENPERCEPT_NO_STATS_FUSION=1 keeps the separate statistics pass
+    // gp_set_precision(GP_PREC_CONTRACT): fp32 storage + split-bf16 operands (three MFMAs per product over a tripled K), see contract.hip.
+    // Weights are packed [n_rows][taps][3 cin_pad] in B order [hi | hi | lo]; every PackedW::cin_pad below is then the TRIPLED width.
+    bool contract = false;
 
     std::unordered_map<std::string, PackedW> convs;
     std::unordered_map<std::string, NormW> norms;
@@ -260,18 +278,29 @@ struct gp_engine {
         return (r / 16) * 32 + ((r % 16) / 4) * 8 + (gate ? 4 : 0) + (r % 4);
     }
     // Pack [cout][cin][ks][ks] fp32 -> [n_rows][taps][cin_pad] bf16 (+ optional GEGLU row interleave).
-    static void pack_rows(const float* w, int cout, int cin, int ks, int cin_pad, bool geglu, std::vector<h16_t>& out, int row0, int n_rows_total) {
+    // split: cin_pad is the logical padded width, the row holds 3 cin_pad elements per tap in B order [hi | hi | lo] (contract precision)
+    static void pack_rows(const float* w, int cout, int cin, int ks, int cin_pad, bool geglu, std::vector<h16_t>& out, int row0, int n_rows_total,
+                          bool split = false) {
         const int taps = ks * ks;
         (void)n_rows_total;
+        const size_t kw = split ? (size_t)3 * cin_pad : (size_t)cin_pad;  // elements per tap
         for (int n = 0; n < cout; ++n) {
             int dst = n;
             if (geglu) {
                 dst = geglu_row(n, cout);
             }
-            h16_t* o = out.data() + (size_t)(row0 + dst) * taps * cin_pad;
+            h16_t* o = out.data() + (size_t)(row0 + dst) * taps * kw;
             const float* wi = w + (size_t)n * cin * taps;
             for (int c = 0; c < cin; ++c)
-                for (int t = 0; t < taps; ++t) o[(size_t)t * cin_pad + c] = f_to_h16_host(wi[(size_t)c * taps + t]);
+                for (int t = 0; t < taps; ++t) {
+                    const float x = wi[(size_t)c * taps + t];
+                    const h16_t hi = f_to_h16_host(x);
+                    o[(size_t)t * kw + c] = hi;
+                    if (split) {
+                        o[(size_t)t * kw + cin_pad + c] = hi;
+                        o[(size_t)t * kw + 2 * cin_pad + c] = f_to_h16_host(x - h16_to_float_host(hi));
+                    }
+                }
         }
     }
     // The x2-nearest-upsample 3x3 conv as four 2 x 2-tap phase convolutions on the source map (conv_halo.hip, PH): output pixel (2y + a, 2x + b) reads
@@ -295,18 +324,19 @@ struct gp_engine {
                         }
     }
     void pack_phases(PackedW& pw, const std::string& name) {
+        if (contract) return;  // (contract precision runs the nine-tap upsample kernel)
         const HostTensor& w = H(name + ".weight");
-        const int cout = (int)w.shape[0], cin = (int)w.shape[1];
         if (w.shape.size() != 4 || w.shape[2] != 3 || w.shape[3] != 3) throw std::invalid_argument(name + ": not a 3x3 conv");
+        const int cout = (int)w.shape[0], cin = (int)w.shape[1];
         std::vector<h16_t> buf((size_t)pw.n_rows * 16 * pw.cin_pad, 0);
         pack_phase_rows(w.v.data(), cout, cin, pw.cin_pad, buf);
         pw.w_ph = upload(buf.data(), buf.size());
     }
     PackedW pack(const float* w, const float* bias, int cout, int cin, int ks, int cin_pad, bool geglu = false) {
         PackedW pw;
-        pw.cout = cout; pw.cin_pad = cin_pad; pw.ks = ks; pw.n_rows = gp_packed_rows(cout);
-        std::vector<h16_t> buf((size_t)pw.n_rows * ks * ks * cin_pad, 0);
-        pack_rows(w, cout, cin, ks, cin_pad, geglu, buf, 0, pw.n_rows);
+        pw.cout = cout; pw.cin_pad = contract ? 3 * cin_pad : cin_pad; pw.ks = ks; pw.n_rows = gp_packed_rows(cout);
+        std::vector<h16_t> buf((size_t)pw.n_rows * ks * ks * pw.cin_pad, 0);
+        pack_rows(w, cout, cin, ks, cin_pad, geglu, buf, 0, pw.n_rows, contract);
         pw.w = upload(buf.data(), buf.size());
         if (bias) {
             std::vector<float> b(bias, bias + cout);
@@ -415,8 +445,11 @@ struct gp_engine {
         a.C = a.gn.C;
         // softmax(q k^T / sqrt(C)): the scale goes into the query projection, so the logits the score GEMM writes are the SCALED ones
         // (what diffusers keeps in fp16 too); raw 512-term dot products of a real checkpoint can pass fp16's 65504
-        a.qk = pack_stacked(q, k, 1.0f / std::sqrt((float)a.C));
-        a.v = pack_named(v, 1);
+        if (contract) a.qkv = pack_stacked(std::vector<std::string>{q, k, v});
+        else {
+            a.qk = pack_stacked(q, k, 1.0f / std::sqrt((float)a.C));
+            a.v = pack_named(v, 1);
+        }
         a.o = pack_named(o, 1);
         vattn[p] = std::move(a);
     }
@@ -682,9 +715,27 @@ struct gp_engine {
     }
     void drop(Act& a) {
         pool.release(a.p);
+        pool.release(a.f);
         if (a.st) pool.release(a.st);
         a.p = nullptr;
+        a.f = nullptr;
         a.st = nullptr;
+    }
+    // ---- contract precision: stored tensors (fp32) and split operands -----------------------------------------------------------------
+    Act new_act_f(int B, int H, int W, int C) {
+        Act a;
+        a.B = B; a.H = H; a.W = W; a.C = C;
+        a.f = (float*)pool.alloc((size_t)B * H * W * C * sizeof(float));
+        return a;
+    }
+    Act new_operand(int B, int H, int W, int C_logical) { return new_act(B, H, W, 3 * C_logical); }
+    // A-order split of a stored tensor (optionally through ReLU): the operand form a conv / linear layer reads
+    Act split_operand(const Act& x, int act = GP_ACT_NONE) {
+        if (!x.f) throw std::logic_error("split_operand: not a stored fp32 tensor");
+        Act y = new_operand(x.B, x.H, x.W, x.C);
+        mark("split3 " + dims(x));
+        launch_c_split3(x.f, x.C, y.p, x.pixels(), x.C, 0, act, 1.0f, st);
+        return y;
     }
     // ask the kernel that is about to write `y` to leave per-tile channel statistics behind (next GroupNorm skips its read pass)
     void attach_stats(Act& y, IGemmParams& p) {
@@ -734,7 +785,8 @@ struct gp_engine {
     }
     void run_igemm(const IGemmParams& p, int hint = 0) {
         const int taps = p.ks == 3 ? 9 : 1;
-        const double fl = 2.0 * (double)p.M * (double)p.N * (double)p.Cin * taps * (p.batch > 0 ? p.batch : 1);
+        // (contract precision: K is tripled -- hi.hi + lo.hi + hi.lo -- and the ALGORITHMIC count is a third of what the kernel executes)
+        const double fl = 2.0 * (double)p.M * (double)p.N * (double)p.Cin * taps * (p.batch > 0 ? p.batch : 1) / (contract ? 3.0 : 1.0);
         const bool halo = conv_uses_halo(p, hint);
         tm.flops_igemm += fl;
         tm.n_igemm++;
@@ -744,7 +796,7 @@ struct gp_engine {
             mark(std::string(p.ks == 3 ? (p.ups ? "conv3x3up " : (p.stride == 2 ? "conv3x3s2 " : "conv3x3 ")) : (p.batch > 1 ? "bgemm " : "gemm ")) + path + " M=" + std::to_string(p.M) +
                      " N=" + std::to_string(p.N) + " K=" + std::to_string(p.Cin * taps) + (p.batch > 1 ? " batch=" + std::to_string(p.batch) : "") + (p.res ? " +res" : "") +
                      (p.act == GP_ACT_GEGLU ? " geglu" : "") + (p.stats_out ? " +stats" : "") + (p.vt_out ? " q|k|vT" : ""),
-                 2.0 * (double)p.M * (double)p.N * (double)p.Cin * taps * (p.batch > 0 ? p.batch : 1));
+                 fl);
         } else {
             tm.n_launches++;
         }
@@ -767,6 +819,7 @@ struct gp_engine {
         int Ho = 0, Wo = 0;     // 0: same as input (or upsampled size)
         int ups_h = 0, ups_w = 0;
         const h16_t* res = nullptr;
+        const float* res_f = nullptr;  // contract precision: the residual is a stored fp32 tensor
         int act = GP_ACT_NONE;
         int n_store = 0;        // 0: cout
         bool want_stats = false;  // the output feeds a GroupNorm
@@ -788,7 +841,22 @@ struct gp_engine {
         p.batch = 1;
         return p;
     }
+    // contract precision: split operand in (made here when x is a stored tensor), fp32 rows out, fp32 residual
+    Act conv_c(const Act& x0, const PackedW& w, const ConvOpt& o) {
+        Act xs = x0;
+        const bool tmp = x0.p == nullptr;
+        if (tmp) xs = split_operand(x0);
+        IGemmParams p = conv_params(xs, w, o, nullptr);
+        Act y = new_act_f(xs.B, p.Ho, p.Wo, p.n_store);
+        p.out = y.f; p.out_fp32 = 1;
+        p.res = (const h16_t*)o.res_f; p.res_f32 = o.res_f ? 1 : 0;
+        if (o.want_stats) attach_stats(y, p);
+        run_igemm(p);
+        if (tmp) drop(xs);
+        return y;
+    }
     Act conv(const Act& x, const PackedW& w, const ConvOpt& o, const float* in_scale = nullptr, const float* in_shift = nullptr, bool in_silu = false) {
+        if (contract) return conv_c(x, w, o);
         IGemmParams p = conv_params(x, w, o, nullptr);
         Act y = new_act(x.B, p.Ho, p.Wo, p.n_store);
         p.out = y.p;
@@ -799,8 +867,33 @@ struct gp_engine {
         return y;
     }
     // y[M][N] = x[M][K] W^T (+bias) (+res), N = w.cout (GEGLU halves it)
+    // contract precision: y fp32 [M][N] = split(x) W^T (+bias) (+res fp32); out_inplace: write into that fp32 buffer (it may be `res`)
+    Act linear_c(const Act& x0, const PackedW& w, const float* res = nullptr, int act = GP_ACT_NONE, float* out_inplace = nullptr, bool want_stats = false) {
+        Act xs = x0;
+        const bool tmp = x0.p == nullptr;
+        if (tmp) xs = split_operand(x0);
+        if (xs.C != w.cin_pad) throw std::logic_error("linear: channel mismatch");
+        const int nout = act == GP_ACT_GEGLU ? w.cout / 2 : w.cout;
+        Act y;
+        if (out_inplace) { y.B = xs.B; y.H = xs.H; y.W = xs.W; y.C = nout; y.f = out_inplace; }
+        else y = new_act_f(xs.B, xs.H, xs.W, nout);
+        IGemmParams p{};
+        p.in = xs.p; p.wt = w.w; p.bias = w.bias; p.res = (const h16_t*)res; p.res_f32 = res ? 1 : 0; p.out = y.f; p.out_fp32 = 1; p.zero = zero;
+        p.M = (int)xs.pixels(); p.N = w.cout; p.Cin = w.cin_pad; p.n_rows = w.n_rows; p.ks = 1;
+        p.B = xs.B; p.Hi = xs.H; p.Wi = xs.W; p.Ho = xs.H; p.Wo = xs.W; p.stride = 1;
+        p.lda = xs.C; p.ldo = nout; p.ldres = nout; p.ldw = w.cin_pad; p.n_store = nout; p.act = act;
+        p.bias_mode = w.bias ? GP_BIAS_COL : GP_BIAS_NONE; p.batch = 1;
+        if (want_stats && !out_inplace) attach_stats(y, p);
+        run_igemm(p);
+        if (tmp) drop(xs);
+        return y;
+    }
     Act linear(const Act& x, const PackedW& w, const h16_t* res = nullptr, int act = GP_ACT_NONE, h16_t* out_inplace = nullptr,
                bool want_stats = false) {
+        if (contract) {
+            if (res || out_inplace) throw std::logic_error("linear: 16-bit residual in contract precision");
+            return linear_c(x, w, nullptr, act, nullptr, want_stats);
+        }
         if (x.C != w.cin_pad) throw std::logic_error("linear: channel mismatch");
         const int nout = act == GP_ACT_GEGLU ? w.cout / 2 : w.cout;
         Act y;
@@ -839,6 +932,15 @@ struct gp_engine {
         float* ws = gn_workspace(x);
         scale = ws + groupnorm_ws_floats(x.B, x.H * x.W, x.C, cfg.norm_groups);
         shift = scale + (size_t)x.B * x.C;
+        if (contract && !x.st) {  // statistics pass over the fp32 tensor: per-row partials in the layout the tile finaliser reads ("mode 2")
+            const int R = c_gn_stat_rows(x.H * x.W, x.C, nullptr);
+            float* part = (float*)pool.alloc((size_t)x.B * R * (2 * x.C + 1) * sizeof(float));
+            mark("c_gn_stats+finalize " + dims(x), 0.0, 2);
+            launch_c_gn_stats(x.f, part, x.B, x.H * x.W, x.C, st);
+            launch_groupnorm_from_partials(part, 2, R, x.B, x.H, x.W, x.C, cfg.norm_groups, eps, n.g, n.b, scale, shift, st);
+            pool.release(part);
+            return;
+        }
         if (x.st) {
             mark("gn_finalize_tiles " + dims(x));
             launch_groupnorm_from_partials(x.st, x.st_mode, x.st_bm, x.B, x.H, x.W, x.C, cfg.norm_groups, eps, n.g, n.b, scale, shift, st);
@@ -848,7 +950,7 @@ struct gp_engine {
         }
     }
     // one-launch GroupNorm for small maps whose producer left no statistics behind (split-K convs of the 12x12 level, ...)
-    bool gn_small(const Act& x) const { return !x.st && groupnorm_small_applicable(x.B, x.H * x.W, x.C, cfg.norm_groups) && !gp_sw().no_gn_small; }
+    bool gn_small(const Act& x) const { return !contract && !x.st && groupnorm_small_applicable(x.B, x.H * x.W, x.C, cfg.norm_groups) && !gp_sw().no_gn_small; }
     Act groupnorm_small(const Act& x, const NormW& n, float eps, bool silu) {
         if (x.C != n.C) throw std::logic_error("groupnorm: channel mismatch");
         Act y = new_act(x.B, x.H, x.W, x.C);
@@ -860,6 +962,12 @@ struct gp_engine {
         if (gn_small(x)) return groupnorm_small(x, n, eps, silu);
         float *scale, *shift;
         gn_scale_shift(x, n, eps, scale, shift);
+        if (contract) {  // the normalised tensor only ever feeds a matrix product: written as its split operand
+            Act y = new_operand(x.B, x.H, x.W, x.C);
+            mark("c_gn_apply_split " + dims(x));
+            launch_c_gn_apply_split(x.f, y.p, scale, shift, x.B, x.H * x.W, x.C, silu ? 1 : 0, st);
+            return y;
+        }
         Act y = new_act(x.B, x.H, x.W, x.C);
         mark("gn_apply " + dims(x));
         launch_groupnorm_apply(x.p, y.p, scale, shift, x.B, x.H * x.W, x.C, silu ? 1 : 0, st);
@@ -878,6 +986,12 @@ struct gp_engine {
     // conv(act(GroupNorm(x))): statistics pass, then the normalisation is applied either inside the conv kernel on the staged
     // input halo (conv_halo.hip) or, when that kernel does not take the layer, by the separate apply pass.
     Act conv_gn(const Act& x, const NormW& n, float eps, bool silu, const PackedW& w, const ConvOpt& o) {
+        if (contract) {
+            Act y = groupnorm(x, n, eps, silu);
+            Act out = conv(y, w, o);
+            drop(y);
+            return out;
+        }
         if (gn_small(x)) {
             IGemmParams p0 = conv_params(x, w, o, nullptr);
             if (!conv_uses_halo(p0, 0)) {  // (a halo conv would fuse the apply: keep the statistics path for it)
@@ -906,6 +1020,12 @@ struct gp_engine {
         return out;
     }
     Act layernorm(const Act& x, const NormW& n) {
+        if (contract) {
+            Act y = new_operand(x.B, x.H, x.W, x.C);
+            mark("c_layernorm_split " + dims(x));
+            launch_c_layernorm_split(x.f, y.p, n.g, n.b, (int)x.pixels(), x.C, 1e-5f, st);
+            return y;
+        }
         Act y = new_act(x.B, x.H, x.W, x.C);
         mark("layernorm " + dims(x));
         launch_layernorm(x.p, y.p, n.g, n.b, (int)x.pixels(), x.C, 1e-5f, st);
@@ -921,6 +1041,7 @@ struct gp_engine {
         if (r.has_sc) sc = linear(x, r.sc);
         ConvOpt o;
         o.res = sc.p;
+        o.res_f = sc.f;
         o.want_stats = true;
         Act y = conv_gn(h, r.n2, eps, true, r.c2, o);
         drop(h);
@@ -961,8 +1082,104 @@ struct gp_engine {
         pool.release(P);
     }
 
+    // contract precision: softmax(scale q k^T) v per head with fp32 logits in HBM (head split -> batched logits GEMM -> row softmax -> batched
+    // P.V GEMM -> head merge; every product over split operands).  qkv: stored [B*T][3C] with q | k | v at columns 0 | C | 2C; returns the
+    // A-order operand [B*T][3C] the output projection reads.
+    Act attention_c(const Act& qkv, int heads, int hd, float scale) {
+        const int B = qkv.B, T = qkv.H * qkv.W, Tpad = round_up(T, 64), Z = B * heads;
+        if (!c_softmax_split_supported(Tpad)) throw std::invalid_argument("contract precision: at most 16384 tokens per attention map");
+        if (hd % 64 || qkv.C != 3 * heads * hd) throw std::logic_error("attention_c: layout");
+        h16_t* Qs = (h16_t*)pool.alloc((size_t)Z * T * 3 * hd * sizeof(h16_t));
+        h16_t* Ks = (h16_t*)pool.alloc((size_t)Z * T * 3 * hd * sizeof(h16_t));
+        h16_t* Vts = (h16_t*)pool.alloc((size_t)Z * hd * 3 * Tpad * sizeof(h16_t));
+        mark("c_heads_split T=" + std::to_string(T) + " heads=" + std::to_string(heads), 0.0, 2);
+        launch_c_heads_split(qkv.f, qkv.C, Qs, Ks, Vts, B, T, Tpad, heads, hd, st);
+        float* S = (float*)pool.alloc((size_t)Z * T * Tpad * sizeof(float));
+        {
+            IGemmParams p{};
+            p.in = Qs; p.wt = Ks; p.out = S; p.zero = zero;
+            p.M = T; p.N = T; p.Cin = 3 * hd; p.n_rows = T; p.ks = 1; p.stride = 1;
+            p.lda = 3 * hd; p.ldw = 3 * hd; p.ldo = Tpad; p.n_store = T; p.out_fp32 = 1;
+            p.batch = Z; p.in_bs = (long long)T * 3 * hd; p.wt_bs = (long long)T * 3 * hd; p.out_bs = (long long)T * Tpad;
+            run_igemm(p);
+        }
+        pool.release(Qs);
+        pool.release(Ks);
+        h16_t* P = (h16_t*)pool.alloc((size_t)Z * T * 3 * Tpad * sizeof(h16_t));
+        mark("c_softmax_split T=" + std::to_string(T));
+        launch_c_softmax_split(S, P, (long long)Z * T, T, Tpad, scale, st);
+        pool.release(S);
+        float* O = (float*)pool.alloc((size_t)Z * T * hd * sizeof(float));
+        {
+            IGemmParams p{};
+            p.in = P; p.wt = Vts; p.out = O; p.zero = zero;
+            p.M = T; p.N = hd; p.Cin = 3 * Tpad; p.n_rows = hd; p.ks = 1; p.stride = 1;
+            p.lda = 3 * Tpad; p.ldw = 3 * Tpad; p.ldo = hd; p.n_store = hd; p.out_fp32 = 1;
+            p.batch = Z; p.in_bs = (long long)T * 3 * Tpad; p.wt_bs = (long long)hd * 3 * Tpad; p.out_bs = (long long)T * hd;
+            run_igemm(p);
+        }
+        pool.release(P);
+        pool.release(Vts);
+        Act a = new_operand(qkv.B, qkv.H, qkv.W, heads * hd);
+        mark("c_heads_merge_split " + dims(a));
+        launch_c_heads_merge_split(O, a.p, B, T, heads, hd, st);
+        pool.release(O);
+        tm.flops_attn += 4.0 * Z * (double)T * T * hd;
+        tm.n_attn++;
+        return a;
+    }
+    Act vae_attention_c(const Act& x, const VaeAttnW& a) {
+        Act n = groupnorm(x, a.gn, cfg.vae_norm_eps, false);
+        Act qkv = linear_c(n, a.qkv);
+        drop(n);
+        Act o = attention_c(qkv, 1, a.C, 1.0f / std::sqrt((float)a.C));
+        drop(qkv);
+        Act y = linear_c(o, a.o, x.f, GP_ACT_NONE, nullptr, true);
+        drop(o);
+        return y;
+    }
+    // BasicTransformerBlock inside Transformer2DModel (custom_unet.py call sites :305-327,341-352), contract precision
+    Act transformer_c(const Act& x, const TfW& t) {
+        const int C = t.C;
+        Act n = groupnorm(x, t.gn, 1e-6f, false);
+        Act y = linear_c(n, t.proj_in);
+        drop(n);
+        Act l1 = layernorm(y, t.ln1);
+        Act qkv = linear_c(l1, t.qkv);
+        drop(l1);
+        Act a = attention_c(qkv, t.heads, 64, 0.125f);
+        drop(qkv);
+        linear_c(a, t.o1, y.f, GP_ACT_NONE, y.f);  // y += to_out(attn), in place
+        drop(a);
+        Act l3;
+        if (t.fU && c_cross_fold_supported(C)) {
+            l3 = new_operand(x.B, x.H, x.W, C);
+            mark("c_cross_fold " + dims(y));
+            launch_c_cross_fold(y.f, y.f, l3.p, t.fU, t.fu0, t.fG, t.fc0, t.ln3.g, t.ln3.b, (int)x.pixels(), C, t.heads, 1e-5f, st);
+        } else {
+            Act l2 = layernorm(y, t.ln2);
+            Act q2 = linear_c(l2, t.q2);
+            drop(l2);
+            Act a2 = new_operand(x.B, x.H, x.W, C);
+            mark("c_cross_attn_small " + dims(q2));
+            launch_c_cross_attn_small(q2.f, t.kc, t.vc, a2.p, (int)x.pixels(), C, ctx_L, st);
+            drop(q2);
+            linear_c(a2, t.o2, y.f, GP_ACT_NONE, y.f);
+            drop(a2);
+            l3 = layernorm(y, t.ln3);
+        }
+        Act ff = linear_c(l3, t.ff1, nullptr, GP_ACT_GEGLU);
+        drop(l3);
+        linear_c(ff, t.ff2, y.f, GP_ACT_NONE, y.f);
+        drop(ff);
+        Act out = linear_c(y, t.proj_out, x.f, GP_ACT_NONE, nullptr, true);
+        drop(y);
+        return out;
+    }
+
     Act vae_attention(const Act& x, const std::string& name) {
         const VaeAttnW& a = vattn.at(name);
+        if (contract) return vae_attention_c(x, a);
         const int T = x.H * x.W, C = a.C, Tpad = round_up(T, 64), B = x.B;
         Act n = groupnorm(x, a.gn, cfg.vae_norm_eps, false);
         Act qk = linear(n, a.qk);  // [B*T][2C]
@@ -997,6 +1214,7 @@ struct gp_engine {
     Act transformer(const Act& x, const std::string& name) {
         const TfW& t = tfs.at(name);
         if (!t.kc) throw std::logic_error("gp_set_context has not been called");
+        if (contract) return transformer_c(x, t);
         const int T = x.H * x.W, C = t.C, Tpad = round_up(T, 64);
         Act n = groupnorm(x, t.gn, 1e-6f, false);
         Act y = linear(n, t.proj_in);
@@ -1076,7 +1294,15 @@ struct gp_engine {
     Act vae_encode(const void* rgb, int is_u8, int B, int Hh, int Ww) {
         const PackedW& win = convs.at("vae.encoder.conv_in");
         Act h;
-        if (win.cout % 32 == 0 && win.cin_pad == 64 && !gp_sw().no_rgb_conv) {
+        if (contract) {  // x / 255 * 2 - 1 is not a bf16 number: the image itself enters as a split operand
+            Act xs = new_operand(B, Hh, Ww, 64);
+            mark("c_rgb_split");
+            launch_c_rgb_split(rgb, is_u8, xs.p, B, Hh, Ww, st);
+            ConvOpt oin;
+            oin.want_stats = true;
+            h = conv(xs, win, oin);
+            drop(xs);
+        } else if (win.cout % 32 == 0 && win.cin_pad == 64 && !gp_sw().no_rgb_conv) {
             // u8 image -> conv_in output in one kernel (K = 27), statistics for the first resnet's norm1 included
             h = new_act(B, Hh, Ww, win.cout);
             if (fuse_stats) {
@@ -1177,10 +1403,12 @@ struct gp_engine {
             for (int j = 0; j < nres; ++j) {
                 Act skip = skips.back();
                 skips.pop_back();
-                Act cat = new_act(h.B, h.H, h.W, h.C + skip.C);
-                const int cbm = fuse_stats ? concat_stats_bm((long long)h.H * h.W, h.pixels(), h.C + skip.C) : 0;
+                Act cat = contract ? new_act_f(h.B, h.H, h.W, h.C + skip.C) : new_act(h.B, h.H, h.W, h.C + skip.C);
+                const int cbm = (fuse_stats && !contract) ? concat_stats_bm((long long)h.H * h.W, h.pixels(), h.C + skip.C) : 0;
                 mark("concat " + dims(cat));
-                if (cbm) {  // the copy also leaves the statistics the resnet's first GroupNorm needs
+                if (contract) {
+                    launch_c_concat(h.f, h.C, skip.f, skip.C, cat.f, h.pixels(), st);
+                } else if (cbm) {  // the copy also leaves the statistics the resnet's first GroupNorm needs
                     cat.st = (float*)pool.alloc((size_t)(h.pixels() / cbm) * cat.C * 2 * sizeof(float));
                     cat.st_mode = 0;
                     cat.st_bm = cbm;
@@ -1233,9 +1461,10 @@ struct gp_engine {
     // the last three layers (conv_few.hip) it is written directly and the returned Act is empty, else the caller runs launch_decode_epilogue
     Act vae_decode(const Act& z_in, float in_scale, float* out_dev = nullptr, int mean3 = 0, int raw = 0) {
         const int L = cfg.vae_latent_channels;
-        Act z = new_act(z_in.B, z_in.H, z_in.W, 64);
+        Act z = contract ? new_act_f(z_in.B, z_in.H, z_in.W, 64) : new_act(z_in.B, z_in.H, z_in.W, 64);
         mark("post_quant_conv");
-        launch_pointwise_small(z_in.p, z.p, pq_w_dev, pq_b_dev, z_in.pixels(), L, L, z_in.C, 64, in_scale, st);
+        if (contract) launch_c_pointwise_small(z_in.f, z.f, pq_w_dev, pq_b_dev, z_in.pixels(), L, L, z_in.C, 64, in_scale, st);
+        else launch_pointwise_small(z_in.p, z.p, pq_w_dev, pq_b_dev, z_in.pixels(), L, L, z_in.C, 64, in_scale, st);
         ConvOpt oin;
         oin.want_stats = true;
         Act h = conv(z, convs.at("vae.decoder.conv_in"), oin);
@@ -1258,7 +1487,7 @@ struct gp_engine {
             }
         }
         const PackedW& wout = convs.at("vae.decoder.conv_out");
-        if (out_dev && conv_few_applicable(h.C, wout.cout, h.H, h.W) && wout.cin_pad == h.C) {
+        if (!contract && out_dev && conv_few_applicable(h.C, wout.cout, h.H, h.W) && wout.cin_pad == h.C) {
             float *scale, *shift;
             gn_scale_shift(h, norms.at("vae.decoder.conv_norm_out"), cfg.vae_norm_eps, scale, shift);
             const double fl = 2.0 * (double)h.pixels() * wout.cout * 9.0 * h.C;
@@ -1280,16 +1509,36 @@ struct gp_engine {
         return out;
     }
 
+    // decoder output NHWC (3 real channels) -> the caller's fp32 NCHW map: channel mean, clip / shift unless raw (genpercept_pipeline.py:523-525,469-472)
+    void decode_epilogue(const Act& dec, float* out, int mean3, int raw) {
+        mark("decode_epilogue");
+        if (dec.f) launch_c_decode_epilogue(dec.f, out, dec.B, dec.H, dec.W, dec.C, mean3, raw, st);
+        else launch_decode_epilogue(dec.p, out, dec.B, dec.H, dec.W, dec.C, mean3, raw, st);
+    }
+
+    Act bilinear(const Act& x, int Ho, int Wo, int align_corners) {
+        Act y = contract ? new_act_f(x.B, Ho, Wo, x.C) : new_act(x.B, Ho, Wo, x.C);
+        mark("bilinear " + dims(y));
+        if (contract) launch_c_bilinear(x.f, y.f, x.B, x.H, x.W, Ho, Wo, x.C, align_corners, st);
+        else launch_bilinear(x.p, y.p, x.B, x.H, x.W, Ho, Wo, x.C, align_corners, st);
+        return y;
+    }
     Act rcu(const Act& x, const std::string& p) {  // pre-activation residual unit (dpt_head.py:256-271)
-        Act r = new_act(x.B, x.H, x.W, x.C);
-        mark("relu " + dims(x));
-        launch_relu(x.p, r.p, x.pixels() * x.C, st);
+        Act r;
+        if (contract) {
+            r = split_operand(x, GP_ACT_RELU);
+        } else {
+            r = new_act(x.B, x.H, x.W, x.C);
+            mark("relu " + dims(x));
+            launch_relu(x.p, r.p, x.pixels() * x.C, st);
+        }
         ConvOpt o1;
         o1.act = GP_ACT_RELU;
         Act h = conv(r, convs.at(p + ".convolution1"), o1);
         drop(r);
         ConvOpt o2;
         o2.res = x.p;
+        o2.res_f = x.f;
         Act y = conv(h, convs.at(p + ".convolution2"), o2);
         drop(h);
         return y;
@@ -1314,9 +1563,7 @@ struct gp_engine {
                 Act r = hsrc;
                 bool resized = false;
                 if (r.H != fused.H || r.W != fused.W) {
-                    Act rr = new_act(r.B, fused.H, fused.W, r.C);
-                    mark("bilinear " + dims(rr));
-                    launch_bilinear(r.p, rr.p, r.B, r.H, r.W, fused.H, fused.W, r.C, 0, st);
+                    Act rr = bilinear(r, fused.H, fused.W, 0);
                     drop(r);
                     r = rr;
                     resized = true;
@@ -1324,9 +1571,10 @@ struct gp_engine {
                 (void)resized;
                 Act rc = rcu(r, lp + ".residual_layer1");
                 drop(r);
-                x = new_act(fused.B, fused.H, fused.W, fused.C);
+                x = contract ? new_act_f(fused.B, fused.H, fused.W, fused.C) : new_act(fused.B, fused.H, fused.W, fused.C);
                 mark("add " + dims(fused));
-                launch_add(fused.p, rc.p, x.p, fused.pixels() * fused.C, st);
+                if (contract) launch_c_add(fused.f, rc.f, x.f, fused.pixels() * fused.C, st);
+                else launch_add(fused.p, rc.p, x.p, fused.pixels() * fused.C, st);
                 drop(rc);
                 drop(fused);
             }
@@ -1337,9 +1585,7 @@ struct gp_engine {
             // and the projection on the SOURCE map is a quarter of the GEMM and of its HBM traffic (r5)
             Act pr = linear(x2, convs.at(lp + ".projection"));
             drop(x2);
-            fused = new_act(pr.B, pr.H * 2, pr.W * 2, pr.C);
-            mark("bilinear " + dims(fused));
-            launch_bilinear(pr.p, fused.p, pr.B, pr.H, pr.W, pr.H * 2, pr.W * 2, pr.C, 1, st);
+            fused = bilinear(pr, pr.H * 2, pr.W * 2, 1);
             drop(pr);
         }
         ConvOpt op;
@@ -1348,28 +1594,29 @@ struct gp_engine {
         drop(fused);
         Act y = conv(x, convs.at("dpt.head.head.0"), ConvOpt{});
         drop(x);
-        Act up = new_act(y.B, y.H * 2, y.W * 2, y.C);
-        mark("bilinear " + dims(up));
-        launch_bilinear(y.p, up.p, y.B, y.H, y.W, y.H * 2, y.W * 2, y.C, 1, st);
+        Act up = bilinear(y, y.H * 2, y.W * 2, 1);
         drop(y);
         ConvOpt o32;
         o32.act = GP_ACT_RELU;
         Act z = conv(up, convs.at("dpt.head.head.2"), o32);
         drop(up);
         mark("dpt_final " + dims(z));
-        launch_dpt_final(z.p, dpt_w_dev, dpt_b, out_dev, z.B, z.H * z.W, z.C, st);
+        if (contract) launch_c_dpt_final(z.f, dpt_w_dev, dpt_b, out_dev, z.B, z.H * z.W, z.C, st);
+        else launch_dpt_final(z.p, dpt_w_dev, dpt_b, out_dev, z.B, z.H * z.W, z.C, st);
         drop(z);
     }
 
     Act from_nchw_f32(const float* src, int B, int C, int Hh, int Ww, int Cpad) {
-        Act a = new_act(B, Hh, Ww, Cpad);
+        Act a = contract ? new_act_f(B, Hh, Ww, Cpad) : new_act(B, Hh, Ww, Cpad);
         mark("nchw_f32_to_nhwc");
-        launch_nchw_f32_to_nhwc(src, a.p, B, C, Hh, Ww, Cpad, st);
+        if (contract) launch_c_nchw_to_nhwc(src, a.f, B, C, Hh, Ww, Cpad, st);
+        else launch_nchw_f32_to_nhwc(src, a.p, B, C, Hh, Ww, Cpad, st);
         return a;
     }
     void to_nchw_f32(const Act& a, int C, float* dst) {
         mark("nhwc_to_nchw_f32");
-        launch_nhwc_to_nchw_f32(a.p, dst, a.B, C, a.H, a.W, a.C, st);
+        if (a.f) launch_c_nhwc_to_nchw(a.f, dst, a.B, C, a.H, a.W, a.C, st);
+        else launch_nhwc_to_nchw_f32(a.p, dst, a.B, C, a.H, a.W, a.C, st);
     }
 
     void collect_profile() {
@@ -1464,7 +1711,8 @@ static void attach_splitk_scratch(IGemmParams& p, int tile_hint) {
 
 extern "C" {
 
-const char* gp_version(void) { return GP_F16 ? "genpercept_hip 0.2 (gfx950, fp16 elements)" : "genpercept_hip 0.2 (gfx950, bf16 elements)"; }
+const char* gp_version(void) { return GP_F16 ? "genpercept_hip 0.3 (gfx950, fp16 elements)" : "genpercept_hip 0.3 (gfx950, bf16 elements)"; }
+int gp_abi_version(void) { return GP_ABI_VERSION; }
 gp_dtype gp_element_dtype(void) { return GP_F16 ? GP_DT_F16 : GP_DT_BF16; }
 
 void gp_default_config(gp_config* c) {
@@ -1560,6 +1808,17 @@ gp_status gp_set_timestep(gp_engine* e, float t) {
         if (e->finalized) { HIPCHK(hipSetDevice(e->cfg.device)); HIPCHK(hipDeviceSynchronize()); e->fold_timestep(); }
     });
 }
+
+gp_status gp_set_precision(gp_engine* e, gp_precision prec) {
+    if (!e || (prec != GP_PREC_NATIVE && prec != GP_PREC_CONTRACT)) return GP_ERR_INVALID;
+    return guard(e, [&] {
+        if (e->finalized) throw std::logic_error("gp_set_precision after gp_finalize (the weights are packed per precision)");
+        // the split is written for bf16 pieces (fp32 range: neither piece can saturate or flush); the fp16 library stays a 16-bit engine
+        if (GP_F16 && prec == GP_PREC_CONTRACT) throw std::invalid_argument("contract precision lives in the bf16 library (libgenpercept_hip.so)");
+        e->contract = prec == GP_PREC_CONTRACT;
+    });
+}
+gp_precision gp_get_precision(const gp_engine* e) { return (e && e->contract) ? GP_PREC_CONTRACT : GP_PREC_NATIVE; }
 
 gp_status gp_finalize(gp_engine* e) {
     if (!e) return GP_ERR_INVALID;
@@ -1676,9 +1935,8 @@ gp_status gp_infer(gp_engine* e, const void* rgb_dev, int is_u8, int B, int H, i
             const int mean3 = !(mode == GP_MODE_NORMAL || mode == GP_MODE_SEG);
             Act dec = e->vae_decode(v, -1.0f / e->cfg.vae_scaling_factor, out_dev, mean3, 0);
             e->drop(v);
-            if (dec.p) {  // (the fused tail kernel wrote out_dev itself otherwise)
-                e->mark("decode_epilogue");
-                launch_decode_epilogue(dec.p, out_dev, B, dec.H, dec.W, dec.C, mean3, 0, e->st);
+            if (dec.p || dec.f) {  // (the fused tail kernel wrote out_dev itself otherwise)
+                e->decode_epilogue(dec, out_dev, mean3, 0);
                 e->drop(dec);
             }
         } else {
@@ -1732,8 +1990,9 @@ gp_status gp_infer_steps(gp_engine* e, const void* rgb_dev, int is_u8, int B, in
         const int off = noise_dev ? L : 0;
         float* sample = (float*)e->pool.alloc((size_t)lat.pixels() * L * sizeof(float));
         e->mark("ddim_init");
-        launch_ddim_init(noise_dev, lat.p, sample, B, lat.H, lat.W, L, lat.C, off, e->st);
-        Act x0 = e->new_act(B, lat.H, lat.W, 64);
+        if (e->contract) launch_c_ddim_init(noise_dev, lat.f, sample, B, lat.H, lat.W, L, lat.C, off, e->st);
+        else launch_ddim_init(noise_dev, lat.p, sample, B, lat.H, lat.W, L, lat.C, off, e->st);
+        Act x0 = e->contract ? e->new_act_f(B, lat.H, lat.W, 64) : e->new_act(B, lat.H, lat.W, 64);
         try {
             for (int i = 0; i < n_steps; ++i) {
                 const gp_ddim_step& s = steps[i];
@@ -1741,7 +2000,8 @@ gp_status gp_infer_steps(gp_engine* e, const void* rgb_dev, int is_u8, int B, in
                 Act v = e->unet(lat, nullptr, true);
                 const DdimCoef k{s.x0_sample, s.x0_model, s.eps_sample, s.eps_model, s.prev_x0, s.prev_eps, s.clip};
                 e->mark("ddim_step");
-                launch_ddim_step(v.p, v.C, sample, lat.p, lat.C, off, i == n_steps - 1 ? x0.p : nullptr, x0.C, lat.pixels(), L, k, e->st);
+                if (e->contract) launch_c_ddim_step(v.f, v.C, sample, lat.f, lat.C, off, i == n_steps - 1 ? x0.f : nullptr, x0.C, lat.pixels(), L, k, e->st);
+                else launch_ddim_step(v.p, v.C, sample, lat.p, lat.C, off, i == n_steps - 1 ? x0.p : nullptr, x0.C, lat.pixels(), L, k, e->st);
                 e->drop(v);
             }
         } catch (...) {  // a failed step must not leave the loop's timestep behind as the engine's (gp_set_timestep) one
@@ -1757,9 +2017,8 @@ gp_status gp_infer_steps(gp_engine* e, const void* rgb_dev, int is_u8, int B, in
         const int mean3 = !(mode == GP_MODE_NORMAL || mode == GP_MODE_SEG);
         Act dec = e->vae_decode(x0, 1.0f / e->cfg.vae_scaling_factor, out_dev, mean3, 0);
         e->drop(x0);
-        if (dec.p) {
-            e->mark("decode_epilogue");
-            launch_decode_epilogue(dec.p, out_dev, B, dec.H, dec.W, dec.C, mean3, 0, e->st);
+        if (dec.p || dec.f) {
+            e->decode_epilogue(dec, out_dev, mean3, 0);
             e->drop(dec);
         }
         e->mark("END", 0.0, 0);
@@ -1797,10 +2056,10 @@ gp_status gp_unet(gp_engine* e, const float* latent_in, int B, int h, int w, flo
         Act v = e->unet(lat, feats_out ? feats : nullptr, sample_out != nullptr);
         e->drop(lat);
         if (sample_out) {
-            if (!v.p) throw std::logic_error("this UNet has no conv_out (DPT variant)");
+            if (!v.p && !v.f) throw std::logic_error("this UNet has no conv_out (DPT variant)");
             e->to_nchw_f32(v, e->cfg.unet_out_channels, sample_out);
         }
-        if (v.p) e->drop(v);
+        if (v.p || v.f) e->drop(v);
         if (feats_out)
             for (int i = 0; i < 4; ++i) {
                 if (feats_out[i]) e->to_nchw_f32(feats[i], feats[i].C, feats_out[i]);
@@ -1819,9 +2078,8 @@ gp_status gp_vae_decode(gp_engine* e, const float* pred_latent, int B, int h, in
         // decode_pred (genpercept_pipeline.py:507-526): channel mean for 1-channel modes, no clip / shift
         Act dec = e->vae_decode(z, 1.0f / e->cfg.vae_scaling_factor, out, mean3, 1);
         e->drop(z);
-        if (dec.p) {
-            e->mark("decode_epilogue");
-            launch_decode_epilogue(dec.p, out, B, h * 8, w * 8, dec.C, mean3, 1, e->st);
+        if (dec.p || dec.f) {
+            e->decode_epilogue(dec, out, mean3, 1);
             e->drop(dec);
         }
         e->collect_saturation();

@@ -24,7 +24,8 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
     const int n_out = geglu ? (p.N >> 1) : p.N;
     const float* bias = p.bias ? p.bias + (long long)z * p.bias_bs : nullptr;
     const h16_t* res = p.res ? p.res + (long long)z * p.res_bs : nullptr;
-    const bool staged = !p.out_fp32 && !geglu && (p.ldo & 7) == 0 && !(p.dbg & 64);
+    const bool f32o = p.out_fp32 == 1;  // contract precision: fp32 rows out, fp32 residual in (IGemmParams::res_f32)
+    const bool staged = (!p.out_fp32 || f32o) && !geglu && (p.ldo & 7) == 0 && !(p.dbg & 64);
 
     if (staged) {
         float* stg = (float*)smem;  // [BM][BN] fp32, 32-byte slots XOR-swizzled with the row index
@@ -63,7 +64,12 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
             const float* sp = stg + (long long)pr * BN + ((s ^ (pr & (SL - 1))) << 3);
             const float4 x0 = *(const float4*)sp, x1 = *(const float4*)(sp + 4);
             float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-            if (res) {
+            if (res && p.res_f32) {
+                const float* rp = (const float*)p.res + (long long)z * p.res_bs + (long long)m * p.ldres + col;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (col + e < n_out) v[e] += rp[e];
+            } else if (res) {
                 const h16_t* rp = res + (long long)m * p.ldres + col;
                 if (res_vec && col + 7 < n_out) {
                     const uint4 rv = *(const uint4*)rp;
@@ -80,6 +86,22 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
                 if (p.act == GP_ACT_SILU) v[e] = silu_f(v[e]);
                 else if (p.act == GP_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
                 if (col + e >= n_out) v[e] = 0.f;
+            }
+            if (f32o) {  // the values themselves are what is stored: statistics of v
+                float* o = (float*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
+                if (col + 7 < p.n_store) {
+                    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (col + e < p.n_store) o[e] = v[e];
+                }
+                if (want_stats) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { st_s[e] += v[e]; st_q[e] += v[e] * v[e]; }
+                }
+                continue;
             }
             h16_t* o = outp + (long long)m * p.ldo + col;
             uint4 pk;
@@ -144,6 +166,13 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
                     v[r] = a * gelu_erf_f(g);
                     if (col + r >= n_out) v[r] = 0.f;
                 }
+                if (f32o) {
+                    float* o = (float*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col + r < p.n_store) o[r] = v[r];
+                    continue;
+                }
                 h16_t* o = (h16_t*)p.out + (long long)z * p.out_bs + (long long)m * p.ldo + col;
                 if (col + 3 < p.n_store && (p.ldo & 3) == 0) {
                     *(uint2*)o = pack_h16x4(v[0], v[1], v[2], v[3]);
@@ -159,7 +188,12 @@ GP_DEV void conv_epilogue(const IGemmParams& p, f32x4_t (&acc)[(BN / WN) / 16][(
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = acc[2 * ip + (e >> 2)][j][e & 3] + bcol[ip][e] + rb;
-            if (res) {
+            if (res && p.res_f32) {
+                const float* rp = (const float*)p.res + (long long)z * p.res_bs + (long long)m * p.ldres + col;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (col + e < n_out) v[e] += rp[e];
+            } else if (res) {
                 const h16_t* rp = res + (long long)m * p.ldres + col;
 #pragma unroll
                 for (int e = 0; e < 8; ++e)

@@ -404,7 +404,7 @@ static int select_cfg(const IGemmParams& p, int tile_hint) {
 
 int igemm_tile_info(const IGemmParams& p, int tile_hint, int* mode, int* bm) {
     // the staged epilogue is the only one that accumulates statistics (epilogue.h)
-    if (p.out_fp32 || p.act == GP_ACT_GEGLU || (p.ldo & 7) || p.batch > 1 || p.N != p.n_store) return 0;
+    if (p.out_fp32 > 1 || p.act == GP_ACT_GEGLU || (p.ldo & 7) || p.batch > 1 || p.N != p.n_store) return 0;  // (fp32 rows, out_fp32 == 1, are staged too: contract precision)
     if (igemm_ksplit(p, tile_hint) > 1) return 0;  // partial sums: no epilogue statistics
     if (conv_uses_halo(p, tile_hint)) {
         const int R = conv_halo_stat_rows(p);

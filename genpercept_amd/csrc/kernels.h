@@ -56,6 +56,8 @@ struct IGemmParams {
     // x2-nearest-upsample 3x3 conv as four 2 x 2-tap phase convolutions (conv_halo.hip, PH): weights [n_rows][phase][2 x 2][Cin] with the kernel rows /
     // columns that fall onto the same source pixel summed (engine: pack_phases); nullptr: the nine-tap upsample kernel
     const h16_t* wt_ph;
+    // contract precision (contract.hip): `res` points to an fp32 [M][ldres] tensor (only with out_fp32 == 1)
+    int res_f32;
 };
 
 // A/B and profiling switches (GENPERCEPT_* environment variables).  Read from the environment in ONE place, gp_switches_reload(), which
@@ -202,6 +204,35 @@ void launch_clip01(const float* in, float* out, long long n, hipStream_t s);
 void launch_normalize_rgb(const float* in, float* out, long long n, hipStream_t s);
 void launch_colorize_lut(const float* x, const unsigned char* lut, unsigned char* rgb, long long n, hipStream_t s);
 void launch_quantize(const float* x, void* q, long long n, int bits, hipStream_t s);
+
+// contract.hip: the kernels between the matrix products of the contract-precision mode (fp32 storage, split-bf16 MFMA operands:
+// A order [hi | lo | hi], B order [hi | hi | lo] over a tripled K).  Split tensors have 3 * C elements per row.
+void launch_c_split3(const float* x, int ldx, h16_t* out, long long rows, int C, int b_order, int act, float scale, hipStream_t s);
+void launch_c_rgb_split(const void* rgb, int is_u8, h16_t* out, int B, int H, int W, hipStream_t s);  // -> [B*H*W][192]
+int c_gn_stat_rows(int HW, int C, int* bm_out);  // statistics rows per image of launch_c_gn_stats ("mode 2" partials: B * R * (2 C + 1) floats)
+void launch_c_gn_stats(const float* x, float* part, int B, int HW, int C, hipStream_t s);
+void launch_c_gn_apply_split(const float* x, h16_t* out, const float* scale, const float* shift, int B, int HW, int C, int silu, hipStream_t s);
+void launch_c_layernorm_split(const float* x, h16_t* out, const float* gamma, const float* beta, int rows, int C, float eps, hipStream_t s);
+void launch_c_concat(const float* a, int Ca, const float* b, int Cb, float* out, long long pixels, hipStream_t s);
+void launch_c_heads_split(const float* qkv, int ld, h16_t* Qs, h16_t* Ks, h16_t* Vts, int B, int T, int Tpad, int heads, int hd, hipStream_t s);
+bool c_softmax_split_supported(int ld);
+void launch_c_softmax_split(const float* in, h16_t* out, long long rows, int T, int ld, float scale, hipStream_t s);
+void launch_c_heads_merge_split(const float* O, h16_t* out, int B, int T, int heads, int hd, hipStream_t s);
+bool c_cross_fold_supported(int C);
+void launch_c_cross_fold(const float* y, float* y_out, h16_t* n3_out, const float* U, const float* u0, const float* G, const float* c0, const float* g3,
+                         const float* b3, int rows, int C, int heads, float eps, hipStream_t s);
+void launch_c_cross_attn_small(const float* q, const float* kc, const float* vc, h16_t* out, int rows, int C, int L, hipStream_t s);
+void launch_c_pointwise_small(const float* in, float* out, const float* w, const float* bias, long long pixels, int Cin, int Cout, int ldi, int ldo,
+                              float in_scale, hipStream_t s);
+void launch_c_decode_epilogue(const float* in, float* out, int B, int H, int W, int ld, int mean3, int raw, hipStream_t s);
+void launch_c_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int Cpad, hipStream_t s);
+void launch_c_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, int ld, hipStream_t s);
+void launch_c_add(const float* a, const float* b, float* out, long long n, hipStream_t s);
+void launch_c_bilinear(const float* in, float* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, hipStream_t s);
+void launch_c_dpt_final(const float* in, const float* w, float bias, float* out, int B, int HW, int Cin, hipStream_t s);
+void launch_c_ddim_init(const float* noise_nchw, float* lat, float* sample, int B, int H, int W, int L, int ld, int off, hipStream_t s);
+void launch_c_ddim_step(const float* model, int ldm, float* sample, float* uin, int ldu, int off, float* x0_out, int ldx, long long pixels, int L,
+                        const DdimCoef& k, hipStream_t s);
 
 // microbench.hip: sustained TFLOP/s of back-to-back v_mfma_f32_32x32x16 on this chip (register operands, all CUs), or < 0 on error
 double mfma_peak_tflops(int ms_target, hipStream_t s, int shape = 0);

@@ -17,6 +17,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATHS = {"bf16": os.path.join(_HERE, "lib", "libgenpercept_hip.so"), "fp16": os.path.join(_HERE, "lib", "libgenpercept_hip_f16.so")}
 LIB_PATH = LIB_PATHS["bf16"]
 ELT_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16}
+# Engine precisions: the two element-type libraries in their native arithmetic, and "fp32c" = the CONTRACT precision of the bf16 library
+# (`gp_set_precision(GP_PREC_CONTRACT)`: fp32 storage, split-bf16 MFMA operands, csrc/contract.hip) -- what torch_dtype=float32 selects.
+ENGINE_PRECISIONS = {"bf16": ("bf16", 0), "fp16": ("fp16", 0), "fp32c": ("bf16", 1)}
 _default_precision = "bf16"
 
 
@@ -32,12 +35,15 @@ def act_dtype(precision: Optional[str] = None) -> torch.dtype:
 
 
 def precision_of(dtype) -> str:
-    """torch dtype a caller asks for (from_pretrained(torch_dtype=...), .to(dtype=...)) -> library: bf16 -> bf16, fp16 and fp32 -> fp16
-    (there is no fp32-storage engine; fp16 elements with fp32 accumulation is the closest the matrix cores offer at full rate)."""
+    """torch dtype a caller asks for (from_pretrained(torch_dtype=...), .to(dtype=...)) -> engine precision: bf16 -> "bf16", fp16 -> "fp16"
+    (the reference's --half_precision), fp32 -> "fp32c" (the reference's default, run.py:273-281: fp32 storage + split-bf16 matrix products,
+    inside north_star's 1e-3 under both readings)."""
     if dtype is None or dtype == torch.bfloat16:
         return "bf16"
-    if dtype in (torch.float16, torch.float32):
+    if dtype == torch.float16:
         return "fp16"
+    if dtype == torch.float32:
+        return "fp32c"
     raise ValueError(f"unsupported dtype {dtype}")
 
 GP_OK = 0
@@ -85,6 +91,9 @@ SYMBOLS = {
     "gp_destroy": (None, [_vp]),
     "gp_last_error": (C.c_char_p, [_vp]),
     "gp_version": (C.c_char_p, []),
+    "gp_abi_version": (_i, []),
+    "gp_set_precision": (_i, [_vp, _i]),
+    "gp_get_precision": (_i, [_vp]),
     "gp_element_dtype": (_i, []),
     "gp_load_tensor": (_i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i, _i]),
     "gp_set_context": (_i, [_vp, _vp, _i, _i]),
@@ -169,7 +178,8 @@ class Engine:
     """One engine per GPU (not re-entrant).  Mirrors the reference's module handles: weights in, stages out."""
 
     def __init__(self, device: int = 0, unet_cfg=None, vae_cfg=None, dpt_cfg=None, precision: str = "bf16"):
-        lib = load_library(precision)
+        libname, contract = ENGINE_PRECISIONS[precision]
+        lib = load_library(libname)
         self.precision = precision
         if not torch.cuda.is_available():
             raise RuntimeError("genpercept_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU path")
@@ -206,6 +216,8 @@ class Engine:
         if st != GP_OK:
             msg = lib.gp_last_error(self._h).decode() if self._h else "gp_create failed"
             raise RuntimeError(msg)
+        if contract:
+            self._check(lib.gp_set_precision(self._h, 1))
         self.finalized = False
 
     # -- error handling --------------------------------------------------------------------------------------------

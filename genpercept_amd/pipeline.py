@@ -187,9 +187,9 @@ class GenPerceptPipeline:
             self.text_embed = self.text_embed.reshape(1, -1, self.text_embed.shape[-1])
             self.text_encoder = None
         self._engine = None
-        # element type of the engine: bf16 (default; BASELINE.json's dtype) or fp16 -- the reference's --half_precision, also used when
-        # fp32 is asked for (run.py's default torch_dtype): there is no fp32-storage engine, fp16 elements + fp32 accumulation is the
-        # most precise build (final maps within 1e-3 of the fp32 path)
+        # precision of the engine: bf16 (default; BASELINE.json's dtype), fp16 (the reference's --half_precision) or -- for torch_dtype=float32,
+        # run.py's default -- the contract precision "fp32c": fp32 storage + split-bf16 matrix products, final maps within 1e-3 of the fp32
+        # path under both readings
         from .engine import precision_of
         self._precision = precision_of(torch_dtype)
         # dtype single_infer draws marigold's initial noise in (genpercept_pipeline.py:416-420: torch.randn(..., dtype=self.dtype)): the dtype the
@@ -265,6 +265,8 @@ class GenPerceptPipeline:
     @property
     def dtype(self) -> torch.dtype:
         from .engine import ELT_DTYPE
+        if self._precision == "fp32c":  # contract precision: activations are stored in fp32 (the matrix products run on split bf16 operands)
+            return torch.float32
         return ELT_DTYPE[self._precision]  # storage / MFMA-operand dtype of the engine; accumulation is fp32
 
     def enable_xformers_memory_efficient_attention(self):  # run.py:382-385 — attention is always flash-style here
@@ -438,7 +440,8 @@ class GenPerceptPipeline:
         self.last_saturation_events = n
         if n:
             logging.warning("GenPerceptPipeline: %d kernel group(s) of the last call clipped activations at the fp16 range (+-65504): the result "
-                            "deviates from the fp32 path.  Use torch_dtype=torch.bfloat16 (fp32 range) for this checkpoint / input.", n)
+                            "deviates from the fp32 path.  Use torch_dtype=torch.float32 (contract precision, fp32 range) or torch.bfloat16 for "
+                            "this checkpoint / input.", n)
 
     def _predict(self, x: torch.Tensor, fix_timesteps, prompt, opts: Optional[dict]) -> torch.Tensor:
         """The batched prediction + test-time ensembling of __call__ (genpercept_pipeline.py:250-297), per image of `x`."""

@@ -83,10 +83,26 @@ gp_status gp_create(const gp_config* cfg, gp_engine** out);
 void gp_destroy(gp_engine* e);
 const char* gp_last_error(const gp_engine* e);
 const char* gp_version(void);
+/* Bumped whenever a struct layout or an existing signature changes (additions do not bump it).  3: gp_timings lost its trailing `sat_events`
+ * field in round 5 (gp_saturation_events replaced it) -- a client built against the older header must be rebuilt; it can check this at load time. */
+#define GP_ABI_VERSION 3
+int gp_abi_version(void);
 /* Storage / MFMA-operand element of THIS library: GP_DT_BF16 (libgenpercept_hip.so) or GP_DT_F16 (libgenpercept_hip_f16.so, the
  * reference's half precision: run.py --half_precision / torch_dtype=torch.float16).  Per-kernel entry points take and return
  * tensors of this element type; stage-level entry points are fp32 at the boundary in both libraries. */
 gp_dtype gp_element_dtype(void);
+
+/* Arithmetic of the engine (call before gp_finalize; the weights are packed per precision):
+ *   GP_PREC_NATIVE    16-bit storage and MFMA operands in this library's element type (the default; BASELINE.json's bf16 when this is
+ *                     libgenpercept_hip.so, the reference's --half_precision when it is libgenpercept_hip_f16.so).
+ *   GP_PREC_CONTRACT  what torch_dtype=float32 -- the reference's default, run.py:273-281 -- asks for: every STORED activation is fp32 and
+ *                     every matrix product runs on the bf16 matrix cores with split operands (x = hi + lo, three MFMAs per product: hi.hi +
+ *                     lo.hi + hi.lo, fp32 accumulation; csrc/contract.hip).  About 2^-16 relative per product: final maps within 1e-3 of the
+ *                     fp32 path under both the mean-absolute and the relative-RMS reading, at roughly a quarter of the native throughput.
+ *                     bf16 library only (GP_ERR_INVALID in the fp16 library). */
+typedef enum { GP_PREC_NATIVE = 0, GP_PREC_CONTRACT = 1 } gp_precision;
+gp_status gp_set_precision(gp_engine* e, gp_precision prec);
+gp_precision gp_get_precision(const gp_engine* e);
 
 /* One call per state-dict entry.  `name` = "<module>.<diffusers key>" with module in {vae, unet, dpt}.  The engine copies
  * (and converts to fp32); the caller keeps ownership of host_ptr. */

@@ -27,7 +27,11 @@ pytestmark = pytest.mark.gpu
 # per element type of the engine (bf16 = libgenpercept_hip.so, fp16 = libgenpercept_hip_f16.so): 2x the largest deviation measured on
 # MI355X for each quantity (gpurun_out/parity_log.jsonl), not more
 TOLS = {"bf16": dict(stage=3.6e-2, map_mean=9e-3, absrel=3e-2),
-        "fp16": dict(stage=4.5e-3, map_mean=1e-3, absrel=4e-3)}
+        "fp16": dict(stage=4.5e-3, map_mean=1e-3, absrel=4e-3),
+        # contract precision (gp_set_precision(GP_PREC_CONTRACT), csrc/contract.hip): fp32 storage + split-bf16 matrix products
+        "fp32c": dict(stage=3e-4, map_mean=5e-5, absrel=3e-4)}
+TORCH_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32c": torch.float32}
+PRECISIONS = ["bf16", "fp16", "fp32c"]
 TOL_STAGE, TOL_MAP_MEAN, TOL_ABSREL = TOLS["bf16"]["stage"], TOLS["bf16"]["map_mean"], TOLS["bf16"]["absrel"]
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -84,14 +88,14 @@ def _engine(tw, dpt, ctx, precision="bf16"):
     return eng
 
 
-@pytest.fixture(scope="module", params=["bf16", "fp16"])
+@pytest.fixture(scope="module", params=PRECISIONS)
 def eng_vae(request, tiny_weights, golden):
     e = _engine(tiny_weights, False, golden["sq_ctx"], request.param)
     yield e
     e.close()
 
 
-@pytest.fixture(scope="module", params=["bf16", "fp16"])
+@pytest.fixture(scope="module", params=PRECISIONS)
 def eng_dpt(request, tiny_weights, golden):
     e = _engine(tiny_weights, True, golden["sq_ctx"], request.param)
     yield e
@@ -113,7 +117,7 @@ def test_stages_vs_golden(tag, eng_vae, golden, metric_log):
     v, feats = eng_vae.unet(gl, want_sample=True, want_feats=True)
     stage_check(f"unet[{tag_p}]", v, golden[f"{tag}_unet"], metric_log, tol)
     for i, f in enumerate(feats):  # (the golden features are stored as fp16: their own rounding, 5e-4, is inside the fp16 tolerance)
-        stage_check(f"unet_feat{i}[{tag_p}]", f, golden[f"{tag}_feat{i}"].astype(np.float32), metric_log, tol)
+        stage_check(f"unet_feat{i}[{tag_p}]", f, golden[f"{tag}_feat{i}"].astype(np.float32), metric_log, max(tol, 6e-4))
     gv = torch.as_tensor(golden[f"{tag}_unet"]).to(d)
     dec = eng_vae.vae_decode(-gv, mean3=False)
     stage_check(f"vae_decode3[{tag_p}]", dec, golden[f"{tag}_dec3"], metric_log, tol)
@@ -155,7 +159,7 @@ def test_infer_dpt_vs_golden(tag, eng_dpt, golden, metric_log):
     assert mean_abs <= 2 * TOLS[eng_dpt.precision]["map_mean"]  # the min-max division rescales the head's rounding noise by 1 / (max - min)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("precision", PRECISIONS)
 def test_dpt_head_vs_reference_outputs(precision, metric_log):
     """Full-size DPT head against outputs of the reference's own dpt_head.py (generated in the build container)."""
     from genpercept_amd.engine import Engine
@@ -180,7 +184,7 @@ def test_dpt_head_vs_reference_outputs(precision, metric_log):
         eng.close()
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("precision", PRECISIONS)
 def test_dpt_head_vs_reference_outputs_odd_shapes(precision, metric_log):
     """The HIP DPT head on odd feature shapes (latents 9x11, 13x10, 29x39) against the REFERENCE's own outputs: covers the
     bilinear resize of a neck feature to the fused map's size (dpt_head.py:297-300) end to end."""
@@ -239,7 +243,7 @@ def test_batch_equals_single(eng_vae, golden, metric_log):
     assert diff <= 1e-6
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("hw", [(64, 64), (232, 312)])
 def test_full_sd21_architecture_small_image(hw, precision, metric_log):
     """Full-width SD2.1 UNet (865.9 M params) + VAE against the fp32 oracle run on the host CPU: 64x64 px (every map below the
@@ -594,7 +598,7 @@ def test_failed_call_returns_buffers(tiny_weights, golden):
         e.close()
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("precision", PRECISIONS)
 def test_infer_eval_loop_with_the_engine(precision, tiny_weights, tmp_path, metric_log):
     """infer.py -> eval.py end to end with the REAL pipeline (r1 only ran it with a stand-in): an NYU-layout tree of RGB
     images goes through genpercept_amd.infer_eval.run_inference (GenPerceptPipeline on the GPU, .npy per image named by get_pred_name),
@@ -611,7 +615,7 @@ def test_infer_eval_loop_with_the_engine(precision, tiny_weights, tmp_path, metr
     ctx = torch.randn(2, tw["uc"].cross_attention_dim, generator=g)
     pipe = GenPerceptPipeline(unet=tw["usd"], vae=tw["vsd"], scheduler=dict(beta_start=1.0, beta_end=1.0, prediction_type="v_prediction", clip_sample=False,
                                                                                        steps_offset=1, timestep_spacing="leading"),
-                              text_encoder=ctx, tokenizer=None, torch_dtype=torch.float16 if precision == "fp16" else torch.bfloat16)
+                              text_encoder=ctx, tokenizer=None, torch_dtype=TORCH_DTYPE[precision])
     pipe.to("cuda")
     base, outd = tmp_path / "data", tmp_path / "pred"
     samples, normals_ref = [], []
@@ -671,7 +675,7 @@ def test_modes_seg_matting_dis_on_the_gpu(eng_vae, tiny_weights, golden, metric_
         assert o.shape[1] == 1 and torch.equal(o, dep), m
     from genpercept_amd import GenPerceptPipeline
     pipe = GenPerceptPipeline(unet=tiny_weights["usd"], vae=tiny_weights["vsd"], text_encoder=golden["sq_ctx"], tokenizer=None,
-                              torch_dtype=torch.float16 if eng_vae.precision == "fp16" else torch.bfloat16)
+                              torch_dtype=TORCH_DTYPE[eng_vae.precision])
     try:
         img = torch.as_tensor(golden["sq_rgb_u8"])[:1]
         outs = {m: pipe(img, processing_res=0, mode=m, color_map=None) for m in ("depth", "normal", "seg", "matting", "dis")}
