@@ -209,12 +209,14 @@ def main(argv=None, engine_factory=None, device=None):
     ap.add_argument("--head", default="vae", choices=["vae", "dpt"], help="BASELINE.json configs[1]/[2] = vae (depth/normal), configs[3] = dpt")
     ap.add_argument("--cpu-res", type=int, default=768, help="edge of the single image timed on the CPU oracle (the benched size)")
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads for the baseline leg (256 oversubscribes badly)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"],
-                    help="element type of the engine (bf16 = BASELINE.json's dtype; fp16 = the 1e-3-parity build, same MFMA rate)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32c"],
+                    help="precision of the benched engine (bf16 = BASELINE.json's dtype; fp16 = the reference's --half_precision; fp32c = the contract "
+                         "precision: fp32 storage + split-bf16 matrix products, what torch_dtype=float32 selects)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the result maps on their GPUs")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-fp16", action="store_true", help="skip the second timed leg with the fp16 library")
+    ap.add_argument("--no-fp32c", action="store_true", help="skip the third timed leg with the contract precision (fp32 storage, split-bf16 products)")
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -265,6 +267,7 @@ def main(argv=None, engine_factory=None, device=None):
 
     eng = build_engine(args.precision)
     t_load = time.time() - t0
+    lib_prec = ge.ENGINE_PRECISIONS[args.precision][0]  # the element-type library behind the benched precision (fp32c lives in the bf16 library)
 
     n_total = args.batch * n_gpus
     lo, hi = gd.shard_range(n_total, rank, n_gpus)
@@ -312,15 +315,15 @@ def main(argv=None, engine_factory=None, device=None):
         tm = eng.timings()
         halo_exec = eng.halo_executed_flops() if hasattr(eng, "halo_executed_flops") else tm["flops_halo"]
         eng.set_profile(0)
-        peak_meas = ge.mfma_peak_tflops(local_rank, args.precision) if rank == 0 else None
-        peak_meas16 = ge.mfma_peak_tflops_shape(local_rank, 1, args.precision) if rank == 0 else None  # the dominant kernel's own MFMA shape
+        peak_meas = ge.mfma_peak_tflops(local_rank, lib_prec) if rank == 0 else None
+        peak_meas16 = ge.mfma_peak_tflops_shape(local_rank, 1, lib_prec) if rank == 0 else None  # the dominant kernel's own MFMA shape
         # the dominant kernel's inner loop in isolation (gp_mfma_lds_probe, ~10 ms each): 16 MFMAs + 8 fragment reads per wave at two waves per SIMD,
         # alone / with the per-step barrier, the weight stream and the halo stream of the real kernel (constant operand bits: an upper bound)
         loop_probe = None
         if rank == 0:
             try:
-                loop_probe = {"mfma_and_fragment_reads": round(ge.mfma_lds_probe(local_rank, 8, 2, 0, args.precision), 1),
-                              "plus_barrier_weight_and_halo_streams": round(ge.mfma_lds_probe(local_rank, 8, 2, 19, args.precision), 1)}
+                loop_probe = {"mfma_and_fragment_reads": round(ge.mfma_lds_probe(local_rank, 8, 2, 0, lib_prec), 1),
+                              "plus_barrier_weight_and_halo_streams": round(ge.mfma_lds_probe(local_rank, 8, 2, 19, lib_prec), 1)}
             except Exception:
                 loop_probe = None
         scale = (args.res / 768.0) ** 2 * ((TFLOP_PER_IMAGE_768_DPT / TFLOP_PER_IMAGE_768) if dpt else 1.0)
@@ -398,6 +401,30 @@ def main(argv=None, engine_factory=None, device=None):
             eng.set_profile(0)
             fp16["stages_fp16"] = {"ms_encode": round(t16["ms_encode"], 3), "ms_unet": round(t16["ms_unet"], 3), "ms_head": round(t16["ms_head"], 3)}
 
+    # ---- third timed leg: the CONTRACT precision (gp_set_precision(GP_PREC_CONTRACT): fp32 storage, split-bf16 matrix products -- three MFMAs
+    # per product), the build torch_dtype=float32 selects and the one inside north_star's 1e-3 under BOTH readings; same steps / barriers -------
+    fp32c = None
+    out0_c = None
+    if args.precision == "bf16" and not args.no_fp32c and n_gpus == 1:
+        eng.close()
+        eng = build_engine("fp32c")
+        elc, oc = timed(eng)
+        if oc is not None and rank == 0:
+            out0_c = oc[0].float().cpu()
+        fp32c = {"value_fp32c": round(images / elc, 3), "ms_per_step_fp32c": round(elc / args.steps * 1e3, 3),
+                 "ms_per_step_fp32c_min": timed.stats.get("ms_per_step_min"), "ms_per_step_fp32c_median": timed.stats.get("ms_per_step_median")}
+        if not args.no_profile:
+            eng.set_profile(1)
+            eng.reset_timings()
+            eng.infer(rgb, args.mode)
+            tc = eng.timings()
+            eng.set_profile(0)
+            fp32c["stages_fp32c"] = {"ms_encode": round(tc["ms_encode"], 3), "ms_unet": round(tc["ms_unet"], 3), "ms_head": round(tc["ms_head"], 3)}
+            # useful (algorithmic) flops per second of the whole pass; the matrix cores execute three times that in this precision
+            sc = (args.res / 768.0) ** 2 * ((TFLOP_PER_IMAGE_768_DPT / TFLOP_PER_IMAGE_768) if dpt else 1.0)
+            fp32c["pipeline_achieved_fp32c"] = round(TFLOP_PER_IMAGE_768 * sc * args.batch / (elc / args.steps), 2)
+            fp32c["pipeline_executed_frac_fp32c"] = round(3.0 * TFLOP_PER_IMAGE_768 * sc * args.batch / (elc / args.steps) / PEAK_BF16_TFLOPS, 4)
+
     cpu = None
     parity = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu and not dpt:
@@ -418,12 +445,14 @@ def main(argv=None, engine_factory=None, device=None):
                                    "on the [0,1] map; rel_rms = rms(HIP - oracle) / rms(oracle - mean(oracle)).  within_1e-3.{mean_abs,rel_rms} per library."}
             if out0_f16 is not None:
                 parity["fp16"] = parity_vs(ref[0], out0_f16)
+            if out0_c is not None:
+                parity["fp32c"] = parity_vs(ref[0], out0_c)
             w = parity[args.precision]["within_1e-3"]
             if not (w["mean_abs"] and w["rel_rms"]):
                 parity["note"] = (f"the benched {args.precision} value is outside 1e-3 under " + " and ".join(k for k, v in w.items() if not v) +
-                                  " (bf16 MFMA operands floor the map at ~2.3e-3 mean_abs; DESIGN.md section 4); value_fp16 is the number of the fp16 "
-                                  "library, which is inside 1e-3 under mean_abs; no engine with 16-bit MFMA operands reaches 1e-3 under rel_rms "
-                                  "(profiles/r04_precision_ablation.json: operands-only-fp16)")
+                                  " (bf16 MFMA operands floor the map at ~2.3e-3 mean_abs; DESIGN.md section 4); value_fp32c is the number of the contract "
+                                  "precision (fp32 storage + split-bf16 products), inside 1e-3 under both readings; value_fp16 is the fp16 library's, "
+                                  "inside 1e-3 under mean_abs only")
         cpu = {"value": round(1.0 / dt, 5), "unit": f"images/sec at {r}x{r} fp32", "cores": nthr, "cpu_model": cpu_model(), "kind": "port",
                "sample": f"1 image {r}x{r} ({TFLOP_PER_IMAGE_768 * (r / 768.0) ** 2:.3f} TFLOP), torch-CPU fp32 restatement of the diffusers path "
                          f"(oracle/), timed directly at this size: {dt:.1f} s",
@@ -456,6 +485,11 @@ def main(argv=None, engine_factory=None, device=None):
             line["value_fp16_within_tolerance"] = parity["fp16"]["within_1e-3"]
         if fp16:
             line.update(fp16)
+        if fp32c:
+            line.update(fp32c)
+            if parity and "fp32c" in parity:
+                line["value_fp32c_within_tolerance"] = parity["fp32c"]["within_1e-3"]
+                line["within_1e-3"] = {k: v["within_1e-3"] for k, v in parity.items() if isinstance(v, dict) and "within_1e-3" in v}
         print(json.dumps(line), flush=True)
     eng.close()
     if world > 1:

@@ -246,6 +246,192 @@ void launch_flash_attn64(const h16_t* q, const h16_t* k, const h16_t* vt, h16_t*
     else hipLaunchKernelGGL((flash_attn64_kernel<2, 3>), grid, dim3(256), 3 * 16384, s, q, k, vt, out, T, heads, ldq, ldk, Tpad, ldo);
 }
 
+// ---- flash_attn64 with SPLIT operands (contract precision, contract.hip): q = q_hi + q_lo, k, v, p likewise (bf16 pieces of fp32 values);
+//   S^T = K_hi Q_hi^T + K_hi Q_lo^T + K_lo Q_hi^T,   O^T += V_hi^T P_hi^T + V_hi^T P_lo^T + V_lo^T P_hi^T   (fp32 accumulators, fp32 softmax).
+// Same dataflow as flash_attn64_kernel (lane-local online softmax on S^T, probabilities already in B-operand order); every K / V^T fragment
+// read from LDS feeds one (lo) or two (hi) MFMAs, so the three-fold matrix work costs 1.5x the LDS traffic.  Per stage: K_hi | K_lo | V_hi^T |
+// V_lo^T tiles of 8 KiB each; two stages = 64 KiB per workgroup.  Inputs: planes QKhi / QKlo [B*T][ld] (q | k row-major, head h at columns
+// h * 64 and C + h * 64), Vthi / Vtlo [B * heads][64][Tpad] (zero beyond T).  Output: the attention result as the A-order split operand
+// [B*T][3 C] ([hi | lo | hi]) the output projection reads.
+__global__ __launch_bounds__(256, 2) void flash_attn64_split_kernel(const h16_t* __restrict__ QKhi, const h16_t* __restrict__ QKlo,
+                                                                  const h16_t* __restrict__ Vthi, const h16_t* __restrict__ Vtlo,
+                                                                  h16_t* __restrict__ O, int T, int heads, int ld, int Tpad) {
+    constexpr int KEYS = 64, KBYTES = 8192, STAGE = 4 * KBYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nqb = (T + 127) >> 7;
+    const int sid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = sid % nqb, bh = sid / nqb;
+    const int h = bh % heads, b = bh / heads;
+    const int C = heads * 64;
+    const int q0 = qb * 128 + wave * 32;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    const long long qoff = (long long)b * T * ld + h * 64;
+    const long long voff = ((long long)b * heads + h) * 64 * Tpad;
+    h16x8_t qh[4], ql[4];
+    {
+        const int q = q0 + l31;
+        const bool ok = q < T;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ok) {
+                qh[ks] = *(const h16x8_t*)(QKhi + qoff + (long long)q * ld + ks * 16 + hh * 8);
+                ql[ks] = *(const h16x8_t*)(QKlo + qoff + (long long)q * ld + ks * 16 + hh * 8);
+            } else {
+                qh[ks] = ql[ks] = h16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+    }
+    const int chunk = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
+    const int nt = (T + KEYS - 1) / KEYS;
+    const unsigned kbytes = (unsigned)(((long long)T - 1) * ld * 2 + 128);
+    const buf_rsrc_t kh_rs = make_rsrc(QKhi + qoff + C, kbytes), kl_rs = make_rsrc(QKlo + qoff + C, kbytes);
+    const buf_rsrc_t vh_rs = make_rsrc(Vthi + voff, (unsigned)(64ll * Tpad * 2)), vl_rs = make_rsrc(Vtlo + voff, (unsigned)(64ll * Tpad * 2));
+    const unsigned k_lane = (unsigned)(((lane >> 3) & 3) + 8 * (lane >> 5)) * (unsigned)(ld * 2) + chunk * 16;  // (K rows staged with bits 2 and 3 swapped)
+    const unsigned v_lane = ((unsigned)(lane >> 3) * Tpad + chunk * 8) * 2;
+    auto stage = [&](int buf, int kt) {
+        char* sb = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int g = wave + 4 * i;
+            const unsigned ko = (unsigned)(kt * KEYS + (g >> 1) * 16 + 4 * (g & 1)) * (unsigned)(ld * 2);
+            blds16(kh_rs, k_lane, ko, sb + g * 1024);
+            blds16(kl_rs, k_lane, ko, sb + KBYTES + g * 1024);
+            const int k0 = kt * KEYS;
+            const unsigned so = k0 < Tpad ? (unsigned)((wave + 4 * i) * 8 * Tpad + k0) * 2u : 0xfffff000u;
+            blds16(vh_rs, v_lane, so, sb + 2 * KBYTES + g * 1024);
+            blds16(vl_rs, v_lane, so, sb + 3 * KBYTES + g * 1024);
+        }
+    };
+    f32x16_t o_acc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const float sc = 0.125f * 1.44269504088896340736f;
+    f32x16_t zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    int cur = 0;
+    const unsigned smem_base = (unsigned)(unsigned long long)smem;
+
+    auto tile = [&](int kt, auto maskc) __attribute__((always_inline)) {
+        constexpr bool MASK = decltype(maskc)::value != 0;
+        const unsigned sb = smem_base + cur * STAGE;
+        f32x16_t s_acc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int row = kb * 32 + l31;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const h16x8_t kfh = lds_frag(sb + attn_off128(row, ks * 2 + hh), 0);
+                const h16x8_t kfl = lds_frag(sb + KBYTES + attn_off128(row, ks * 2 + hh), 0);
+                s_acc[kb] = mfma_32x32x16(kfl, qh[ks], ks == 0 ? zero16 : s_acc[kb]);  // small terms first
+                s_acc[kb] = mfma_32x32x16(kfh, ql[ks], s_acc[kb]);
+                s_acc[kb] = mfma_32x32x16(kfh, qh[ks], s_acc[kb]);
+            }
+        }
+        if (MASK) {
+            const int kbase = kt * KEYS + 8 * hh;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + kb * 32 + (r & 7) + 16 * (r >> 3) >= T) s_acc[kb][r] = -1e30f;
+        }
+        float mx = s_acc[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kb][r]);
+        mx = xor32_max(mx);
+        if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0ull) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+        }
+        const float nm = -m_run * sc;
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float t = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][r], sc, nm));
+                s_acc[kb][r] = t;
+                rs += t;
+            }
+        l_run += rs;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                union { h16x8_t v; unsigned u[4]; } ph, pl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = s_acc[kb][8 * j + 2 * e], c = s_acc[kb][8 * j + 2 * e + 1];
+                    ph.u[e] = pack_h16x2_ns(a, c);
+                    pl.u[e] = pack_h16x2_ns(a - h16_lo(ph.u[e]), c - h16_hi(ph.u[e]));
+                }
+                const int slot = kb * 4 + 2 * j + hh;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const h16x8_t vfh = lds_frag(sb + 2 * KBYTES + attn_off128(d * 32 + l31, slot), 0);
+                    const h16x8_t vfl = lds_frag(sb + 3 * KBYTES + attn_off128(d * 32 + l31, slot), 0);
+                    o_acc[d] = mfma_32x32x16(vfl, ph.v, o_acc[d]);
+                    o_acc[d] = mfma_32x32x16(vfh, pl.v, o_acc[d]);
+                    o_acc[d] = mfma_32x32x16(vfh, ph.v, o_acc[d]);
+                }
+            }
+    };
+    stage(0, 0);
+    auto step = [&](int kt, auto maskc) __attribute__((always_inline)) {
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
+        tile(kt, maskc);
+        cur ^= 1;
+    };
+    const bool ragged = nt * KEYS > T;
+    const int nfull = ragged ? nt - 1 : nt;
+    for (int kt = 0; kt < nfull; ++kt) step(kt, IC<0>{});
+    if (ragged) step(nt - 1, IC<1>{});
+    l_run += __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_run;
+    const int q = q0 + l31;
+    if (q < T) {  // this lane: query q, channels d = 32 blk + 8 g + 4 hh + 0..3; written as [hi | lo | hi] blocks of C
+        h16_t* ob = O + ((long long)b * T + q) * 3 * C + h * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float v0 = o_acc[d][4 * g] * inv, v1 = o_acc[d][4 * g + 1] * inv, v2 = o_acc[d][4 * g + 2] * inv, v3 = o_acc[d][4 * g + 3] * inv;
+                const unsigned h0 = pack_h16x2(v0, v1), h1 = pack_h16x2(v2, v3);
+                const unsigned l0 = pack_h16x2(v0 - h16_lo(h0), v1 - h16_hi(h0)), l1 = pack_h16x2(v2 - h16_lo(h1), v3 - h16_hi(h1));
+                const int c = d * 32 + 8 * g + 4 * hh;
+                *(uint2*)(ob + c) = make_uint2(h0, h1);
+                *(uint2*)(ob + C + c) = make_uint2(l0, l1);
+                *(uint2*)(ob + 2 * C + c) = make_uint2(h0, h1);
+            }
+    }
+}
+void launch_flash_attn64_split(const h16_t* qk_hi, const h16_t* qk_lo, const h16_t* vt_hi, const h16_t* vt_lo, h16_t* out, int B, int T, int heads, int ld,
+                               int Tpad, hipStream_t s) {
+    static unsigned long long attr_mask = 0;
+    gp_once_per_device(&attr_mask, [&] {
+        (void)hipFuncSetAttribute((const void*)flash_attn64_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768);
+    });
+    dim3 grid(((T + 127) / 128) * heads * B);
+    hipLaunchKernelGGL(flash_attn64_split_kernel, grid, dim3(256), 2 * 32768, s, qk_hi, qk_lo, vt_hi, vt_lo, out, T, heads, ld, Tpad);
+}
+
 // ---- flash_attn512: the VAE mid-block attention (one head, head_dim 512; genpercept_pipeline.py:500-501,521-522) ----------------------
 // Same dataflow as flash_attn64 (S^T = K Q^T on v_mfma_f32_32x32x16, lane-local online softmax, the probabilities already in
 // B-operand order for O^T += V^T P^T), sized for d = 512:

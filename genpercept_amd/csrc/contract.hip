@@ -271,6 +271,52 @@ void launch_c_heads_split(const float* qkv, int ld, h16_t* Qs, h16_t* Ks, h16_t*
     hipLaunchKernelGGL(c_heads_split_vt_kernel, dim3(Tpad / 64, hd / 64, B * heads), dim3(256), 0, s, qkv, ld, Vts, T, Tpad, heads, hd);
 }
 
+// The same head split for flash_attn64_split_kernel (attention.hip): PLANES instead of interleaved blocks -- QKhi / QKlo [B*T][2C] (q | k row-major),
+// Vthi / Vtlo [B * heads][hd][Tpad] (V transposed, zero beyond T).
+__global__ __launch_bounds__(256) void c_qk_planes_kernel(const float* __restrict__ qkv, int ld, h16_t* __restrict__ hi, h16_t* __restrict__ lo, long long rows,
+                                                           int C2) {
+    const int nv = C2 >> 3;
+    const long long n = rows * nv;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long r = i / nv;
+        const int c = (int)(i - r * nv) * 8;
+        float a[8];
+        load8(qkv + r * ld + c, a);
+        uint4 h4, l4;
+        split8(a, h4, l4);
+        *(uint4*)(hi + r * C2 + c) = h4;
+        *(uint4*)(lo + r * C2 + c) = l4;
+    }
+}
+__global__ __launch_bounds__(256) void c_vt_planes_kernel(const float* __restrict__ qkv, int ld, h16_t* __restrict__ hi, h16_t* __restrict__ lo, int T, int Tpad,
+                                                           int heads, int hd) {
+    __shared__ float tile[64][65];
+    const int t0 = blockIdx.x * 64, d0 = blockIdx.y * 64, z = blockIdx.z, b = z / heads, h = z - b * heads;
+    const int C = heads * hd;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int tt = i >> 6, d = i & 63;
+        tile[tt][d] = (t0 + tt < T) ? qkv[((long long)b * T + t0 + tt) * ld + 2 * C + h * hd + d0 + d] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+        const int d = i >> 3, g = i & 7;
+        float a[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = tile[g * 8 + e][d];
+        uint4 h4, l4;
+        split8(a, h4, l4);
+        const long long o = ((long long)z * hd + d0 + d) * Tpad + t0 + g * 8;
+        *(uint4*)(hi + o) = h4;
+        *(uint4*)(lo + o) = l4;
+    }
+}
+void launch_c_qkv_planes(const float* qkv, int ld, h16_t* qk_hi, h16_t* qk_lo, h16_t* vt_hi, h16_t* vt_lo, int B, int T, int Tpad, int heads, int hd,
+                         hipStream_t s) {
+    const int C = heads * hd;
+    hipLaunchKernelGGL(c_qk_planes_kernel, dim3(cgrid((long long)B * T * (2 * C / 8))), dim3(256), 0, s, qkv, ld, qk_hi, qk_lo, (long long)B * T, 2 * C);
+    hipLaunchKernelGGL(c_vt_planes_kernel, dim3(Tpad / 64, hd / 64, B * heads), dim3(256), 0, s, qkv, ld, vt_hi, vt_lo, T, Tpad, heads, hd);
+}
+
 // row softmax of fp32 logits [rows][ld] (first T valid) -> split A-order probabilities [rows][3 ld], zero beyond T.  One workgroup per row,
 // the row kept in registers (ld <= 256 * 4 * CS_MAXV).
 constexpr int CS_MAXV = 16;

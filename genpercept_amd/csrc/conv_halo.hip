@@ -26,6 +26,9 @@ GP_DEV void halo_wait_vm() { wait_vm<N>(); }
 
 constexpr int GN_MAXC = 2560;      // fused input transform: per-channel scale/shift of one image live in 20 KiB of LDS (widest UNet up-block input)
 constexpr int HALO_NB = 3;         // weight ring depth
+// ABL bit of conv3x3_halo3_kernel that is NOT an ablation: fp32 rows out and an fp32 residual in (IGemmParams::out_fp32 == 1 / res_f32), the
+// epilogue of the contract precision (contract.hip: split-bf16 operands over a tripled K; the K loop is the ordinary one)
+constexpr int HALO_F32O = 1 << 20;
 
 // TR: output-pixel rows per wave row group (4 row groups per workgroup): 4 = the 16 x 16 tile; 3 = a 12-row x 16-column tile (r5, plain stride-1
 // convs only: conv3x3_halo3_kernel<false, 0, 0, 3>, chosen where 16-row tiles quantise badly over the persistent grid, see halo_plan)
@@ -363,7 +366,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
     using G = HaloGeom<UPS, TR>;
     using G3 = Halo3Geom<UPS, TR, PH>;
     static_assert(TR == 4 || (TR == 3 && !UPS && FUSED == 0), "12-row tiles: plain stride-1 convs only");
-    static_assert(!PH || (!UPS && FUSED == 0 && TR == 4 && ABL == 0), "phase mode: its own geometry");
+    static_assert(!PH || (!UPS && FUSED == 0 && TR == 4 && (ABL & ~HALO_F32O) == 0), "phase mode: its own geometry");
+    constexpr bool F32O = (ABL & HALO_F32O) != 0;
+    static_assert(!F32O || FUSED == 0, "fp32 rows out: plain input only");
     constexpr int NT = PH ? 4 : 9;        // taps (K-steps) per 64-channel chunk
     constexpr int NBR = G3::NBR;          // weight ring depth
     constexpr int BN = 128, NW = 8, TN = 64, FM = TR, FN = 4, FP = 2;
@@ -700,8 +705,22 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
 #pragma unroll
         for (int w = 0; w < 4; ++w) tmask[w] = (col + 2 * w < n_out ? 0xffffu : 0u) | (col + 2 * w + 1 < n_out ? 0xffff0000u : 0u);
         h16_t* outp = (h16_t*)p.out;
+        float* const outf = (float*)p.out;             // F32O
+        const float* const resf = (const float*)p.res;  // F32O: the residual is an fp32 tensor
         int m2[FM][2];
         uint4 rv[FM][2];
+        f32x4_t rf[2][2];  // F32O: fp32 residual of the NEXT tile row only (prefetched one row ahead: all FM rows would be 64 VGPRs)
+        auto res_f32_load = [&](int j) __attribute__((always_inline)) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                rf[h][0] = rf[h][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (m2[j][h] >= 0 && p.res) {
+                    const float* rp = resf + (long long)m2[j][h] * p.ldres + col;
+                    rf[h][0] = *(const f32x4_t*)rp;
+                    rf[h][1] = *(const f32x4_t*)(rp + 4);
+                }
+            }
+        };
 #pragma unroll
         for (int j = 0; j < FM; ++j)
 #pragma unroll
@@ -709,11 +728,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
                 int oy = ty * TH + TR * wm + j, ox = tx * 16 + pl + 8 * h;
                 if (PH) { oy = 2 * oy + ph_a; ox = 2 * ox + ph_b; }  // source position (y, x) of phase (a, b) -> output pixel (2 y + a, 2 x + b); Ho = 2 Hi
                 m2[j][h] = (oy < Ho && ox < Wo && col_ok) ? (b * Ho + oy) * Wo + ox : -1;
-                if (RES) {
+                if (RES && !F32O) {
                     rv[j][h] = make_uint4(0u, 0u, 0u, 0u);
                     if (m2[j][h] >= 0 && p.res) rv[j][h] = *(const uint4*)(p.res + (long long)m2[j][h] * p.ldres + col);
                 }
             }
+        if (RES && F32O) res_f32_load(0);
         float st_s[8], st_q[8];
         float satm = 0.f;  // fp16 build: max |value| this thread packs in this tile (common.h: sat_track / sat_report)
 #pragma unroll
@@ -732,6 +752,32 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
                 const unsigned sa = stg + (pr * 64 + ((sl8 ^ (pr & 7)) << 3)) * 4;
                 const f32x4_t x0 = *(lds_f4_ptr)sa, x1 = *(lds_f4_ptr)(sa + 16);
                 const long long m = m2[j][h];
+                if (F32O) {
+                    if (m >= 0) {
+                        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                        if (RES) {
+                            v[0] += rf[h][0].x; v[1] += rf[h][0].y; v[2] += rf[h][0].z; v[3] += rf[h][0].w;
+                            v[4] += rf[h][1].x; v[5] += rf[h][1].y; v[6] += rf[h][1].z; v[7] += rf[h][1].w;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (ACT) {
+                                if (p.act == GP_ACT_SILU) v[e] = silu_f(v[e]);
+                                else if (p.act == GP_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                            }
+                            if (col + e >= n_out) v[e] = 0.f;  // zero-padded channels of the last slot
+                        }
+                        float* o = outf + m * p.ldo + col;
+                        *(f32x4_t*)o = f32x4_t{v[0], v[1], v[2], v[3]};
+                        *(f32x4_t*)(o + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+                        if (STATS) {  // the stored values are the fp32 values themselves
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { st_s[e] += v[e]; st_q[e] += v[e] * v[e]; }
+                        }
+                    }
+                    if (RES && h == 1 && j + 1 < FM) res_f32_load(j + 1);  // (both pixels of row j have consumed rf)
+                    continue;
+                }
                 if (m >= 0) {
                     float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                     if (RES) {
@@ -989,8 +1035,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo3_kernel(const IGemmParams p)
 }
 
 bool conv_halo_applicable(const IGemmParams& p) {
-    if (p.ks != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.batch > 1 || p.out_fp32 || p.act == GP_ACT_GEGLU) return false;
+    if (p.ks != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.batch > 1 || p.out_fp32 > 1 || p.act == GP_ACT_GEGLU) return false;
     if (p.bias_mode == GP_BIAS_ROW || (p.ldo & 7)) return false;
+    if (p.out_fp32 == 1) {  // fp32 rows out (contract precision): the persistent kernel's F32O epilogue, plain input, whole slots, exact x2 only as phases
+        if (p.in_scale || (p.n_store & 7) || (p.res && (!p.res_f32 || (p.ldres & 7) || p.ldres < p.n_store)) || (p.dbg & 256)) return false;
+        if (p.ups && !conv_halo_uses_phases(p)) return false;
+    } else if (p.res_f32) return false;
     if (p.in_scale && p.Cin > GN_MAXC) return false;
     if (p.ups) {
         if (p.Hu != 2 * p.Hi || p.Wu != 2 * p.Wi || p.Ho != p.Hu || p.Wo != p.Wu) return false;
@@ -1017,7 +1067,8 @@ static void launch_halo3_ph(const IGemmParams& p, int grid, hipStream_t s) {
     IGemmParams q = p;
     q.wt = p.wt_ph;
     q.ldw = 16 * p.Cin;
-    launch_halo3_one<false, 0, 0, 4, true>(q, grid, s);
+    if (p.out_fp32 == 1) launch_halo3_one<false, 0, HALO_F32O, 4, true>(q, grid, s);
+    else launch_halo3_one<false, 0, 0, 4, true>(q, grid, s);
 }
 bool conv_halo_uses_phases(const IGemmParams& p) {
     return p.ups && p.wt_ph && !p.in_scale && !gp_sw().no_up_phases && p.Ho == 2 * p.Hi && p.Wo == 2 * p.Wi &&
@@ -1027,6 +1078,11 @@ bool conv_halo_uses_phases(const IGemmParams& p) {
 static void launch_halo3(const IGemmParams& p, int grid, int tr, hipStream_t s) {
     const int abl = (p.dbg >> 9) & 2047;  // profiling ablations (GENPERCEPT_IGEMM_DBG = 512 * ABL), plain convs only
     const int fused = !p.in_scale ? 0 : p.in_silu ? 2 : 1;
+    if (p.out_fp32 == 1) {  // contract precision (conv_halo_applicable: plain input, no nine-tap upsample)
+        if (tr == 3) launch_halo3_one<false, 0, HALO_F32O, 3>(p, grid, s);
+        else launch_halo3_one<false, 0, HALO_F32O, 4>(p, grid, s);
+        return;
+    }
     if (tr == 3) { launch_halo3_one<false, 0, 0, 3>(p, grid, s); return; }  // (halo_plan: plain stride-1 convs only)
     if (p.ups) {
         if (fused == 2) launch_halo3_one<true, 2, 0>(p, grid, s);
@@ -1082,6 +1138,7 @@ static int halo3_wgs_per_image(const IGemmParams& p, int ncu, int th = 16) {
 }
 static bool halo_persistent(const IGemmParams& p) {
     const bool slots_ok = (p.n_store & 7) == 0 && (p.ldo & 7) == 0 && (!p.res || ((p.ldres & 7) == 0 && p.ldres >= p.n_store));
+    if (p.out_fp32 == 1) return slots_ok;  // (no one-tile-per-workgroup fallback with fp32 rows: conv_halo_applicable refuses those shapes)
     return slots_ok && !(p.dbg & 256);
 }
 // workgroups per image (a multiple of tiles_n) of the persistent kernel: one function for the launch AND for the statistics-row count the engine

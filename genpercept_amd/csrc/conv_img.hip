@@ -226,7 +226,8 @@ static int conv_img_nb(int B, int H, int W) {
 
 bool conv_img_applicable(const IGemmParams& p) {
     const bool off = gp_sw().no_conv_img;  // A/B switch
-    if (off || p.ks != 3 || p.stride != 1 || p.ups || p.pad_t != 1 || p.pad_l != 1 || p.batch > 1 || p.in_scale || p.out_fp32) return false;
+    if (off || p.ks != 3 || p.stride != 1 || p.ups || p.pad_t != 1 || p.pad_l != 1 || p.batch > 1 || p.in_scale || p.out_fp32 > 1) return false;
+    if ((p.out_fp32 == 1) != (p.res_f32 != 0) && p.res) return false;  // (splitk_reduce_kernel: residual in the output's element type)
     if (p.act == GP_ACT_GEGLU || p.bias_mode == GP_BIAS_ROW || p.Ho != p.Hi || p.Wo != p.Wi) return false;
     if ((p.Cin & 31) || (p.N & 63) || p.N != p.n_store || p.n_store != p.ldo || (p.ldo & 3) || p.Cin < 64) return false;
     return conv_img_nb(p.B, p.Hi, p.Wi) > 0 && conv_img_ksplit(p) >= 2;  // (the partial sums always go through the split-K workspace)

@@ -306,30 +306,36 @@ struct gp_engine {
     // The x2-nearest-upsample 3x3 conv as four 2 x 2-tap phase convolutions on the source map (conv_halo.hip, PH): output pixel (2y + a, 2x + b) reads
     // source rows {y - 1 + a, y + a} with the kernel rows that fall onto the same source row summed -- a = 0: {w[0]}, {w[1] + w[2]}; a = 1: {w[0] + w[1]},
     // {w[2]} -- and the same along x.  Sums in fp32, ONE rounding to the element type.  Layout [n_rows][phase = 2 a + b][tap = 2 ty + tx][cin_pad].
-    static void pack_phase_rows(const float* w, int cout, int cin, int cin_pad, std::vector<h16_t>& out) {
+    // split (contract precision): 3 cin_pad elements per tap in B order [hi | hi | lo] of the fp32 sum, like pack_rows
+    static void pack_phase_rows(const float* w, int cout, int cin, int cin_pad, std::vector<h16_t>& out, bool split = false) {
         static const int lo[2][2] = {{0, 1}, {0, 2}}, hi[2][2] = {{0, 2}, {1, 2}};  // [phase][tap]: kernel index range [lo, hi]
+        const size_t kw = split ? (size_t)3 * cin_pad : (size_t)cin_pad;
         for (int n = 0; n < cout; ++n)
             for (int a = 0; a < 2; ++a)
                 for (int b = 0; b < 2; ++b)
                     for (int ty = 0; ty < 2; ++ty)
                         for (int tx = 0; tx < 2; ++tx) {
-                            h16_t* o = out.data() + (((size_t)n * 4 + (2 * a + b)) * 4 + (2 * ty + tx)) * cin_pad;
+                            h16_t* o = out.data() + (((size_t)n * 4 + (2 * a + b)) * 4 + (2 * ty + tx)) * kw;
                             for (int c = 0; c < cin; ++c) {
                                 const float* wi = w + ((size_t)n * cin + c) * 9;
                                 float acc = 0.f;
                                 for (int ky = lo[a][ty]; ky <= hi[a][ty]; ++ky)
                                     for (int kx = lo[b][tx]; kx <= hi[b][tx]; ++kx) acc += wi[ky * 3 + kx];
-                                o[c] = f_to_h16_host(acc);
+                                const h16_t h = f_to_h16_host(acc);
+                                o[c] = h;
+                                if (split) {
+                                    o[cin_pad + c] = h;
+                                    o[2 * cin_pad + c] = f_to_h16_host(acc - h16_to_float_host(h));
+                                }
                             }
                         }
     }
     void pack_phases(PackedW& pw, const std::string& name) {
-        if (contract) return;  // (contract precision runs the nine-tap upsample kernel)
         const HostTensor& w = H(name + ".weight");
         if (w.shape.size() != 4 || w.shape[2] != 3 || w.shape[3] != 3) throw std::invalid_argument(name + ": not a 3x3 conv");
         const int cout = (int)w.shape[0], cin = (int)w.shape[1];
-        std::vector<h16_t> buf((size_t)pw.n_rows * 16 * pw.cin_pad, 0);
-        pack_phase_rows(w.v.data(), cout, cin, pw.cin_pad, buf);
+        std::vector<h16_t> buf((size_t)pw.n_rows * 16 * pw.cin_pad, 0);  // (contract precision: pw.cin_pad is already the tripled width)
+        pack_phase_rows(w.v.data(), cout, cin, contract ? pw.cin_pad / 3 : pw.cin_pad, buf, contract);
         pw.w_ph = upload(buf.data(), buf.size());
     }
     PackedW pack(const float* w, const float* bias, int cout, int cin, int ks, int cin_pad, bool geglu = false) {
@@ -1087,8 +1093,27 @@ struct gp_engine {
     // A-order operand [B*T][3C] the output projection reads.
     Act attention_c(const Act& qkv, int heads, int hd, float scale) {
         const int B = qkv.B, T = qkv.H * qkv.W, Tpad = round_up(T, 64), Z = B * heads;
-        if (!c_softmax_split_supported(Tpad)) throw std::invalid_argument("contract precision: at most 16384 tokens per attention map");
         if (hd % 64 || qkv.C != 3 * heads * hd) throw std::logic_error("attention_c: layout");
+        if (hd == 64 && !gp_sw().c_no_flash && (long long)T * qkv.C * 2 < 0x7fffffffll) {  // flash attention over split operands (attention.hip)
+            const int C = heads * hd;
+            h16_t* qk_hi = (h16_t*)pool.alloc((size_t)B * T * 2 * C * sizeof(h16_t));
+            h16_t* qk_lo = (h16_t*)pool.alloc((size_t)B * T * 2 * C * sizeof(h16_t));
+            h16_t* vt_hi = (h16_t*)pool.alloc((size_t)Z * hd * Tpad * sizeof(h16_t));
+            h16_t* vt_lo = (h16_t*)pool.alloc((size_t)Z * hd * Tpad * sizeof(h16_t));
+            mark("c_qkv_planes T=" + std::to_string(T) + " heads=" + std::to_string(heads), 0.0, 2);
+            launch_c_qkv_planes(qkv.f, qkv.C, qk_hi, qk_lo, vt_hi, vt_lo, B, T, Tpad, heads, hd, st);
+            Act a = new_operand(qkv.B, qkv.H, qkv.W, C);
+            const double fl = 4.0 * Z * (double)T * T * hd;
+            tm.flops_attn += fl;
+            tm.n_attn++;
+            mark("flash_attn64_split T=" + std::to_string(T) + " heads=" + std::to_string(heads), fl);
+            prof_begin(1);
+            launch_flash_attn64_split(qk_hi, qk_lo, vt_hi, vt_lo, a.p, B, T, heads, 2 * C, Tpad, st);
+            prof_end();
+            pool.release(qk_hi); pool.release(qk_lo); pool.release(vt_hi); pool.release(vt_lo);
+            return a;
+        }
+        if (!c_softmax_split_supported(Tpad)) throw std::invalid_argument("contract precision: at most 16384 tokens per unfused attention map");
         h16_t* Qs = (h16_t*)pool.alloc((size_t)Z * T * 3 * hd * sizeof(h16_t));
         h16_t* Ks = (h16_t*)pool.alloc((size_t)Z * T * 3 * hd * sizeof(h16_t));
         h16_t* Vts = (h16_t*)pool.alloc((size_t)Z * hd * 3 * Tpad * sizeof(h16_t));

@@ -68,6 +68,7 @@ void gp_switches_reload() {
     s.gn_small_old = flag("GENPERCEPT_GN_SMALL_OLD");      // A/B: gn_small_kernel (three passes over L2) instead of gn_small_reg_kernel (r5)
     s.xfold_lds = num("GENPERCEPT_XFOLD_LDS", -1);       // 0 = the r2 cross-attention fold kernel
     s.no_fin_fuse = flag("GENPERCEPT_NO_FIN_FUSE");
+    s.c_no_flash = flag("GENPERCEPT_C_NO_FLASH");         // A/B: contract precision's head_dim-64 attention unfused (logits in HBM) instead of flash_attn64_split_kernel
     s.pgemm_ring3 = flag("GENPERCEPT_PGEMM_RING3");       // A/B: the 128-row persistent GEMM with the 3-deep ring of r2 / r3 (default since r4: 4-deep)
     // Engines on other host threads read g_switches on their launch paths: write it only when the environment really changed (tests / A/B
     // scripts, between calls), under a lock, so that concurrent engine creation with an unchanged environment never stores to it.
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IGemmParams p
 // ---- split-K: out[m][n] = act( sum_z part[z][m][n] + bias[n] ) (+ res[m][n]); columns in [n_out, n_store) are written as 0 ----------
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, long long slice, int M, int N, int n_store,
                                                              const float* __restrict__ bias, const h16_t* __restrict__ res, int ldres, int act,
-                                                             h16_t* __restrict__ out, int ldo) {
+                                                             h16_t* __restrict__ out, int ldo, int f32) {  // f32 (contract precision): fp32 rows out, fp32 residual
     const int nv = n_store >> 2;  // 4 columns per thread (n_store % 4 == 0)
     const long long total = (long long)M * nv;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -311,14 +312,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         for (int e = 0; e < 4; ++e) {
             if (c + e < N) {
                 if (bias) v[e] += bias[c + e];
-                if (res) v[e] += h16_to_f(res[m * ldres + c + e]);
+                if (res) v[e] += f32 ? ((const float*)res)[m * ldres + c + e] : h16_to_f(res[m * ldres + c + e]);
                 if (act == GP_ACT_SILU) v[e] = silu_f(v[e]);
                 else if (act == GP_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
             } else {
                 v[e] = 0.f;
             }
         }
-        *(uint2*)(out + m * ldo + c) = pack_h16x4(v[0], v[1], v[2], v[3]);
+        if (f32) *(float4*)((float*)out + m * ldo + c) = make_float4(v[0], v[1], v[2], v[3]);
+        else *(uint2*)(out + m * ldo + c) = pack_h16x4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -328,7 +330,8 @@ int igemm_ksplit(const IGemmParams& p, int tile_hint) {
     const bool no_split = gp_sw().no_splitk;
     if (tile_hint == 0 && !no_split && conv_img_applicable(p)) return conv_img_ksplit(p);  // whole-image tiles (conv_img.hip)
     if (tile_hint != 0 && tile_hint != 2) return 1;
-    if (no_split || p.ks != 3 || p.ups || p.batch > 1 || p.out_fp32 || p.act == GP_ACT_GEGLU || p.bias_mode == GP_BIAS_ROW || p.in_scale) return 1;
+    if (no_split || p.ks != 3 || p.ups || p.batch > 1 || p.out_fp32 > 1 || p.act == GP_ACT_GEGLU || p.bias_mode == GP_BIAS_ROW || p.in_scale) return 1;
+    if ((p.out_fp32 == 1) != (p.res_f32 != 0) && p.res) return 1;  // (the reduce kernel reads the residual in the output's element type)
     if ((p.n_store & 3) || (p.ldo & 3) || p.n_store != p.ldo) return 1;
     if (conv_uses_halo(p, tile_hint)) return 1;
     const int ncols = p.N > p.n_store ? p.N : p.n_store;
@@ -445,7 +448,7 @@ void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s) {
             int blocks = (int)((total + 255) / 256);
             if (blocks > 2048) blocks = 2048;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, S, (long long)slice, p.M, p.N, p.n_store,
-                               p.bias_mode == GP_BIAS_COL ? p.bias : nullptr, p.res, p.ldres, p.act, (h16_t*)p.out, p.ldo);
+                               p.bias_mode == GP_BIAS_COL ? p.bias : nullptr, p.res, p.ldres, p.act, (h16_t*)p.out, p.ldo, p.out_fp32 == 1 ? 1 : 0);
             return;
         }
         if (ws) {
@@ -457,7 +460,7 @@ void launch_igemm(const IGemmParams& p, int tile_hint, hipStream_t s) {
             int blocks = (int)((total + 255) / 256);
             if (blocks > 2048) blocks = 2048;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, S, (long long)slice, p.M, p.N, p.n_store,
-                               p.bias_mode == GP_BIAS_COL ? p.bias : nullptr, p.res, p.ldres, p.act, (h16_t*)p.out, p.ldo);
+                               p.bias_mode == GP_BIAS_COL ? p.bias : nullptr, p.res, p.ldres, p.act, (h16_t*)p.out, p.ldo, p.out_fp32 == 1 ? 1 : 0);
             return;
         }
     }

@@ -66,7 +66,7 @@ struct IGemmParams {
 struct GpSwitches {
     int flash_ring3, no_flash512, f5_dbg, no_conv_few, no_conv_img, conv_img_s, no_cross_fold, no_gn_fusion, gn_fuse_max_slices,
         gn_fuse_below_px, no_stats_fusion, vt_tile, no_gn_small, fp32_scores, no_qkv_fuse, qkv_fuse_max_rows, no_rgb_conv, igemm_dbg, no_splitk,
-        no_halo, no_pgemm, gn_apply_old, xfold_lds, no_fin_fuse, pgemm_ring3, gn_small_old, no_up_phases;
+        no_halo, no_pgemm, gn_apply_old, xfold_lds, no_fin_fuse, pgemm_ring3, gn_small_old, no_up_phases, c_no_flash;
 };
 const GpSwitches& gp_sw();
 void gp_switches_reload();
@@ -215,6 +215,11 @@ void launch_c_gn_apply_split(const float* x, h16_t* out, const float* scale, con
 void launch_c_layernorm_split(const float* x, h16_t* out, const float* gamma, const float* beta, int rows, int C, float eps, hipStream_t s);
 void launch_c_concat(const float* a, int Ca, const float* b, int Cb, float* out, long long pixels, hipStream_t s);
 void launch_c_heads_split(const float* qkv, int ld, h16_t* Qs, h16_t* Ks, h16_t* Vts, int B, int T, int Tpad, int heads, int hd, hipStream_t s);
+void launch_c_qkv_planes(const float* qkv, int ld, h16_t* qk_hi, h16_t* qk_lo, h16_t* vt_hi, h16_t* vt_lo, int B, int T, int Tpad, int heads, int hd,
+                         hipStream_t s);
+// attention.hip: flash attention (head_dim 64) over split operands; out = A-order split operand [B*T][3 * heads * 64]
+void launch_flash_attn64_split(const h16_t* qk_hi, const h16_t* qk_lo, const h16_t* vt_hi, const h16_t* vt_lo, h16_t* out, int B, int T, int heads, int ld,
+                               int Tpad, hipStream_t s);
 bool c_softmax_split_supported(int ld);
 void launch_c_softmax_split(const float* in, h16_t* out, long long rows, int T, int ld, float scale, hipStream_t s);
 void launch_c_heads_merge_split(const float* O, h16_t* out, int B, int T, int heads, int hd, hipStream_t s);

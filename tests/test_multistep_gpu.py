@@ -16,7 +16,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TOL_MAP = {"bf16": 2.0e-2, "fp16": 2.5e-3}
+TOL_MAP = {"bf16": 2.0e-2, "fp16": 2.5e-3, "fp32c": 1.5e-4}  # fp32c: the contract precision (fp32 storage, split-bf16 products)
+TORCH_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32c": torch.float32}
 SCHED = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False, steps_offset=1,
              prediction_type="v_prediction", timestep_spacing="leading")  # hf_configs/scheduler_beta_0.00085_0.012
 
@@ -46,7 +47,7 @@ def _engine(w, arch, ctx, precision):
     return eng
 
 
-@pytest.fixture(scope="module", params=[("marigold", "bf16"), ("marigold", "fp16"), ("blend", "bf16"), ("blend", "fp16")], ids=lambda p: "-".join(p))
+@pytest.fixture(scope="module", params=[("marigold", "bf16"), ("marigold", "fp16"), ("marigold", "fp32c"), ("blend", "bf16"), ("blend", "fp16"), ("blend", "fp32c")], ids=lambda p: "-".join(p))
 def eng(request, weights, golden):
     arch, precision = request.param
     e = _engine(weights, arch, golden["ctx"], precision)
@@ -139,7 +140,7 @@ def test_loop_contract(eng, golden):
         eng.infer_steps(rgb, "depth", bad, noise if eng.arch == "marigold" else None)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "fp32c"])
 def test_pipeline_multistep_surface(precision, weights, golden, metric_log):
     """GenPerceptPipeline(genpercept_pipeline=False): run.py:361-368 construction, __call__ with denoising_steps / ensemble_size / generator
     (genpercept_pipeline.py:199-297), against the oracle's loop + the ensembling on the same noise."""
@@ -151,7 +152,7 @@ def test_pipeline_multistep_surface(precision, weights, golden, metric_log):
     ctx = torch.as_tensor(golden["ctx"])
     img_u8 = golden["sq_rgb"][0]
     img = Image.fromarray(np.transpose(img_u8, (1, 2, 0)))
-    dt = torch.bfloat16 if precision == "bf16" else torch.float16
+    dt = TORCH_DTYPE[precision]
     tol = TOL_MAP[precision]
     # marigold from a 4-channel UNet checkpoint: conv_in is replaced like run.py:322-323 does
     pipe = GenPerceptPipeline(unet=w["u4"], vae=w["vsd"], scheduler=dict(SCHED), text_encoder=ctx, tokenizer=None, genpercept_pipeline=False,
@@ -191,7 +192,7 @@ def test_pipeline_multistep_surface(precision, weights, golden, metric_log):
         pg(img, denoising_steps=4, mode="depth")
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "fp32c"])
 def test_full_sd21_widths_marigold(precision, metric_log):
     """The loop at the real SD2.1 widths (8-channel conv_in, 865.9 M parameters), 64x64 px, 4 steps, against the oracle on the host."""
     from genpercept_amd.engine import Engine

@@ -25,7 +25,7 @@ def inputs():
     return np.load(os.path.join(GOLD, "e2e_tiny.npz"))
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "fp32c"])
 @pytest.mark.parametrize("tag", ["sq", "odd"])
 def test_engine_vs_reference_executed(tag, precision, tiny_weights, refexec, inputs, metric_log):
     d = torch.device("cuda", 0)
@@ -124,7 +124,7 @@ def v1_weights():
                 dsd=None)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "fp32c"])
 @pytest.mark.parametrize("cname", ["ctx2", "ctx77"])
 def test_engine_vs_genpercept_v1_single_infer(cname, precision, v1_weights, metric_log):
     """HIP engine against what GenPercept_v1's `single_infer` (pipeline_genpercept.py:263-309) computes when EXECUTED

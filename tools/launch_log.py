@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--head", default="vae")
     ap.add_argument("--tag", default="r02")
     ap.add_argument("--passes", type=int, default=3)
+    ap.add_argument("--precision", default="bf16", help="bf16 | fp16 | fp32c (contract precision)")
     args = ap.parse_args()
     from bench import synthetic_rgb
     from genpercept_amd import config as gc
@@ -29,7 +30,7 @@ def main():
     dpt = args.head == "dpt"
     ucfg, vcfg = gc.UNetConfig(has_out=not dpt), gc.VAEConfig()
     dcfg = gc.DPTConfig() if dpt else None
-    eng = Engine(0, ucfg, vcfg, dcfg)
+    eng = Engine(0, ucfg, vcfg, dcfg, precision=args.precision)
     eng.load_state_dict("vae", gw.synth_state_dict(gw.vae_manifest(vcfg), seed=1))
     eng.load_state_dict("unet", gw.synth_state_dict(gw.unet_manifest(ucfg), seed=0))
     if dpt:
@@ -54,7 +55,7 @@ def main():
         ms = sorted(l[i][0] for l in logs)[len(logs) // 2]
         rows.append((ms, logs[0][i][1], logs[0][i][2]))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    path = os.path.join(ROOT, "gpurun_out", f"launch_log_{args.tag}_{args.head}_b{args.batch}_{args.res}.txt")
+    path = os.path.join(ROOT, "gpurun_out", f"launch_log_{args.tag}_{args.head}_b{args.batch}_{args.res}" + ("" if args.precision == "bf16" else "_" + args.precision) + ".txt")
     # stage boundaries by name: encoder ends at the first 'unet' conv_in = the conv with K = 576 after the encoder's conv_out
     tot = sum(r[0] for r in rows)
     with open(path, "w") as f:
@@ -65,6 +66,8 @@ def main():
     kinds = collections.OrderedDict()
     for ms, fl, name in rows:
         k = " ".join(name.split()[:2]) if name.split()[0] in ("gemm", "bgemm", "conv3x3", "conv3x3up", "conv3x3s2") else name.split()[0]
+        if args.precision == "fp32c" and name.split()[0] == "bgemm":
+            k += " " + [t for t in name.split() if t.startswith("K=")][0]
         a = kinds.setdefault(k, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += ms
