@@ -1070,8 +1070,16 @@ static void launch_halo3_ph(const IGemmParams& p, int grid, hipStream_t s) {
     if (p.out_fp32 == 1) launch_halo3_one<false, 0, HALO_F32O, 4, true>(q, grid, s);
     else launch_halo3_one<false, 0, 0, 4, true>(q, grid, s);
 }
+// the persistent kernel (conv3x3_halo3_kernel) takes the problem: whole 8-channel slots everywhere (else the one-tile-per-workgroup fallback)
+static bool halo_persistent(const IGemmParams& p) {
+    const bool slots_ok = (p.n_store & 7) == 0 && (p.ldo & 7) == 0 && (!p.res || ((p.ldres & 7) == 0 && p.ldres >= p.n_store));
+    if (p.out_fp32 == 1) return slots_ok;  // (no one-tile-per-workgroup fallback with fp32 rows: conv_halo_applicable refuses those shapes)
+    return slots_ok && !(p.dbg & 256);
+}
+// ONE decision for the launcher, the engine's executed-flop accounting and the test entry point's guard: the phase kernel exists in the
+// persistent form only
 bool conv_halo_uses_phases(const IGemmParams& p) {
-    return p.ups && p.wt_ph && !p.in_scale && !gp_sw().no_up_phases && p.Ho == 2 * p.Hi && p.Wo == 2 * p.Wi &&
+    return p.ups && p.wt_ph && !p.in_scale && !gp_sw().no_up_phases && p.Ho == 2 * p.Hi && p.Wo == 2 * p.Wi && halo_persistent(p) &&
            (long long)p.n_rows * 16 * p.Cin * 2 < 0xfffffff0ll;
 }
 
@@ -1135,11 +1143,6 @@ static int halo3_wgs_per_image(const IGemmParams& p, int ncu, int th = 16) {
     if (J < tiles_n) J = tiles_n;
     if (J > tiles_sp * tiles_n) J = tiles_sp * tiles_n;
     return J;
-}
-static bool halo_persistent(const IGemmParams& p) {
-    const bool slots_ok = (p.n_store & 7) == 0 && (p.ldo & 7) == 0 && (!p.res || ((p.ldres & 7) == 0 && p.ldres >= p.n_store));
-    if (p.out_fp32 == 1) return slots_ok;  // (no one-tile-per-workgroup fallback with fp32 rows: conv_halo_applicable refuses those shapes)
-    return slots_ok && !(p.dbg & 256);
 }
 // workgroups per image (a multiple of tiles_n) of the persistent kernel: one function for the launch AND for the statistics-row count the engine
 // allocates.  (r4's alternative structures -- 32 x 16 tiles, two workgroups per CU, Winograd F(2,3) along x -- measured 0-10 % slower and live in

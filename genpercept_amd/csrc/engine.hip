@@ -2150,7 +2150,7 @@ int gp_latent_size(int x) { for (int i = 0; i < 3; ++i) x = (x - 2) / 2 + 1; ret
 int gp_dpt_out_size(int latent) { for (int i = 0; i < 2; ++i) latent = (latent - 1) / 2 + 1; return 32 * latent; }
 
 gp_status gp_pack_weight(const float* w, int cout, int cin, int ks, int cin_pad, int geglu, void* dev_out) {
-    if (!w || !dev_out || (ks != 1 && ks != 3) || cin_pad < cin || (cin_pad % 64)) return GP_ERR_INVALID;
+    if (!w || !dev_out || cout < 1 || cin < 1 || (ks != 1 && ks != 3) || cin_pad < cin || (cin_pad % 64)) return GP_ERR_INVALID;
     try {
         const int n_rows = gp_packed_rows(cout);
         std::vector<h16_t> buf((size_t)n_rows * ks * ks * cin_pad, 0);
@@ -2184,7 +2184,7 @@ gp_status gp_conv2d(const void* in, const void* w_packed, const float* bias, con
 }
 
 gp_status gp_pack_weight_phases(const float* w, int cout, int cin, int cin_pad, void* dev_out) {
-    if (!w || !dev_out || cin_pad < cin || (cin_pad % 64)) return GP_ERR_INVALID;
+    if (!w || !dev_out || cout < 1 || cin < 1 || cin_pad < cin || (cin_pad % 64)) return GP_ERR_INVALID;
     try {
         std::vector<h16_t> buf((size_t)gp_packed_rows(cout) * 16 * cin_pad, 0);
         gp_engine::pack_phase_rows(w, cout, cin, cin_pad, buf);
@@ -2208,6 +2208,33 @@ gp_status gp_conv2d_up2(const void* in, const void* w_packed, const void* w_phas
         p.dbg = gp_sw().igemm_dbg;
         if (!conv_uses_halo(p, 5) || !conv_halo_uses_phases(p)) return GP_ERR_INVALID;  // (this entry point exists to test the phase kernel)
         launch_igemm(p, 5, (hipStream_t)stream);
+        HIPCHK(hipGetLastError());
+        return GP_OK;
+    } catch (...) { return GP_ERR_HIP; }
+}
+
+gp_status gp_conv2d_up2_stats(const void* in, const void* w_packed, const void* w_phases, const float* bias, const void* residual, void* out, int B, int Hi,
+                              int Wi, int Cin, int Cout, const float* gamma, const float* beta, int groups, float eps, float* scale_out, float* shift_out,
+                              void* stream) {
+    if (!in || !w_packed || !w_phases || !out || !gamma || !beta || !scale_out || !shift_out || (Cin % 64) || (Cout % 8) || groups < 1 || (Cout % groups))
+        return GP_ERR_INVALID;
+    try {
+        KernelEntry lk;
+        IGemmParams p{};
+        p.in = (const h16_t*)in; p.wt = (const h16_t*)w_packed; p.wt_ph = (const h16_t*)w_phases; p.bias = bias; p.res = (const h16_t*)residual; p.out = out;
+        p.zero = zero_page();
+        p.M = B * 4 * Hi * Wi; p.N = Cout; p.Cin = Cin; p.n_rows = gp_packed_rows(Cout); p.ks = 3;
+        p.B = B; p.Hi = Hi; p.Wi = Wi; p.Ho = 2 * Hi; p.Wo = 2 * Wi; p.stride = 1; p.pad_t = 1; p.pad_l = 1;
+        p.ups = 1; p.Hu = 2 * Hi; p.Wu = 2 * Wi;
+        p.lda = Cin; p.ldo = Cout; p.ldres = Cout; p.ldw = 9 * Cin; p.n_store = Cout; p.bias_mode = bias ? GP_BIAS_COL : GP_BIAS_NONE; p.batch = 1;
+        if (!conv_uses_halo(p, 5) || !conv_halo_uses_phases(p)) return GP_ERR_INVALID;
+        int mode = 0, bm = 0;
+        const int nt = igemm_tile_info(p, 5, &mode, &bm);
+        if (nt <= 0) return GP_ERR_INVALID;
+        float* part = scratch_floats(1, (size_t)nt * (Cout * 2 + 1));
+        p.stats_out = part;
+        launch_igemm(p, 5, (hipStream_t)stream);
+        launch_groupnorm_from_partials(part, mode, bm, B, 2 * Hi, 2 * Wi, Cout, groups, eps, gamma, beta, scale_out, shift_out, (hipStream_t)stream);
         HIPCHK(hipGetLastError());
         return GP_OK;
     } catch (...) { return GP_ERR_HIP; }

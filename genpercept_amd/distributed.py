@@ -83,19 +83,25 @@ class ResultGatherer:
 _gatherers: dict = {}
 
 
-def gather_results(local: torch.Tensor, n_total: int, dst: Optional[int] = 0) -> Optional[torch.Tensor]:
+def gather_results(local: torch.Tensor, n_total: int, dst: Optional[int] = 0, clone: bool = False) -> Optional[torch.Tensor]:
     """Gather per-rank result maps [n_local, C, H, W] back into batch order [n_total, C, H, W].
 
     dst = None -> all ranks get the result (all_gather); dst = r -> only rank r (others return None).  Shards may be ragged; they are padded
     to the largest shard for the collective (RCCL wants equal counts) and trimmed afterwards.  Buffers are allocated on the first call with a
-    given (shape, dtype, device, n_total, dst) and reused (ResultGatherer): the result is valid until the next call with the same key."""
+    given (shape, dtype, device, n_total, dst, world size, rank) and reused (ResultGatherer): the result is a VIEW of that buffer, valid until the
+    next call with the same key -- pass clone=True to keep it across calls.  A new process group (other world size / rank remap after
+    destroy_process_group + init_process_group) gets its own buffers: the key carries both, and gatherers of another group size are dropped."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return local
-    key = (tuple(local.shape[1:]), local.dtype, str(local.device), n_total, dst)
+        return local.clone() if clone else local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    key = (tuple(local.shape[1:]), local.dtype, str(local.device), n_total, dst, world, rank)
     g = _gatherers.get(key)
     if g is None:
+        for k in [k for k in _gatherers if k[5:] != (world, rank)]:  # stale: built for a process group that no longer exists
+            del _gatherers[k]
         g = _gatherers[key] = ResultGatherer(local, n_total, dst)
-    return g.gather(local)
+    out = g.gather(local)
+    return out.clone() if (clone and out is not None) else out
 
 
 def barrier():

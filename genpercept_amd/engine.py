@@ -118,6 +118,7 @@ SYMBOLS = {
     "gp_pack_weight": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "gp_pack_weight_phases": (_i, [_vp, _i, _i, _i, _vp]),
     "gp_conv2d_up2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "gp_conv2d_up2_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     "gp_conv2d": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 17 + [_vp]),
     "gp_conv2d_gn": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 7 + [_vp, _vp, _i, _f, _i, _vp]),
     "gp_rgb_conv_in": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -470,6 +471,21 @@ def conv2d_up2(x_nhwc: torch.Tensor, w_packed: torch.Tensor, w_phases: torch.Ten
     if st != GP_OK:
         raise RuntimeError(f"gp_conv2d_up2 failed ({st})")
     return out
+
+
+def conv2d_up2_stats(x_nhwc: torch.Tensor, w_packed: torch.Tensor, w_phases: torch.Tensor, bias, cout: int, gamma: torch.Tensor, beta: torch.Tensor, groups: int,
+                     eps: float, residual=None):
+    """`gp_conv2d_up2_stats`: the phase kernel with its GroupNorm-statistics epilogue; returns (out, scale[b][c], shift[b][c])."""
+    lib = load_library()
+    b, hi, wi, cin = x_nhwc.shape
+    out = torch.empty((b, 2 * hi, 2 * wi, cout), dtype=act_dtype(), device=x_nhwc.device)
+    scale = torch.empty((b, cout), dtype=torch.float32, device=x_nhwc.device)
+    shift = torch.empty((b, cout), dtype=torch.float32, device=x_nhwc.device)
+    st = lib.gp_conv2d_up2_stats(x_nhwc.data_ptr(), w_packed.data_ptr(), w_phases.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), b, hi, wi, cin, cout,
+                                 gamma.data_ptr(), beta.data_ptr(), groups, eps, scale.data_ptr(), shift.data_ptr(), _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_conv2d_up2_stats failed ({st})")
+    return out, scale, shift
 
 
 def conv2d_gn(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,

@@ -209,6 +209,11 @@ gp_status gp_pack_weight(const float* w_oihw_host, int cout, int cin, int ks, in
 gp_status gp_pack_weight_phases(const float* w_oihw_host, int cout, int cin, int cin_pad, void* dev_out);
 gp_status gp_conv2d_up2(const void* in, const void* w_packed, const void* w_phases, const float* bias, const void* residual, void* out, int B, int Hi,
                         int Wi, int Cin, int Cout, void* stream);
+/* the same with the GroupNorm statistics of the tensor it writes (the phase kernel's per-(tile, phase) partial sums and pixel counts, what the VAE
+ * decoder's upsampler convs leave for the next resnet's norm1), finalised to scale / shift like gp_conv2d_stats.  Test entry point. */
+gp_status gp_conv2d_up2_stats(const void* in, const void* w_packed, const void* w_phases, const float* bias, const void* residual, void* out, int B, int Hi,
+                              int Wi, int Cin, int Cout, const float* gamma, const float* beta, int groups, float eps, float* scale_out, float* shift_out,
+                              void* stream);
 gp_status gp_conv2d(const void* in, const void* w_packed, const float* bias, const void* residual, void* out, int B, int Hi, int Wi, int Cin,
                     int Cout, int ks, int stride, int pad_t, int pad_l, int Ho, int Wo, int ups_h, int ups_w, int act, int n_store,
                     int out_fp32, int tile_hint, void* stream);

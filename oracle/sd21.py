@@ -336,6 +336,22 @@ def transformer_2d(x: Tensor, sd, p: str, heads: int, ctx: Tensor, groups: int) 
     return y.reshape(b, h, w, c).permute(0, 3, 1, 2) + res
 
 
+def unet_downsample(x: Tensor, sd, p: str) -> Tensor:
+    """diffusers Downsample2D as the SD2.1 UNet configures it (downsample_padding 1): Conv3x3 stride 2, SYMMETRIC padding 1 (Appendix B.6)."""
+    return _conv(x, sd, p, stride=2, padding=1)
+
+
+def vae_downsample(h: Tensor, sd, p: str) -> Tensor:
+    """diffusers Downsample2D inside DownEncoderBlock2D (padding 0): zero-pad RIGHT / BOTTOM only, then Conv3x3 stride 2 without padding (B.6)."""
+    return _conv(F.pad(h, (0, 1, 0, 1)), sd, p, stride=2, padding=0)
+
+
+def upsample_conv(x: Tensor, sd, p: str, size=None) -> Tensor:
+    """diffusers Upsample2D: nearest x2 (or nearest to `size`, the custom UNet's upsample_size rule, custom_unet.py:115-119,377-378), then Conv3x3 pad 1."""
+    x = F.interpolate(x, scale_factor=2.0, mode="nearest") if size is None else F.interpolate(x, size=tuple(size), mode="nearest")
+    return _conv(x, sd, p)
+
+
 def timestep_embedding(t: Tensor, dim: int) -> Tensor:
     """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos, sin], fp32 (B.9)."""
     half = dim // 2
@@ -372,7 +388,7 @@ def unet_forward(sd, cfg: UNetCfg, sample: Tensor, timestep, ctx: Tensor, return
                 x = transformer_2d(x, sd, f"down_blocks.{i}.attentions.{j}", cfg.num_heads[i], ctx, g)
             skips.append(x)
         if i != nb - 1:
-            x = _conv(x, sd, f"down_blocks.{i}.downsamplers.0.conv", stride=2, padding=1)
+            x = unet_downsample(x, sd, f"down_blocks.{i}.downsamplers.0.conv")
             skips.append(x)
     x = resnet_block(x, sd, "mid_block.resnets.0", g, cfg.norm_eps, emb)
     x = transformer_2d(x, sd, "mid_block.attentions.0", cfg.num_heads[-1], ctx, g)
@@ -391,11 +407,7 @@ def unet_forward(sd, cfg: UNetCfg, sample: Tensor, timestep, ctx: Tensor, return
             if blk["attn"]:
                 x = transformer_2d(x, sd, f"up_blocks.{i}.attentions.{j}", blk["heads"], ctx, g)
         if blk["upsample"]:
-            if upsample_size is None:
-                x = F.interpolate(x, scale_factor=2.0, mode="nearest")
-            else:
-                x = F.interpolate(x, size=tuple(upsample_size), mode="nearest")
-            x = _conv(x, sd, f"up_blocks.{i}.upsamplers.0.conv")
+            x = upsample_conv(x, sd, f"up_blocks.{i}.upsamplers.0.conv", upsample_size)
         feats.append(x)
     if return_feature or not cfg.has_out:
         return None, feats
@@ -434,8 +446,7 @@ def vae_encode_moments(sd, cfg: VAECfg, x: Tensor) -> Tensor:
         for j in range(cfg.layers_per_block):
             h = resnet_block(h, sd, f"encoder.down_blocks.{i}.resnets.{j}", g, eps, None)
         if i != nb - 1:
-            h = F.pad(h, (0, 1, 0, 1))  # right/bottom only (B.6)
-            h = _conv(h, sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", stride=2, padding=0)
+            h = vae_downsample(h, sd, f"encoder.down_blocks.{i}.downsamplers.0.conv")  # right/bottom only (B.6)
     h = resnet_block(h, sd, "encoder.mid_block.resnets.0", g, eps, None)
     h = vae_mid_attention(h, sd, "encoder.mid_block.attentions.0", g, eps)
     h = resnet_block(h, sd, "encoder.mid_block.resnets.1", g, eps, None)
@@ -462,8 +473,7 @@ def vae_decode(sd, cfg: VAECfg, z: Tensor) -> Tensor:
         for j in range(cfg.layers_per_block + 1):
             h = resnet_block(h, sd, f"decoder.up_blocks.{i}.resnets.{j}", g, eps, None)
         if i != nb - 1:
-            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
-            h = _conv(h, sd, f"decoder.up_blocks.{i}.upsamplers.0.conv")
+            h = upsample_conv(h, sd, f"decoder.up_blocks.{i}.upsamplers.0.conv")
     h = F.silu(_gn(h, sd, "decoder.conv_norm_out", g, eps))
     return _conv(h, sd, "decoder.conv_out")
 

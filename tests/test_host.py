@@ -166,7 +166,15 @@ if rank == 0:
 # equal shards: the receive buffer is the result (a view, no compaction copy)
 eq = gd.gather_results(torch.full((2, 1, 4, 6), float(rank)), 2 * world, dst=None)
 ok = ok and eq.shape[0] == 2 * world and all(float(eq[2 * r].mean()) == r and float(eq[2 * r + 1].mean()) == r for r in range(world))
-ok = ok and len(gd._gatherers) == 3 and not gd._gatherers[((1, 4, 6), torch.float32, "cpu", 2 * world, None)].ragged
+ok = ok and len(gd._gatherers) == 3 and not gd._gatherers[((1, 4, 6), torch.float32, "cpu", 2 * world, None, world, rank)].ragged
+# clone=True: the caller's copy survives the next call with the same key (ADVICE r5: the default result is a view of the reused buffer)
+keep = gd.gather_results(local_out, n_total, dst=None, clone=True)
+again = gd.gather_results(local_out + 3.0, n_total, dst=None)
+ok = ok and keep.data_ptr() != again.data_ptr() and all(float(keep[i].mean()) == i for i in range(n_total)) and float(again[0].mean()) == 3.0
+# a key built for another process group (world size / rank) is never reused: simulate a stale entry and check it is dropped
+gd._gatherers[((9,), torch.float32, "cpu", 1, None, world + 1, rank)] = object()
+_ = gd.gather_results(torch.full((1, 2, 2, 2), 1.0), world, dst=None)
+ok = ok and not any(k[5] != world for k in gd._gatherers)
 mx = gd.max_over_ranks(float(rank + 1), torch.device("cpu"))
 ok = ok and mx == float(world)
 print("RANK", rank, "OK" if ok else "FAIL", flush=True)

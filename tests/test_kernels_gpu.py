@@ -320,6 +320,36 @@ def test_conv_halo3_12row_tiles_groupnorm_statistics(case, metric_log, monkeypat
     assert e_sc < 2e-4 and e_sh < 2e-4, (e_sc, e_sh)
 
 
+@pytest.mark.parametrize("case", [(1, 16, 16, 64, 128, False), (2, 24, 40, 128, 128, True), (2, 31, 47, 192, 320, False), (4, 96, 96, 128, 256, False)])
+def test_conv_upsample_x2_phase_kernel_groupnorm_statistics(case, metric_log):
+    """the phase kernel's statistics path is live in the product (the VAE decoder's upsampler convs feed the next resnet's norm1): per (tile,
+    phase) unit sums and pixel counts, partial tiles at the edges -- the scale / shift finalised from them are those of the tensor it stored."""
+    e = _eng()
+    b, h, w, cin, cout, with_res = case
+    groups, eps = 32, 1e-6
+    g = torch.Generator().manual_seed(sum(int(v) for v in case[:5]) + 77)
+    x = rbf(torch.randn(b, cin, h, w, generator=g))
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    bias = torch.randn(cout, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(cout, generator=g), 0.3 * torch.randn(cout, generator=g)
+    res = rbf(torch.randn(b, cout, 2 * h, 2 * w, generator=g)) if with_res else None
+    d = _dev()
+    y, scale, shift = e.conv2d_up2_stats(e.to_nhwc_bf16(x.to(d)), e.pack_weight(wt, device=d), e.pack_weight_phases(wt, device=d), bias.to(d), cout,
+                                         gamma.to(d), beta.to(d), groups, eps, residual=e.to_nhwc_bf16(res.to(d)) if with_res else None)
+    y0 = e.conv2d_up2(e.to_nhwc_bf16(x.to(d)), e.pack_weight(wt, device=d), e.pack_weight_phases(wt, device=d), bias.to(d), cout,
+                      residual=e.to_nhwc_bf16(res.to(d)) if with_res else None)
+    assert torch.equal(y, y0), "the statistics epilogue changed the stored tensor"
+    yg = nhwc_to_nchw(y).float().cpu().reshape(b, groups, -1)
+    mean, var = yg.mean(dim=2), yg.var(dim=2, unbiased=False)
+    cpg = cout // groups
+    sc_ref = gamma[None, :] * (var + eps).rsqrt().repeat_interleave(cpg, dim=1)
+    sh_ref = beta[None, :] - mean.repeat_interleave(cpg, dim=1) * sc_ref
+    e_sc = ((scale.cpu() - sc_ref).abs() / sc_ref.abs().clamp_min(1e-3)).max().item()
+    e_sh = (shift.cpu() - sh_ref).abs().max().item()
+    metric_log(f"conv_up2_phase_stats{case}", scale_rel=e_sc, shift_abs=e_sh)
+    assert e_sc < 2e-4 and e_sh < 2e-4, (e_sc, e_sh)
+
+
 @pytest.mark.parametrize("case", [(2, 32, 32, 128, 128, False, True), (1, 40, 24, 320, 192, False, True), (2, 16, 16, 64, 128, False, False),
                                   (1, 12, 16, 256, 128, True, True), (1, 17, 21, 960, 64, False, True), (1, 24, 24, 2560, 128, False, True),
                                   (4, 48, 48, 1920, 128, False, True)])

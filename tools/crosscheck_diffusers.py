@@ -10,7 +10,19 @@ local SD2.1 checkpoint, this script closes that gap:
 
 It instantiates UNet2DConditionModel / AutoencoderKL, copies their state dicts into the oracle (zero missing / unexpected keys is the
 first check), runs both on the same seeded inputs on the CPU in fp32 and reports max / rms differences per stage.  It is a
-validation tool, not a code path: nothing in genpercept_amd/, tests/ or bench.py imports it.
+validation tool, not a code path: nothing in genpercept_amd/ or bench.py imports it.
+
+One-command form for a machine that has diffusers but not this build container:
+
+    python tools/crosscheck_diffusers.py --verify tests/golden/crosscheck_tiny.npz
+
+The committed fixture (written here, offline, by `--emit`; tests/test_block_identities.py keeps it in step with the oracle) holds a TINY configuration of
+the SD2.1 topology -- same block types, widths 64 / 128 / 256 / 256, seeded weights that `oracle.sd21.synth_state_dict` regenerates (per-module checksums
+in the fixture detect a torch build that draws other numbers) -- with seeded inputs and the ORACLE's outputs for encode_rgb, the UNet at t = 1 (sample
+and the four up-block features), and the decoder.  `--verify` instantiates diffusers' UNet2DConditionModel / AutoencoderKL with that configuration,
+loads the regenerated weights (zero missing / unexpected keys is the first check), runs them on the fixture's inputs and prints, per stage,
+    <stage>  rel max diff <d>   (<= tol: OK)
+then `OK` (exit 0: row 8c's "parity unpinned" is closed for the block internals) or `MISMATCH` (exit 1).
 """
 import argparse
 import os
@@ -22,12 +34,100 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+TINY_UNET = dict(block_out_channels=(64, 128, 256, 256), num_heads=(1, 2, 4, 4), cross_attention_dim=64)
+TINY_VAE = dict(block_out_channels=(64, 128, 128, 128))
+SEEDS = dict(unet=101, vae=102, inputs=103)
+
+
+def _checksums(sd):
+    import numpy as np
+    return np.array([[float(v.double().sum()), float((v.double() ** 2).sum())] for v in sd.values()], dtype=np.float64)
+
+
+def build_fixture():
+    """inputs, oracle outputs and weight checksums of the tiny configuration (pure oracle: runs in the build container)"""
+    import numpy as np
+    from oracle import sd21 as osd
+    ucfg, vcfg = osd.UNetCfg(**TINY_UNET), osd.VAECfg(**TINY_VAE)
+    usd = osd.synth_state_dict(osd.unet_manifest(ucfg), SEEDS["unet"])
+    vsd = osd.synth_state_dict(osd.vae_manifest(vcfg), SEEDS["vae"])
+    g = torch.Generator().manual_seed(SEEDS["inputs"])
+    rgb = torch.rand(1, 3, 72, 88, generator=g) * 2 - 1      # latent 9 x 11: not divisible by 8 -> the upsample_size rule is exercised
+    ctx = torch.randn(1, 2, ucfg.cross_attention_dim, generator=g)
+    with torch.no_grad():
+        lat = osd.encode_rgb(vsd, vcfg, rgb)
+        v, feats = osd.unet_forward(usd, ucfg, lat, 1, ctx)
+        dec = osd.vae_decode(vsd, vcfg, -v / vcfg.scaling_factor)
+    out = dict(rgb=rgb.numpy(), ctx=ctx.numpy(), latent=lat.numpy(), unet=v.numpy(), dec=dec.numpy(), unet_checksums=_checksums(usd), vae_checksums=_checksums(vsd),
+               config=np.array(repr(dict(unet=TINY_UNET, vae=TINY_VAE, seeds=SEEDS, timestep=1, torch=torch.__version__))))
+    for i, f in enumerate(feats):
+        out[f"feat{i}"] = f.numpy()
+    return out
+
+
+def verify_fixture(path, tol):
+    import numpy as np
+    try:
+        from diffusers import AutoencoderKL, UNet2DConditionModel
+    except ImportError:
+        print("diffusers is not installed here: nothing to verify (this is expected in the build container)")
+        return 2
+    from oracle import sd21 as osd
+    fx = np.load(path)
+    ucfg, vcfg = osd.UNetCfg(**TINY_UNET), osd.VAECfg(**TINY_VAE)
+    usd = osd.synth_state_dict(osd.unet_manifest(ucfg), SEEDS["unet"])
+    vsd = osd.synth_state_dict(osd.vae_manifest(vcfg), SEEDS["vae"])
+    if not (np.allclose(_checksums(usd), fx["unet_checksums"], rtol=1e-9) and np.allclose(_checksums(vsd), fx["vae_checksums"], rtol=1e-9)):
+        print("this torch build regenerates other weights than the fixture was written with: run the direct mode (no --verify) instead")
+        return 3
+    unet = UNet2DConditionModel(sample_size=16, in_channels=4, out_channels=4, block_out_channels=TINY_UNET["block_out_channels"],
+                                down_block_types=("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",), up_block_types=("UpBlock2D",) + ("CrossAttnUpBlock2D",) * 3,
+                                layers_per_block=2, cross_attention_dim=TINY_UNET["cross_attention_dim"], attention_head_dim=TINY_UNET["num_heads"],
+                                use_linear_projection=True).eval()
+    vae = AutoencoderKL(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=TINY_VAE["block_out_channels"], layers_per_block=2,
+                        down_block_types=("DownEncoderBlock2D",) * 4, up_block_types=("UpDecoderBlock2D",) * 4, norm_num_groups=32, sample_size=64).eval()
+    ok = True
+    for name, mod, sd in (("unet", unet, usd), ("vae", vae, vsd)):
+        r = mod.load_state_dict(sd, strict=False)
+        print(f"{name}: missing {len(r.missing_keys)}, unexpected {len(r.unexpected_keys)}")
+        ok &= not (r.missing_keys or r.unexpected_keys)
+
+    def report(stage, a, b):
+        nonlocal ok
+        d = float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+        print(f"{stage:14s} rel max diff {d:.3e}   ({'<= tol: OK' if d <= tol else '> tol'})")
+        ok &= d <= tol
+
+    rgb, ctx = torch.from_numpy(fx["rgb"]), torch.from_numpy(fx["ctx"])
+    with torch.no_grad():
+        lat = vae.quant_conv(vae.encoder(rgb))[:, :4] * 0.18215
+        report("vae.encode", fx["latent"], lat.numpy())
+        lat_o = torch.from_numpy(fx["latent"])
+        v = unet(lat_o, 1, encoder_hidden_states=ctx).sample
+        report("unet(t=1)", fx["unet"], v.numpy())
+        dec = vae.decoder(vae.post_quant_conv(-torch.from_numpy(fx["unet"]) / 0.18215))
+        report("vae.decode", fx["dec"], dec.numpy())
+    print("(the four up-block features of the fixture are the CUSTOM UNet's outputs, custom_unet.py:365-400: compare them with the reference's "
+          "CustomUNet2DConditionModel if /root/reference is importable; plain diffusers does not return them)")
+    print("OK" if ok else "MISMATCH")
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sd21", default=None, help="directory with unet/ and vae/ in diffusers layout")
     ap.add_argument("--size", type=int, default=128, help="test image edge (multiple of 8)")
     ap.add_argument("--tol", type=float, default=2e-4, help="max |oracle - diffusers| / max |diffusers| per stage")
+    ap.add_argument("--emit", default=None, help="write the tiny-configuration fixture (inputs + oracle outputs; needs no diffusers)")
+    ap.add_argument("--verify", default=None, help="check diffusers against a fixture written by --emit")
     args = ap.parse_args()
+    if args.emit:
+        import numpy as np
+        np.savez_compressed(args.emit, **build_fixture())
+        print(f"wrote {args.emit}")
+        return 0
+    if args.verify:
+        return verify_fixture(args.verify, args.tol)
     try:
         from diffusers import AutoencoderKL, UNet2DConditionModel
     except ImportError:
