@@ -77,12 +77,20 @@ GP_DEV float h16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }  //
 // fp32 -> bf16 round-to-nearest-even via v_cvt_pk_bf16_f32 (bf16 has the fp32 range: nothing to saturate)
 GP_DEV unsigned pack_h16x2(float lo, float hi) {
     f32x2_t v = {lo, hi};
+#ifdef GP_ROUND_ABL  // measurement build only (tools/build_round_abl.sh): one mantissa bit less, i.e. this translation unit's rounding error doubled
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2n_t)) & 0xfffefffeu;
+#else
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2n_t));
+#endif
 }
 GP_DEV unsigned pack_h16x2_ns(float lo, float hi) { return pack_h16x2(lo, hi); }
 GP_DEV uint2 pack_h16x4(float a, float b, float c, float d) {
+#ifdef GP_ROUND_ABL
+    return make_uint2(pack_h16x2(a, b), pack_h16x2(c, d));
+#else
     f32x4_t v = {a, b, c, d};
     return __builtin_bit_cast(uint2, __builtin_convertvector(v, bf16x4n_t));
+#endif
 }
 // (bf16 has the fp32 range: the saturation tracking of the fp16 build compiles to nothing)
 GP_DEV float sat_track(float m, float, float) { return m; }

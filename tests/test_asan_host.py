@@ -79,6 +79,13 @@ fl = C.c_double(-1.0)
 assert lib.gp_halo_executed_flops(hdl, C.byref(fl)) == 0 and fl.value == 0.0 and lib.gp_halo_executed_flops(None, C.byref(fl)) != 0
 assert lib.gp_pack_weight_phases(None, 8, 4, 64, None) != 0 and lib.gp_pack_weight_phases(x32.ctypes.data, 8, 4, 3, x32.ctypes.data) != 0   # (bad cin_pad)
 assert lib.gp_conv2d_up2(None, None, None, None, None, None, 1, 16, 16, 64, 64, None) != 0
+# r6 entry points: ABI version, engine precision (state rules: before gp_finalize only; bad values refused), the phase conv with statistics, weight-count checks
+assert lib.gp_abi_version() >= 3
+assert lib.gp_get_precision(hdl) == 0 and lib.gp_set_precision(hdl, 1) == 0 and lib.gp_get_precision(hdl) == 1
+assert lib.gp_set_precision(hdl, 7) != 0 and lib.gp_set_precision(None, 1) != 0 and lib.gp_set_precision(hdl, 0) == 0 and lib.gp_get_precision(hdl) == 0
+assert lib.gp_conv2d_up2_stats(None, None, None, None, None, None, 1, 16, 16, 64, 64, None, None, 32, 1e-6, None, None, None) != 0
+assert lib.gp_pack_weight_phases(x32.ctypes.data, -1, 4, 64, x32.ctypes.data) != 0 and lib.gp_pack_weight_phases(x32.ctypes.data, 8, 0, 64, x32.ctypes.data) != 0
+assert lib.gp_pack_weight(x32.ctypes.data, 0, 4, 3, 64, 0, x32.ctypes.data) != 0
 ev = C.c_longlong(-1)
 lib.gp_saturation_events(hdl, C.byref(ev), 1)
 lib.gp_destroy(hdl)

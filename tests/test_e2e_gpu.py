@@ -24,10 +24,11 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-# per element type of the engine (bf16 = libgenpercept_hip.so, fp16 = libgenpercept_hip_f16.so): 2x the largest deviation measured on
-# MI355X for each quantity (gpurun_out/parity_log.jsonl), not more
-TOLS = {"bf16": dict(stage=3.6e-2, map_mean=9e-3, absrel=3e-2),
-        "fp16": dict(stage=4.5e-3, map_mean=1e-3, absrel=4e-3),
+# per precision of the engine (bf16 = libgenpercept_hip.so, fp16 = libgenpercept_hip_f16.so): r6 -- 1.25x the largest deviation measured on
+# MI355X for each quantity (gpurun_out/parity_log.jsonl of tools/sessions/gpu_r06_s1.sh: stage rel-rms 1.83e-2 bf16 / 2.26e-3 fp16, map mean
+# 6.74e-3 / 8.2e-4), not more (r5: 2x)
+TOLS = {"bf16": dict(stage=2.3e-2, map_mean=8.4e-3, absrel=3e-2),
+        "fp16": dict(stage=2.9e-3, map_mean=1e-3, absrel=4e-3),
         # contract precision (gp_set_precision(GP_PREC_CONTRACT), csrc/contract.hip): fp32 storage + split-bf16 matrix products
         "fp32c": dict(stage=3e-4, map_mean=5e-5, absrel=3e-4)}
 TORCH_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32c": torch.float32}

@@ -26,12 +26,19 @@ pytestmark = pytest.mark.gpu
 # mean |delta| on [0,1] maps vs the fp32 oracle.  fp16: the contract.  bf16: 1.5x the simulated floor of bf16 MFMA operands
 # (engine-bf16 row of profiles/r02_precision_ablation.json), i.e. a regression gate, not a parity claim.
 # fp32c = the contract precision (gp_set_precision(GP_PREC_CONTRACT): fp32 storage, split-bf16 matrix products; what torch_dtype=float32 selects)
-MAP_TOL = {"fp16": {"depth": 1e-3, "normal": 1e-3, "disparity": 2e-3}, "bf16": {"depth": 5e-3, "normal": 8e-3, "disparity": 1.2e-2},
-           "fp32c": {"depth": 1e-4, "normal": 1e-4, "disparity": 1e-4}}
-ABSREL_TOL = {"fp16": 4e-3, "bf16": 3e-2, "fp32c": 5e-4}
+# r6: every bf16 / fp16 regression gate is 1.25x what this build measures on MI355X (gpurun_out/parity_log.jsonl of
+# tools/sessions/gpu_r06_s1.sh: bf16 depth / normal / disparity mean_abs 3.35e-3 / 5.47e-3 / 3.05e-3, rel_rms 3.96e-2 / 3.48e-2 / 3.56e-2; fp16
+# 4.39e-4 / 7.24e-4 / 4.91e-4 and 5.16e-3 / 4.57e-3 / 5.60e-3; AbsRel after alignment 1.18e-2 / 1.25e-3), so that ONE kernel whose rounding doubles
+# fails them (profiles/r06_gate_sensitivity.json: the halo conv storing one mantissa bit less moves bf16 depth to 5.1e-3).  The fp16 mean_abs gates
+# stay AT the contract (1e-3; 2e-3 for the min-max-rescaled DPT map).  fp32c: ~2x its measured 4.6e-6 / 7.7e-6 / 7.1e-6 and 5.5e-5 / 4.9e-5 / 7.9e-5.
+MAP_TOL = {"fp16": {"depth": 1e-3, "normal": 1e-3, "disparity": 2e-3}, "bf16": {"depth": 4.2e-3, "normal": 6.9e-3, "disparity": 3.9e-3},
+           "fp32c": {"depth": 1.5e-5, "normal": 1.5e-5, "disparity": 1.5e-5}}
+ABSREL_TOL = {"fp16": 1.6e-3, "bf16": 1.5e-2, "fp32c": 1.2e-4}
+# two runs of one build on other persistent grids (batch 8 vs batch 4: other summation order of the GroupNorm statistics) differ like two roundings
+B8_VS_B4_TOL = {"fp16": 6.2e-4, "bf16": 4.9e-3, "fp32c": 1.5e-5}
 # rel-RMS of the same maps: regression gates (~1.5x the simulated engine rows of profiles/r04_precision_ablation.json), NOT the contract
-RELRMS_TOL = {"fp16": {"depth": 8e-3, "normal": 8e-3, "disparity": 8e-3}, "bf16": {"depth": 6e-2, "normal": 6e-2, "disparity": 6e-2},
-              "fp32c": {"depth": 1e-3, "normal": 1e-3, "disparity": 1e-3}}
+RELRMS_TOL = {"fp16": {"depth": 6.5e-3, "normal": 5.8e-3, "disparity": 7.0e-3}, "bf16": {"depth": 5.0e-2, "normal": 4.4e-2, "disparity": 4.5e-2},
+              "fp32c": {"depth": 1e-4, "normal": 1e-4, "disparity": 1e-4}}
 PRECISIONS = ["fp16", "bf16", "fp32c"]
 # what the regression-gated tests above measured, keyed (precision, head): read by test_contract_1e3 below (same maps, no second engine run)
 _MEASURED = {}
@@ -143,7 +150,7 @@ def test_768_depth_and_normal_vs_live_oracle(precision, full, metric_log):
             assert e <= MAP_TOL[precision]["depth"], (name, e)
         # images 0..3 of the shard against the batch-4 call (other persistent grids: other summation order of the statistics)
         metric_log(f"full768_b8_vs_b4[{precision}]", mean_abs=float((b8[:4] - b4).abs().mean()), max_abs=float((b8[:4] - b4).abs().max()))
-        assert float((b8[:4] - b4).abs().mean()) <= MAP_TOL[precision]["depth"]
+        assert float((b8[:4] - b4).abs().mean()) <= B8_VS_B4_TOL[precision]
     finally:
         eng.close()
 

@@ -30,11 +30,35 @@ def test_library_exports_every_header_symbol():
     assert lib.gp_dpt_out_size(96) == 768 and lib.gp_dpt_out_size(9) == 96
 
 
+def test_abi_version_and_precision_entry_points():
+    """GP_ABI_VERSION of the header == gp_abi_version() of both libraries (ADVICE r5: the r5 removal of gp_timings.sat_events is version 3);
+    gp_set_precision argument handling needs no GPU; torch dtypes map to engine precisions the way run.py:273-281 asks (fp32 = the contract precision)."""
+    import ctypes as C
+    from genpercept_amd import engine
+    hdr = open(os.path.join(ROOT, "include", "genpercept_hip.h")).read()
+    ver = int(re.search(r"#define GP_ABI_VERSION (\d+)", hdr).group(1))
+    assert ver >= 3
+    for prec in ("bf16", "fp16"):
+        lib = engine.load_library(prec)
+        assert lib.gp_abi_version() == ver
+        assert lib.gp_set_precision(None, 1) == 1 and lib.gp_get_precision(None) == 0  # GP_ERR_INVALID on a null engine; native by default
+    assert C.sizeof(engine.GpTimings) == 72  # the frozen layout of ABI version 3 (no trailing sat_events)
+    assert engine.precision_of(torch.float32) == "fp32c" and engine.precision_of(torch.float16) == "fp16"
+    assert engine.precision_of(torch.bfloat16) == "bf16" and engine.precision_of(None) == "bf16"
+    assert engine.ENGINE_PRECISIONS["fp32c"] == ("bf16", 1)
+    with pytest.raises(ValueError):
+        engine.precision_of(torch.int8)
+    from genpercept_amd import GenPerceptPipeline
+    pipe = GenPerceptPipeline(unet={}, vae={}, text_encoder=np.zeros((2, 1024), np.float32), torch_dtype=torch.float32)
+    assert pipe._precision == "fp32c" and pipe.dtype == torch.float32
+    assert pipe.to(dtype=torch.float16)._precision == "fp16" and pipe.dtype == torch.float16
+
+
 def test_library_contains_gfx950_code_objects():
     from genpercept_amd import engine
     for path in engine.LIB_PATHS.values():
         blob = open(path, "rb").read()
-        assert b"gfx950" in blob and b"igemm_kernel" in blob and b"flash_attn64_kernel" in blob
+        assert b"gfx950" in blob and b"igemm_kernel" in blob and b"flash_attn64_kernel" in blob and b"flash_attn64_split_kernel" in blob and b"c_gn_apply_split_kernel" in blob
 
 
 def test_default_config_is_sd21():

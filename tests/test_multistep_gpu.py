@@ -16,7 +16,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TOL_MAP = {"bf16": 2.0e-2, "fp16": 2.5e-3, "fp32c": 1.5e-4}  # fp32c: the contract precision (fp32 storage, split-bf16 products)
+TOL_MAP = {"bf16": 1.62e-2, "fp16": 2.5e-3, "fp32c": 5e-5}  # r6: 1.25x / 1.2x the worst case measured in any round (1.3e-2 / 2.1e-3); fp32c 2.3e-5 x 2  # fp32c: the contract precision (fp32 storage, split-bf16 products)
 TORCH_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32c": torch.float32}
 SCHED = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False, steps_offset=1,
              prediction_type="v_prediction", timestep_spacing="leading")  # hf_configs/scheduler_beta_0.00085_0.012
