@@ -17,9 +17,10 @@ inside the timed region, its own cost reported as `gather_ms`.  Rank 0 prints ON
                `peak_measured` = this chip's own back-to-back-MFMA rate (gp_mfma_peak_tflops) measured in the same run.
   cpu_baseline the fp32 oracle (oracle/, a restatement: kind "port") timed on the host cores at the benched size: ONE 768x768 image --
                image 0 of the benched batch, so the same run also reports
-  parity       HIP map vs that fp32 oracle map at the benched size (mean / max |delta| on [0,1], AbsRel after the reference's least-squares
-               alignment), for the benched element type and, in `fp16`, for the fp16 library (the build inside north_star's 1e-3), which
-               is timed in the same run: `value_fp16` / `ms_per_step_fp16` (same K steps, same barriers).
+  parity       HIP map vs that fp32 oracle map at the benched size (mean / max |delta| on [0,1], rel-rms, AbsRel after the reference's least-squares
+               alignment) for every precision timed in the run: the benched bf16, the fp16 library (`value_fp16`) and the CONTRACT precision
+               (`value_fp32c`: fp32 storage + split-bf16 matrix products, what torch_dtype=float32 selects -- the build inside north_star's
+               1e-3 under both readings); `within_1e-3` = {precision: {mean_abs, rel_rms}} (same K steps, same barriers for each leg).
   stages       per-stage times from a pass with FOUR events only (profiling level 1); the per-kernel sums of `roofline` come from a second,
                per-launch-instrumented pass whose ~500 event pairs cost ~7 % and must not leak into `unet_mfma_util`.
 """
@@ -353,6 +354,28 @@ def main(argv=None, engine_factory=None, device=None):
                         traffic_note = f"null: no PMC summary under profiles/ is of this build ({bid}); newest: {seen[0]}"
             except Exception:
                 pass
+            # matrix-pipe busy fraction per kernel from the SQ counters (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ... in their own run:
+            # tools/sessions/gpu_r06_pmc.sh); like `traffic` it only counts when it was taken from THESE sources
+            mfma_busy, mfma_busy_note = None, f"null: no SQ-counter summary of this build ({bid}) under profiles/ (tools/sessions/gpu_r06_pmc.sh collects it)"
+            try:
+                import glob
+                for mf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma_summary*.json")), reverse=True):
+                    mj = json.load(open(mf))
+                    if mj.get("build_id") != bid:
+                        continue
+                    pick = {}
+                    for k, v in mj["kernels"].items():
+                        if "mfma_busy_fraction" in v and any(t in k for t in ("conv3x3_halo3", "pgemm_kernel", "flash_attn64", "flash_attn512", "igemm_kernel", "conv_img")):
+                            pick[k] = {"mfma_busy_fraction": v["mfma_busy_fraction"], "dispatches": v["dispatches"],
+                                       "valu_per_mfma_busy_cycle": v.get("valu_per_mfma_busy_cycle"), "lds_bank_conflict_cycles": v.get("SQ_LDS_BANK_CONFLICT")}
+                    halo = [(v["SQ_VALU_MFMA_BUSY_CYCLES"], v["GRBM_GUI_ACTIVE"]) for k, v in mj["kernels"].items() if "conv3x3_halo3" in k and v.get("GRBM_GUI_ACTIVE")]
+                    mfma_busy = {"dominant_kernel_family": round(sum(a for a, _ in halo) / (sum(b for _, b in halo) / 8.0 * 1024.0), 4) if halo else None,
+                                 "per_kernel": pick}
+                    mfma_busy_note = (f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs) per kernel, rocprofv3 --pmc, same build ({bid}), "
+                                      f"profiles/{os.path.basename(mf)}")
+                    break
+            except Exception:
+                pass
             roofline = {"bound": "mfma", "kernel": f"conv3x3_halo3_kernel (3x3 stride-1 convs of the large maps, v_mfma_f32_16x16x32_{'f16' if args.precision == 'fp16' else 'bf16'})",
                         "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                         "peak_measured": round(peak_meas, 1) if peak_meas and peak_meas > 0 else None,
@@ -363,6 +386,7 @@ def main(argv=None, engine_factory=None, device=None):
                         # `executed_achieved` is the rate of the arithmetic actually issued (what the matrix pipe sustains), `achieved` the useful-work rate
                         "executed_achieved": round(halo_exec / (tm["ms_halo"] * 1e-3) / 1e12, 2), "executed_frac": round(halo_exec / (tm["ms_halo"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                         "traffic": traffic, "traffic_note": traffic_note,
+                        "mfma_busy_fraction": mfma_busy, "mfma_busy_note": mfma_busy_note,
                         "launches": tm["n_halo"], "flops_per_launch_avg": tm["flops_halo"] / max(tm["n_halo"], 1),
                         "avg_launch_ms": tm["ms_halo"] / max(tm["n_halo"], 1), "sum_ms": round(tm["ms_halo"], 3),
                         "family_kernel": "conv3x3_halo3_kernel + pgemm_kernel + igemm_kernel (every conv / linear launch)",

@@ -374,9 +374,38 @@ __global__ __launch_bounds__(256) void c_softmax_split_kernel(const float* __res
         }
     }
 }
-bool c_softmax_split_supported(int ld) { return (ld & 3) == 0 && ld <= 256 * 4 * CS_MAXV; }
+// the same for rows too long for the register-resident form (maps beyond 128 x 128 latents): three passes over the row (L2-hot), same arithmetic
+__global__ __launch_bounds__(256) void c_softmax_split_long_kernel(const float* __restrict__ in, h16_t* __restrict__ out, int T, int ld, float scale) {
+    __shared__ float red[8];
+    const long long row = blockIdx.x;
+    const float* x = in + row * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = -3.0e38f;
+    for (int c = tid; c < T; c += 256) m = fmaxf(m, x[c] * scale);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int c = tid; c < T; c += 256) sum += __expf(x[c] * scale - m);
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.f / ((red[4] + red[5]) + (red[6] + red[7]));
+    h16_t* orow = out + row * 3 * ld;
+    for (int c = tid * 2; c < ld; c += 512) {
+        const float p0 = c < T ? __expf(x[c] * scale - m) * inv : 0.f, p1 = c + 1 < T ? __expf(x[c + 1] * scale - m) * inv : 0.f;
+        const unsigned h = pack_h16x2(p0, p1), l = pack_h16x2(p0 - h16_lo(h), p1 - h16_hi(h));
+        *(unsigned*)(orow + c) = h;
+        *(unsigned*)(orow + ld + c) = l;
+        *(unsigned*)(orow + 2 * ld + c) = h;
+    }
+}
+bool c_softmax_split_supported(int ld) { return (ld & 3) == 0; }
 void launch_c_softmax_split(const float* in, h16_t* out, long long rows, int T, int ld, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(c_softmax_split_kernel, dim3((unsigned)rows), dim3(256), 0, s, in, out, T, ld, scale);
+    if (ld <= 256 * 4 * CS_MAXV) hipLaunchKernelGGL(c_softmax_split_kernel, dim3((unsigned)rows), dim3(256), 0, s, in, out, T, ld, scale);
+    else hipLaunchKernelGGL(c_softmax_split_long_kernel, dim3((unsigned)rows), dim3(256), 0, s, in, out, T, ld, scale);
 }
 
 // O fp32 [B*heads][T][hd] -> split A-order [B*T][3 C] (C = heads * hd): the input of to_out

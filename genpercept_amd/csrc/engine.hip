@@ -1113,7 +1113,7 @@ struct gp_engine {
             pool.release(qk_hi); pool.release(qk_lo); pool.release(vt_hi); pool.release(vt_lo);
             return a;
         }
-        if (!c_softmax_split_supported(Tpad)) throw std::invalid_argument("contract precision: at most 16384 tokens per unfused attention map");
+        if (!c_softmax_split_supported(Tpad)) throw std::logic_error("attention_c: Tpad");
         h16_t* Qs = (h16_t*)pool.alloc((size_t)Z * T * 3 * hd * sizeof(h16_t));
         h16_t* Ks = (h16_t*)pool.alloc((size_t)Z * T * 3 * hd * sizeof(h16_t));
         h16_t* Vts = (h16_t*)pool.alloc((size_t)Z * hd * 3 * Tpad * sizeof(h16_t));

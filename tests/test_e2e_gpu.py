@@ -455,6 +455,35 @@ def test_vae_attention_large_norm_logits(hw, rms, fused, metric_log, monkeypatch
     assert bad <= 5e-3 and rel_rms(out, ref) <= 3.6e-2
 
 
+@pytest.mark.parametrize("hw", [(12, 10), (130, 128)])
+def test_vae_attention_contract_precision(hw, metric_log):
+    """The VAE mid-block attention alone (gp_vae_mid_attention) in the contract precision: the unfused split-operand path (head split -> batched logits GEMM with
+    fp32 logits in HBM -> row softmax -> batched P.V GEMM -> merge; contract.hip) against the fp32 oracle, on a small map (register-resident softmax rows) and on
+    one with more than 16384 tokens (130 x 128 = 16640: the three-pass long-row softmax kernel)."""
+    from genpercept_amd.engine import Engine
+    from oracle import sd21 as osd
+    uc, vc = osd.UNetCfg.tiny(), osd.VAECfg()
+    vsd = osd.synth_state_dict(osd.vae_manifest(vc), 21)
+    p = "decoder.mid_block.attentions.0"
+    for n in ("to_q", "to_k"):  # logits of a few units: a softmax with structure, not a uniform average
+        vsd[f"{p}.{n}.weight"] = vsd[f"{p}.{n}.weight"] * 3.0
+    g = torch.Generator().manual_seed(hw[0])
+    x = torch.randn(1, 512, hw[0], hw[1], generator=g)
+    with torch.no_grad():
+        ref = osd.vae_mid_attention(x, vsd, p, vc.norm_num_groups, vc.norm_eps)
+    eng = Engine(0, uc, vc, None, precision="fp32c")
+    try:
+        eng.load_state_dict("vae", vsd)
+        eng.finalize()
+        out = eng.vae_mid_attention(x.cuda(), decoder=True).cpu()
+    finally:
+        eng.close()
+    # the attention branch alone (the residual x dominates the sum)
+    r = ((out - ref).pow(2).mean().sqrt() / (ref - x).pow(2).mean().sqrt()).item()
+    metric_log(f"vae_attn_contract{hw}", rel_rms_of_branch=r, max_abs=(out - ref).abs().max().item())
+    assert torch.isfinite(out).all() and r <= 2e-4, r
+
+
 def test_full_size_768_properties_dpt_head(metric_log):
     """BASELINE.json configs[3] (DPT head at 768x768, full widths, batch 4) pinned by the same size-independent properties: bitwise
     determinism, batch-slot and batch-size independence, per-image min-max normalisation (genpercept_pipeline.py:480-482)."""
