@@ -486,7 +486,8 @@ def main(argv=None, engine_factory=None, device=None):
     if rank == 0:
         head_name = "DPT disparity head" if dpt else f"{args.mode} head"
         cfg_idx = 3 if dpt else (1 if args.mode == "depth" else 2)
-        line = {"metric": f"images/sec at 768x768 bf16 ({'depth' if not dpt and args.mode == 'depth' else head_name})", "value": round(value, 3), "unit": "images/sec", "n_gpus": n_gpus,
+        dt_label = "bf16" if args.precision == "bf16" else f"{args.precision} (NOT BASELINE.json's dtype: --precision {args.precision})"
+        line = {"metric": f"images/sec at 768x768 {dt_label} ({'depth' if not dpt and args.mode == 'depth' else head_name})", "value": round(value, 3), "unit": "images/sec", "n_gpus": n_gpus,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                 # per-step durations from one event per step (rank 0's stream) and the clock / power the timed region ran at: resolution below the
                 # pool's box-to-box spread (ms_per_step stays the contract's wall-clock figure, max over ranks)

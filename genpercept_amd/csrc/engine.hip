@@ -796,7 +796,7 @@ struct gp_engine {
         const bool halo = conv_uses_halo(p, hint);
         tm.flops_igemm += fl;
         tm.n_igemm++;
-        if (halo) { tm.flops_halo += fl; tm.n_halo++; flops_halo_exec += conv_halo_uses_phases(p) ? fl * (4.0 / 9.0) : fl; }
+        if (halo) { tm.flops_halo += fl; tm.n_halo++; flops_halo_exec += (conv_halo_uses_phases(p) ? fl * (4.0 / 9.0) : fl) * (contract ? 3.0 : 1.0); }  // (executed: the tripled K counts)
         if (prof >= 3) {
             const char* path = conv_uses_halo(p, hint) ? (p.in_scale ? (p.in_silu ? "halo+gn+silu" : "halo+gn") : "halo") : igemm_uses_pgemm(p, hint) ? "pgemm" : "igemm";
             mark(std::string(p.ks == 3 ? (p.ups ? "conv3x3up " : (p.stride == 2 ? "conv3x3s2 " : "conv3x3 ")) : (p.batch > 1 ? "bgemm " : "gemm ")) + path + " M=" + std::to_string(p.M) +
