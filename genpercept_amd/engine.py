@@ -13,7 +13,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # One library per 16-bit element type (csrc/common.h): identical C-ABI, bf16 or IEEE fp16 activations / weights / MFMA operands.
 # "bf16" is the default (BASELINE.json's dtype); "fp16" is the reference's half precision (run.py --half_precision), 8x finer
-# rounding at the same speed -- the build that meets north_star's 1e-3 tolerance (profiles/r02_precision_ablation.json).
+# rounding at the same speed (inside north_star's 1e-3 under the mean-absolute reading on benign weights only); the build that meets the
+# tolerance under both readings is the contract precision below.
 LIB_PATHS = {"bf16": os.path.join(_HERE, "lib", "libgenpercept_hip.so"), "fp16": os.path.join(_HERE, "lib", "libgenpercept_hip_f16.so")}
 LIB_PATH = LIB_PATHS["bf16"]
 ELT_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16}

@@ -1,16 +1,17 @@
 """Full-size parity against the LIVE fp32 oracle (oracle/), full SD2.1 widths, the reference's default processing resolution
 (genpercept_pipeline.py:106 `default_processing_resolution = 768`; call shape run.py:420-432): BASELINE.json configs[1] (depth), configs[2]
-(normal), configs[3] (DPT disparity head) at 768x768 with both element-type libraries, configs[0]'s 384x384 image through the pipeline
-surface, and configs[4]'s rank-local shard (8 images per GPU).
+(normal), configs[3] (DPT disparity head) at 768x768 with all three engine precisions -- bf16 library, fp16 library, and the contract precision "fp32c"
+(fp32 storage + split-bf16 matrix products; gp_set_precision / torch_dtype=float32) --, configs[0]'s 384x384 image through the pipeline surface (fp32 = the
+contract precision), and configs[4]'s rank-local shard (8 images per GPU).
 
-Tolerance (north_star: "within 1e-3 rel of the reference"), measured under BOTH readings for both libraries:
-  mean_abs = mean |HIP - oracle| on the [0,1] map   -- the contract metric: the fp16 library (the reference's own half precision,
-             run.py:273-281) is gated AT 1e-3; the bf16 library (BASELINE.json's dtype) at 1.5x its simulated operand-rounding floor
-             (profiles/r04_precision_ablation.json: 3.2e-3 depth / 5.1e-3 normal), a regression gate -- it is outside the contract and
-             bench.py says so in its own line.
-  rel_rms  = rms(HIP - oracle) / rms(oracle - mean(oracle)) -- the deviation relative to the map's own signal.  NO engine with 16-bit
-             MFMA operands reaches 1e-3 here (simulated floor with fp16 operands and everything else fp32: 3.4e-3 at 128 px):
-             gated as a regression gate only (RELRMS_TOL) and logged (gpurun_out/parity_log.jsonl).
+Tolerance (north_star: "within 1e-3 rel of the reference"), measured under BOTH readings for every precision:
+  mean_abs = mean |HIP - oracle| on the [0,1] map
+  rel_rms  = rms(HIP - oracle) / rms(oracle - mean(oracle)) -- the deviation relative to the map's own signal.
+  fp32c  inside 1e-3 under both (measured 4.6e-6 / 5.5e-5): test_contract_1e3 asserts it, the regression gates sit at ~2x the measured values.
+  fp16   inside 1e-3 under mean_abs only (gated AT 1e-3); rel_rms 5e-3: no engine with single 16-bit MFMA operands reaches 1e-3 there (simulated floor with
+         fp16 operands and everything else fp32: 3.4e-3 at 128 px) -- strict xfails in test_contract_1e3, regression gates at 1.25x measured.
+  bf16   BASELINE.json's dtype, the benched default: outside the tolerance under both readings (3.35e-3 / 3.96e-2), bench.py says so in its own line;
+         strict xfails in test_contract_1e3, regression gates at 1.25x measured (r6; shown to fail when one kernel's rounding doubles).
 
 The oracle runs once per module (about 12 s of CPU at 768x768 on the GPU box's host cores: encoder, ONE UNet pass that returns the sample
 and the multi-level features, the 3-channel decode, the DPT head)."""
