@@ -350,6 +350,33 @@ def test_conv_upsample_x2_phase_kernel_groupnorm_statistics(case, metric_log):
     assert e_sc < 2e-4 and e_sh < 2e-4, (e_sc, e_sh)
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 128, 128, 0), (1, 40, 24, 192, 320, 0), (4, 96, 96, 512, 512, 1), (1, 50, 70, 64, 200, 0), (2, 48, 48, 640, 640, 1)])
+def test_conv_halo3_fp32_rows_epilogue(case, metric_log, monkeypatch):
+    """conv3x3_halo3_kernel<..., HALO_F32O> (r6, the contract precision's conv epilogue: fp32 rows out instead of 16-bit): same operands as the 16-bit kernel, so the
+    result is the fp32 accumulator itself -- against fp32 torch on identical 16-bit operands it must agree to fp32 summation-order noise, for 16-row and (case[5] = 1:
+    forced) 12-row tiles, ragged tiles and channel counts that are not multiples of 128."""
+    e = _eng()
+    b, h, w, cin, cout, tr3 = case
+    if tr3:
+        monkeypatch.setenv("GENPERCEPT_IGEMM_DBG", str(1 << 20))
+    g = torch.Generator().manual_seed(cin + cout + h + 5)
+    x = rbf(torch.randn(b, cin, h, w, generator=g))
+    wt = rbf(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1).float()
+    d = _dev()
+    y = e.conv2d(e.to_nhwc_bf16(x.to(d)), e.pack_weight(wt, device=d), bias.to(d), cout, 3, out_fp32=True, tile=5)
+    assert y.dtype == torch.float32
+    out = y.permute(0, 3, 1, 2).cpu()
+    err = (out - ref).abs()
+    rel = (err.max() / ref.abs().max()).item()
+    metric_log(f"conv_halo3_f32o{case}", rel_max=rel, mean_err=err.mean().item())
+    assert torch.isfinite(out).all() and rel <= 2e-6 * math.sqrt(cin * 9 / 64), rel  # fp32 accumulation over K = 9 Cin
+    # the 16-bit kernel's output is this tensor rounded once
+    y16 = e.conv2d(e.to_nhwc_bf16(x.to(d)), e.pack_weight(wt, device=d), bias.to(d), cout, 3, tile=5)
+    assert torch.equal(y16.float().cpu(), y.cpu().to(e.act_dtype()).float()), "16-bit and fp32-row epilogues disagree beyond the final rounding"
+
+
 @pytest.mark.parametrize("case", [(2, 32, 32, 128, 128, False, True), (1, 40, 24, 320, 192, False, True), (2, 16, 16, 64, 128, False, False),
                                   (1, 12, 16, 256, 128, True, True), (1, 17, 21, 960, 64, False, True), (1, 24, 24, 2560, 128, False, True),
                                   (4, 48, 48, 1920, 128, False, True)])
