@@ -2391,6 +2391,25 @@ gp_status gp_flash_attention(const void* q, const void* k, const void* vt, void*
     } catch (...) { return GP_ERR_HIP; }
 }
 
+gp_status gp_flash_attention_split(const float* qkv, int ld, void* out_split, int B, int T, int heads, void* stream) {
+    if (!qkv || !out_split || B < 1 || T < 1 || heads < 1 || ld < 3 * heads * 64 || GP_F16) return GP_ERR_INVALID;
+    try {
+        KernelEntry lk;
+        const int C = heads * 64, Tpad = (T + 63) / 64 * 64;
+        const size_t n_qk = (size_t)B * T * 2 * C, n_vt = (size_t)B * heads * 64 * Tpad;
+        h16_t* buf = nullptr;
+        HIPCHK(hipMalloc((void**)&buf, (2 * n_qk + 2 * n_vt) * sizeof(h16_t)));
+        h16_t *qk_hi = buf, *qk_lo = buf + n_qk, *vt_hi = buf + 2 * n_qk, *vt_lo = vt_hi + n_vt;
+        launch_c_qkv_planes(qkv, ld, qk_hi, qk_lo, vt_hi, vt_lo, B, T, Tpad, heads, 64, (hipStream_t)stream);
+        launch_flash_attn64_split(qk_hi, qk_lo, vt_hi, vt_lo, (h16_t*)out_split, B, T, heads, 2 * C, Tpad, (hipStream_t)stream);
+        const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        (void)hipFree(buf);
+        if (e != hipSuccess) return GP_ERR_HIP;
+        HIPCHK(hipGetLastError());
+        return GP_OK;
+    } catch (...) { return GP_ERR_HIP; }
+}
+
 gp_status gp_flash_attention_hd512(const void* q, const void* k, const void* vt, void* out, int B, int T, int ldq, int ldk, int Tpad, int ldo,
                                    float scale, int ncu, void* stream) {
     if (!q || !k || !vt || !out || (Tpad % 64) || Tpad < T || B < 1 || T < 1 || ncu < 0) return GP_ERR_INVALID;

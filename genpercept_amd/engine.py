@@ -130,6 +130,7 @@ SYMBOLS = {
     "gp_groupnorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "gp_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "gp_flash_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "gp_flash_attention_split": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     "gp_flash_attention_hd512": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "gp_cross_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "gp_resize_max_res_size": (None, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
@@ -621,6 +622,21 @@ def flash_attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: i
     if st != GP_OK:
         raise RuntimeError(f"gp_flash_attention failed ({st})")
     return out
+
+
+def flash_attention_split(qkv: torch.Tensor, batch: int, tokens: int, heads: int) -> torch.Tensor:
+    """qkv fp32 [B*T, 3C] (q | k | v) -> the attention result as fp32 [B*T, C], reassembled (hi + lo) from the split operand gp_flash_attention_split writes
+    (contract precision; bf16 library)."""
+    lib = load_library("bf16")
+    m, c3 = qkv.shape
+    c = heads * 64
+    assert m == batch * tokens and c3 >= 3 * c and qkv.dtype == torch.float32
+    out = torch.empty((m, 3 * c), dtype=torch.bfloat16, device=qkv.device)
+    st = lib.gp_flash_attention_split(qkv.data_ptr(), qkv.stride(0), out.data_ptr(), batch, tokens, heads, _stream_ptr())
+    if st != GP_OK:
+        raise RuntimeError(f"gp_flash_attention_split failed ({st})")
+    assert torch.equal(out[:, :c], out[:, 2 * c:])  # [hi | lo | hi]
+    return out[:, :c].float() + out[:, c:2 * c].float()
 
 
 def cross_attention(q: torch.Tensor, kc: torch.Tensor, vc: torch.Tensor) -> torch.Tensor:

@@ -253,6 +253,11 @@ gp_status gp_groupnorm(const void* x, void* y, const float* gamma, const float* 
 gp_status gp_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C, float eps, void* stream);
 gp_status gp_flash_attention(const void* q, const void* k, const void* vt, void* out, int B, int T, int heads, int ldq, int ldk, int Tpad, int ldo,
                              void* stream);
+/* Contract precision (gp_set_precision; csrc/contract.hip, attention.hip: flash_attn64_split_kernel): the UNet's self-attention core over SPLIT operands.
+ * qkv: DEVICE fp32 [B*T][ld] with q | k | v at columns 0 | C | 2C (C = heads * 64; the output of the stacked attn1.to_q / to_k / to_v projection);
+ * out_split: DEVICE 16-bit [B*T][3C] = the A-order split operand [hi | lo | hi] of softmax(q k^T / 8) v that the output projection reads (value = hi + lo).
+ * bf16 library only.  Synchronises the stream (test entry point). */
+gp_status gp_flash_attention_split(const float* qkv, int ld, void* out_split, int B, int T, int heads, void* stream);
 /* The VAE mid-block attention's core (one head, head_dim 512; diffusers Attention inside AutoencoderKL, call sites
  * genpercept_pipeline.py:500-501,521-522), fused: softmax(scale * q k^T) v with scores and probabilities kept on the CU.  q, k: [B][T][ld]
  * (512 channels), vt: [B][512][Tpad] zero beyond T, out [B][T][ldo].  ncu: persistent workgroups to size the launch for (0 = the device's CU

@@ -86,6 +86,7 @@ assert lib.gp_set_precision(hdl, 7) != 0 and lib.gp_set_precision(None, 1) != 0 
 assert lib.gp_conv2d_up2_stats(None, None, None, None, None, None, 1, 16, 16, 64, 64, None, None, 32, 1e-6, None, None, None) != 0
 assert lib.gp_pack_weight_phases(x32.ctypes.data, -1, 4, 64, x32.ctypes.data) != 0 and lib.gp_pack_weight_phases(x32.ctypes.data, 8, 0, 64, x32.ctypes.data) != 0
 assert lib.gp_pack_weight(x32.ctypes.data, 0, 4, 3, 64, 0, x32.ctypes.data) != 0
+assert lib.gp_flash_attention_split(None, 192, None, 1, 64, 1, None) != 0 and lib.gp_flash_attention_split(x32.ctypes.data, 100, x32.ctypes.data, 1, 64, 1, None) != 0   # (ld < 3 C)
 ev = C.c_longlong(-1)
 lib.gp_saturation_events(hdl, C.byref(ev), 1)
 lib.gp_destroy(hdl)

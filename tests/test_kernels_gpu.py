@@ -350,6 +350,26 @@ def test_conv_upsample_x2_phase_kernel_groupnorm_statistics(case, metric_log):
     assert e_sc < 2e-4 and e_sh < 2e-4, (e_sc, e_sh)
 
 
+@pytest.mark.parametrize("case", [(2, 256, 5), (1, 1200, 10), (3, 100, 2), (1, 4800, 5), (2, 64, 20), (1, 37, 1)])
+def test_flash_attention_split_operands(case, metric_log):
+    """flash_attn64_split_kernel (+ c_qkv_planes): softmax(q k^T / 8) v per head over hi / lo bf16 pieces of fp32 q, k, v (three MFMAs per product, fp32 softmax, P split
+    in registers), against fp32 torch attention on the SAME fp32 inputs; token counts that are / are not multiples of the 64-key tile and of the 128-query block."""
+    from genpercept_amd import engine as e
+    if e.act_dtype() != torch.bfloat16:
+        pytest.skip("the contract precision lives in the bf16 library")
+    b, t, heads = case
+    c = heads * 64
+    g = torch.Generator().manual_seed(t + heads)
+    qkv = torch.randn(b * t, 3 * c, generator=g) * torch.tensor([1.5] * c + [1.5] * c + [1.0] * c)  # logits of a few units: a softmax with structure
+    q, k, v = (qkv[:, i * c:(i + 1) * c].reshape(b, t, heads, 64).transpose(1, 2).double() for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v).transpose(1, 2).reshape(b * t, c).float()
+    out = e.flash_attention_split(qkv.to(_dev()), b, t, heads).cpu()
+    err = (out - ref).abs()
+    rel = (err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    metric_log(f"flash_attn64_split{case}", rel_rms=rel, max_abs=err.max().item())
+    assert torch.isfinite(out).all() and rel <= 3e-5, rel
+
+
 @pytest.mark.parametrize("case", [(2, 32, 32, 128, 128, 0), (1, 40, 24, 192, 320, 0), (4, 96, 96, 512, 512, 1), (1, 50, 70, 64, 200, 0), (2, 48, 48, 640, 640, 1)])
 def test_conv_halo3_fp32_rows_epilogue(case, metric_log, monkeypatch):
     """conv3x3_halo3_kernel<..., HALO_F32O> (r6, the contract precision's conv epilogue: fp32 rows out instead of 16-bit): same operands as the 16-bit kernel, so the
