@@ -339,3 +339,25 @@ def test_crosscheck_fixture_is_current():
     for k in ("latent", "unet", "dec", "feat0", "feat1", "feat2", "feat3"):
         assert fx[k].shape == cur[k].shape and rel(cur[k].astype(F64), fx[k].astype(F64)) < 1e-5, k
     assert mod.verify_fixture(os.path.join(root, "tests", "golden", "crosscheck_tiny.npz"), 2e-4) == 2  # no diffusers here: says so, never "OK"
+
+
+@pytest.mark.parametrize("heads,tq,tk", [(1, 7, 7), (4, 9, 5), (5, 6, 2)])
+def test_attention_matches_torch_multihead_attention(heads, tq, tk):
+    """An implementation this repository did not write: torch.nn.MultiheadAttention (identity projections, zero biases) and
+    F.scaled_dot_product_attention compute softmax(q k^T / sqrt(head_dim)) v with heads as CONTIGUOUS channel slices -- the convention diffusers'
+    attention processors share (Appendix B.4).  The oracle's _attention must agree with both."""
+    c = 64 * heads
+    g = torch.Generator().manual_seed(heads * 100 + tq)
+    q, k, v = torch.randn(2, tq, c, generator=g), torch.randn(2, tk, c, generator=g), torch.randn(2, tk, c, generator=g)
+    out = osd._attention(q, k, v, heads)
+    mha = torch.nn.MultiheadAttention(c, heads, bias=True, batch_first=True)
+    with torch.no_grad():
+        mha.in_proj_weight.copy_(torch.cat([torch.eye(c)] * 3))
+        mha.in_proj_bias.zero_()
+        mha.out_proj.weight.copy_(torch.eye(c))
+        mha.out_proj.bias.zero_()
+        ref, _ = mha(q, k, v, need_weights=False)
+        hd = c // heads
+        sdpa = torch.nn.functional.scaled_dot_product_attention(q.view(2, tq, heads, hd).transpose(1, 2), k.view(2, tk, heads, hd).transpose(1, 2),
+                                                                v.view(2, tk, heads, hd).transpose(1, 2)).transpose(1, 2).reshape(2, tq, c)
+    assert rel(_np(out), _np(ref)) < TOL and rel(_np(out), _np(sdpa)) < TOL
