@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--res", type=int, default=768)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32c"])
     ap.add_argument("--iters", type=int, default=5)
     a = ap.parse_args()
     from genpercept_amd import config as gc
