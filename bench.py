@@ -414,7 +414,7 @@ def main(argv=None, engine_factory=None, device=None):
             out0_f16 = o16[0].float().cpu()
         fp16 = {"value_fp16": round(images / el16, 3), "ms_per_step_fp16": round(el16 / args.steps * 1e3, 3),
                 "ms_per_step_fp16_min": timed.stats.get("ms_per_step_min"), "ms_per_step_fp16_median": timed.stats.get("ms_per_step_median")}
-        if rank == 0:  # the chip's own back-to-back-MFMA rate with fp16 operands (the bf16 figure is roofline.peak_measured): same instruction
+        if rank == 0 and dev.type == "cuda":  # the chip's own back-to-back-MFMA rate with fp16 operands (the bf16 figure is roofline.peak_measured): same instruction
             pk16 = ge.mfma_peak_tflops(local_rank, "fp16")  # count, lower sustained clock -- the guide's micro-benchmarks show the same 6-9 % gap
             fp16["peak_measured_fp16"] = round(pk16, 1) if pk16 and pk16 > 0 else None
         if not args.no_profile:

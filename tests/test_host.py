@@ -632,6 +632,43 @@ sys.exit(0 if ok else 1)
 """
 
 
+def test_bench_single_rank_precision_legs_with_a_stub_engine(capsys):
+    """bench.py's N = 1 control flow around the engine -- the benched bf16 leg, then the fp16 library, then the contract precision, each timed with the same
+    steps -- executed on CPU with a stub engine: ONE JSON line carrying value / value_fp16 / value_fp32c, and no profile / parity fields when those legs are off."""
+    import json
+    import time
+    import bench
+    built = []
+
+    class Stub:
+        def __init__(self, local_rank, precision):
+            built.append(precision)
+            self.precision, self.calls, self.closed = precision, 0, False
+
+        def infer(self, rgb, mode):
+            assert not self.closed and rgb.dtype == torch.uint8 and tuple(rgb.shape) == (4, 3, 32, 32)
+            self.calls += 1
+            time.sleep(0.005)  # (a step long enough for the 3-decimal ms_per_step of the line to resolve it)
+            return torch.full((4, 1, 32, 32), {"bf16": 0.25, "fp16": 0.5, "fp32c": 0.75}[self.precision])
+
+        def close(self):
+            self.closed = True
+
+    line = bench.main(["--gpus", "1", "--steps", "2", "--warmup", "1", "--res", "32", "--no-cpu", "--no-profile"], engine_factory=Stub, device="cpu")
+    printed = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert printed == line and built == ["bf16", "fp16", "fp32c"]
+    assert line["n_gpus"] == 1 and line["dtype"] == "bf16" and line["metric"].startswith("images/sec at 768x768 bf16")
+    for k in ("value", "value_fp16", "value_fp32c", "ms_per_step_fp16", "ms_per_step_fp32c"):
+        assert line[k] > 0, k
+    assert line["roofline"] is None and line["cpu_baseline"] is None and line["parity"] is None and line["value_within_tolerance"] is None
+    assert abs(line["value"] - 4 * 2 / (line["ms_per_step"] * 2e-3)) <= 1e-2 * line["value"]
+    # a non-default precision is labelled as such and runs no other leg
+    built.clear()
+    line = bench.main(["--gpus", "1", "--steps", "1", "--warmup", "0", "--res", "32", "--no-cpu", "--no-profile", "--precision", "fp32c"], engine_factory=Stub, device="cpu")
+    capsys.readouterr()
+    assert built == ["fp32c"] and line["dtype"] == "fp32c" and "NOT BASELINE" in line["metric"] and "value_fp16" not in line and "value_fp32c" not in line
+
+
 def test_bench_multi_gpu_path_world_size_2_gloo(tmp_path):
     """bench.py's own N > 1 code (init_process_group from the torchrun environment, WORLD_SIZE == --gpus check, contiguous shards, the timed
     loop with barrier + max over ranks, the in-step result gather to rank 0, the gather-alone leg, ONE JSON line from rank 0) executed on
